@@ -1,0 +1,161 @@
+/*
+ * mjx.h -- C ABI of libmjx.so: the MI355X (gfx950) implementation of mjrl's
+ * NPG / TRPO policy-update hot path, GAE and baseline fitting.
+ *
+ * The reference (aravindr93/mjrl) is pure Python and has no FFI of its own; the
+ * seam this library sits behind is Agent.train_from_paths + process_samples.* +
+ * Baseline.{fit,predict}.  Each entry point below names the reference code it
+ * replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 = mjx error, >0 = hipError_t;
+ *     mjx_last_error() returns a thread-local message for the last failure.
+ *   - all `const float*` / `double*` DATA pointers are DEVICE pointers unless the
+ *     parameter name ends in `_host`.  The caller owns them (e.g. torch tensors);
+ *     the context owns only its internal workspace.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *     work is enqueued asynchronously; nothing synchronises unless stated.
+ *   - flat parameter order = [W1 (h1 x n) row-major, b1, W2 (h2 x h1), b2, ...,
+ *     W_out (m x h_last), b_out, log_std (m)]
+ *     (mjrl/policies/gaussian_mlp.py:37,50-52,60-63).
+ *   - transforms are packed as [in_shift(n), in_scale(n), out_shift(m), out_scale(m)]
+ *     (mjrl/utils/fc_network.py:27-37).
+ *   - one context per process / per GPU; calls on one context are not re-entrant.
+ */
+#ifndef MJX_H
+#define MJX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mjx_ctx mjx_ctx;
+
+#define MJX_OK 0
+#define MJX_ERR_ARG (-1)
+#define MJX_ERR_STATE (-2)
+#define MJX_ERR_UNSUPPORTED (-3)
+#define MJX_ERR_NOGPU (-4)
+
+/* ---- lifecycle ----------------------------------------------------------- */
+const char* mjx_last_error(void);
+int mjx_version(void);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int mjx_device_count(void);
+
+/* Create a context for a tanh-MLP Gaussian policy obs(n) -> hidden[...] -> act(m)
+ * on HIP device `device`.  Replaces the torch modules built in
+ * mjrl/policies/gaussian_mlp.py:8-56 (MLP) and gaussian_linear.py:9-56
+ * (n_hidden = 0).  max_samples bounds the per-call batch (workspace sizing for
+ * the layer-wise path); pass 0 to size lazily at mjx_bind_batch. */
+int mjx_create(mjx_ctx** out, int device, int n, int m, const int* hidden, int n_hidden);
+void mjx_destroy(mjx_ctx* ctx);
+/* number of flat parameters d (gaussian_mlp.py:53) */
+int64_t mjx_num_params(const mjx_ctx* ctx);
+/* 1 if the fused single-kernel path serves this network shape, 0 if the
+ * layer-wise path does */
+int mjx_uses_fused_path(const mjx_ctx* ctx);
+
+/* ---- plain device-memory helpers (so a C / cgo / JNI caller needs no torch) -- */
+int mjx_malloc(void** dev_ptr, int64_t bytes);
+int mjx_free(void* dev_ptr);
+int mjx_memcpy_h2d(void* dst_dev, const void* src_host, int64_t bytes, void* stream);
+int mjx_memcpy_d2h(void* dst_host, const void* src_dev, int64_t bytes, void* stream);
+int mjx_stream_sync(void* stream);
+
+/* ---- binding the inputs of one update ----------------------------------- */
+/* The (N_local, n) observation, (N_local, m) action and (N_local) advantage
+ * blocks of THIS rank's trajectory shard, fp32 row-major -- the arrays
+ * process_paths concatenates (mjrl/algos/batch_reinforce.py:178-185).
+ * N_global = total samples over all ranks (means are taken over N_global).
+ * act / adv may be NULL when only mjx_fvp is used. */
+int mjx_bind_batch(mjx_ctx* ctx, const float* obs, const float* act, const float* adv,
+                   int64_t N_local, int64_t N_global);
+/* theta_new / theta_old: flat parameter vectors (d floats each) of policy.model /
+ * policy.old_model (+log_std); tr_new / tr_old: packed transforms (2n+2m floats)
+ * or NULL for identity.  old_is_new != 0 asserts both describe the same function
+ * (always true at entry to train_from_paths, gaussian_mlp.py:44-45, npg_cg.py:142). */
+int mjx_bind_policy(mjx_ctx* ctx, const float* theta_new, const float* theta_old,
+                    const float* tr_new, const float* tr_old, int old_is_new);
+
+/* ---- K1: CPI surrogate + vanilla policy gradient ------------------------- */
+/* grad_out[d] = sum over local samples of d/dtheta_new [LR_i * adv_i] / N_global
+ * (BatchREINFORCE.flat_vpg, batch_reinforce.py:54-58);
+ * scal_out[0] = sum_i LR_i*adv_i (local, NOT divided; CPI_surrogate :40-46),
+ * scal_out[1] = number of local samples.  scal_out is 4 doubles. */
+int mjx_surr_vpg(mjx_ctx* ctx, float* grad_out, double* scal_out, void* stream);
+
+/* ---- K2: Fisher-vector product ------------------------------------------- */
+/* out[d] = local share of (Hessian of mean_kl wrt theta_new at theta_new==theta_old) * v,
+ * WITHOUT the damping term (NPG.HVP, mjrl/algos/npg_cg.py:62-81 minus `regu_coef*vector`).
+ * Summing `out` over ranks gives the full product.  Requires old_is_new. */
+int mjx_fvp(mjx_ctx* ctx, const float* v, float* out, void* stream);
+
+/* ---- K3: surrogate + KL evaluation (no gradient) ------------------------- */
+/* scal_out[0] = sum_i LR_i*adv_i, scal_out[1] = sum_i KL_i(new||old) (local sums,
+ * divide by N_global after the cross-rank sum) -- CPI_surrogate + kl_old_new,
+ * batch_reinforce.py:40-52; the four post-step forwards of npg_cg.py:140-141 and
+ * the TRPO line search trpo.py:107-126. */
+int mjx_eval_surr_kl(mjx_ctx* ctx, double* scal_out, void* stream);
+
+/* ---- K4: conjugate gradient (mjrl/utils/cg_solve.py:3-22) ----------------- */
+/* Optional cross-rank sum hook, called on the stream between the local FVP and
+ * the CG vector update (buf holds `count` floats).  NULL = single rank. */
+typedef int (*mjx_allreduce_fn)(void* user, float* buf, int64_t count, void* stream);
+/* x_out = CG(A, b) with A p = allreduce(mjx_fvp(p)) + damping*p, x0 = 0 (the
+ * reference ignores its x_0 argument), `iters` iterations, early stop once
+ * r.r < tol (the remaining launches become no-ops on device: no host sync).
+ * Also writes bdotx_out[0] = b . x  (double) for the step-size rule. */
+int mjx_cg_solve(mjx_ctx* ctx, const float* b, int iters, float damping, double tol,
+                 float* x_out, double* bdotx_out, mjx_allreduce_fn allreduce, void* user, void* stream);
+/* the three pieces, for callers that interleave their own collective: */
+int mjx_cg_init(mjx_ctx* ctx, const float* b, void* stream);
+const float* mjx_cg_p(mjx_ctx* ctx);                       /* current search direction (device) */
+int mjx_cg_step(mjx_ctx* ctx, const float* Ap_nodamp, float damping, double tol, void* stream);
+int mjx_cg_finish(mjx_ctx* ctx, const float* b, float* x_out, double* bdotx_out, void* stream);
+
+/* theta_out = theta + alpha * x, then log_std = max(log_std, min_log_std)
+ * (npg_cg.py:137-139 + gaussian_mlp.py:73-75). */
+int mjx_apply_step(mjx_ctx* ctx, const float* theta, const float* x, float alpha,
+                   float min_log_std, float* theta_out, void* stream);
+
+/* ---- K5: returns / GAE over ragged trajectories --------------------------- */
+/* y[t] = x[t] + gamma*y[t+1] within each trajectory [offsets[i], offsets[i+1]),
+ * terminal value 0 (process_samples.discount_sum :37-44, compute_returns :3-5). fp64. */
+int mjx_discount_scan(const double* x, const int64_t* offsets, int64_t n_traj, double gamma,
+                      double* y, void* stream);
+/* GAE branch of compute_advantages (process_samples.py:21-29):
+ *   b1 = [b, terminated ? 0 : b[-1]]; td = r + gamma*b1[1:] - b1[:-1];
+ *   adv = discount_scan(td, gamma*lam).
+ * lam outside [0,1] selects the non-GAE branch adv = returns - baseline (:10-13),
+ * in which case `rewards` must hold the returns. */
+int mjx_gae(const double* rewards, const double* baseline, const int64_t* offsets,
+            const uint8_t* terminated, int64_t n_traj, double gamma, double lam,
+            double* adv, void* stream);
+/* Advantage whitening of process_paths (batch_reinforce.py:185) fused with the
+ * fp64->fp32 cast the reference performs per call (gaussian_mlp.py:102-109):
+ * out32 = (adv - mean)/(std + eps) with mean/std supplied by the caller (the
+ * cross-rank values); stats_out = [sum, sum of squares about `shift`, count]. */
+int mjx_sum_stats(const double* x, int64_t N, double shift, double* stats_out, void* stream);
+int mjx_whiten_cast(const double* adv, int64_t N, double mean, double std, double eps,
+                    float* out32, void* stream);
+int mjx_cast_f64_f32(const double* x, int64_t count, float* out32, void* stream);
+
+/* ---- in-library kernel timing (bench.py roofline) ------------------------- */
+/* While enabled, every launch of the dominant Fisher-vector-product kernel (fused k_fused
+ * MODE_FVP, or the whole layer-wise FVP chain) is bracketed by hipEvents recorded on the
+ * launch stream.  mjx_profile_read synchronises and returns out[0] = total milliseconds,
+ * out[1] = number of launches measured since the last mjx_profile_enable(ctx, 1). */
+int mjx_profile_enable(mjx_ctx* ctx, int on);
+int mjx_profile_read(mjx_ctx* ctx, double* out_host);
+
+/* ---- debugging aid (tests only) ------------------------------------------ */
+/* When non-NULL, the fused kernels dump the first tile's intermediates here. */
+int mjx_set_debug_buffer(mjx_ctx* ctx, float* dbg, int64_t floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJX_H */

@@ -1,0 +1,84 @@
+"""ctypes binding of libmjx.so (C ABI: include/mjx.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is
+no CPU fallback: if the shared object is missing or no GPU is visible the product path
+raises -- parity claims are only meaningful for the HIP path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmjx.so")
+
+c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_void_p)
+
+# name -> (restype, argtypes); every symbol include/mjx.h declares
+PROTOTYPES = {
+    "mjx_last_error": (ctypes.c_char_p, []),
+    "mjx_version": (c_int, []),
+    "mjx_device_count": (c_int, []),
+    "mjx_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, ctypes.POINTER(c_int), c_int]),
+    "mjx_destroy": (None, [c_void_p]),
+    "mjx_num_params": (c_int64, [c_void_p]),
+    "mjx_uses_fused_path": (c_int, [c_void_p]),
+    "mjx_malloc": (c_int, [ctypes.POINTER(c_void_p), c_int64]),
+    "mjx_free": (c_int, [c_void_p]),
+    "mjx_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "mjx_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "mjx_stream_sync": (c_int, [c_void_p]),
+    "mjx_bind_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
+    "mjx_bind_policy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "mjx_surr_vpg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mjx_fvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mjx_eval_surr_kl": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mjx_cg_solve": (c_int, [c_void_p, c_void_p, c_int, c_float, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mjx_cg_init": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mjx_cg_p": (c_void_p, [c_void_p]),
+    "mjx_cg_step": (c_int, [c_void_p, c_void_p, c_float, c_double, c_void_p]),
+    "mjx_cg_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mjx_apply_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),
+    "mjx_discount_scan": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p]),
+    "mjx_gae": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_void_p, c_void_p]),
+    "mjx_sum_stats": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p]),
+    "mjx_whiten_cast": (c_int, [c_void_p, c_int64, c_double, c_double, c_double, c_void_p, c_void_p]),
+    "mjx_cast_f64_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "mjx_profile_enable": (c_int, [c_void_p, c_int]),
+    "mjx_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_double)]),
+    "mjx_set_debug_buffer": (c_int, [c_void_p, c_void_p, c_int64]),
+}
+
+_lib = None
+
+
+class MjxError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libmjx.so and attach prototypes (idempotent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MjxError("libmjx.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mjx_last_error()
+        raise MjxError("libmjx error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """device (or host) pointer of a torch tensor / None."""
+    return None if t is None else c_void_p(t.data_ptr())

@@ -1,0 +1,187 @@
+"""Batch policy-gradient agent base class with mjrl's Agent surface.
+
+Mirrors ``mjrl.algos.batch_reinforce.BatchREINFORCE`` (reference
+mjrl/algos/batch_reinforce.py:21-214): ``train_step`` pipeline (sample -> returns ->
+advantages -> train_from_paths -> baseline.fit), ``process_paths`` (concatenate + advantage
+whitening + return statistics), the surrogate / KL / vanilla-gradient operators and the
+vanilla-PG ``train_from_paths``.  All batch arithmetic runs in libmjx through
+``mjrl_amd.engine.UpdateEngine``; this class only orchestrates.
+"""
+import time as timer
+
+import numpy as np
+
+from .. import samplers as trajectory_sampler
+from ..engine import UpdateEngine, _dist
+from ..utils import process_samples
+from ..utils.logger import DataLog
+
+
+class BatchREINFORCE:
+    def __init__(self, env, policy, baseline, learn_rate=0.01, seed=123, desired_kl=None, save_logs=False, **kwargs):
+        self.env = env
+        self.policy = policy
+        self.baseline = baseline
+        self.alpha = learn_rate
+        self.seed = seed
+        self.save_logs = save_logs
+        self.running_score = None
+        self.desired_kl = desired_kl
+        if save_logs:
+            self.logger = DataLog()
+
+    # ------------------------------------------------------------------ device plumbing
+    _engine_obj = None
+
+    @property
+    def engine(self):
+        """Lazily created in the training process only (never pickled, never forked)."""
+        if self._engine_obj is None:
+            self._engine_obj = UpdateEngine(self.policy.n, self.policy.m, self.policy.hidden_sizes)
+        return self._engine_obj
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_engine_obj", None)
+        return state
+
+    def _push_policy(self):
+        p = self.policy
+        self.engine.set_policy(p.get_param_values(), p.get_old_param_values(), p.model.packed_transforms(),
+                               p.old_model.packed_transforms())
+
+    def _bind(self, observations, actions, advantages):
+        self._push_policy()
+        self.engine.set_batch(observations, actions, advantages)
+
+    # ------------------------------------------------------------------ operators (host ndarrays in, python / ndarray out)
+    def CPI_surrogate(self, observations, actions, advantages):
+        """mean(LR * adv) -- batch_reinforce.py:40-46."""
+        self._bind(observations, actions, advantages)
+        return self.engine.eval_surr_kl()[0]
+
+    def kl_old_new(self, observations, actions):
+        """mean KL(new || old) -- batch_reinforce.py:48-52."""
+        self._bind(observations, actions, np.zeros(len(observations), np.float32))
+        return self.engine.eval_surr_kl()[1]
+
+    def flat_vpg(self, observations, actions, advantages):
+        """flattened gradient of the CPI surrogate -- batch_reinforce.py:54-58."""
+        self._bind(observations, actions, advantages)
+        return self.engine.surr_vpg()[0].cpu().numpy()
+
+    # ------------------------------------------------------------------ main loop step
+    def train_step(self, N, env=None, sample_mode='trajectories', horizon=1e6, gamma=0.995, gae_lambda=0.97,
+                   num_cpu='max', env_kwargs=None):
+        """batch_reinforce.py:61-114"""
+        if env is None:
+            env = self.env.env_id if hasattr(self.env, "env_id") else self.env
+        if sample_mode not in ('trajectories', 'samples'):
+            raise ValueError("sample_mode must be either 'trajectories' or 'samples'")
+        t0 = timer.time()
+        common = dict(env=env, policy=self.policy, horizon=horizon, base_seed=self.seed, num_cpu=num_cpu, env_kwargs=env_kwargs)
+        if sample_mode == 'trajectories':
+            paths = trajectory_sampler.sample_paths(num_traj=N, **common)
+        else:
+            paths = trajectory_sampler.sample_data_batch(num_samples=N, **common)
+        if self.save_logs:
+            self.logger.log_kv('time_sampling', timer.time() - t0)
+        if self.seed is not None:
+            self.seed = self.seed + N
+
+        process_samples.compute_returns(paths, gamma)
+        process_samples.compute_advantages(paths, self.baseline, gamma, gae_lambda)
+        eval_statistics = self.train_from_paths(paths)
+        eval_statistics.append(N)
+        if self.save_logs:
+            self.logger.log_kv('num_samples', int(np.sum([p["rewards"].shape[0] for p in paths])))
+            t0 = timer.time()
+            error_before, error_after = self.baseline.fit(paths, return_errors=True)
+            self.logger.log_kv('time_VF', timer.time() - t0)
+            self.logger.log_kv('VF_error_before', error_before)
+            self.logger.log_kv('VF_error_after', error_after)
+        else:
+            self.baseline.fit(paths)
+        return eval_statistics
+
+    # ------------------------------------------------------------------ vanilla PG update
+    def train_from_paths(self, paths):
+        """batch_reinforce.py:117-175 (optional halving line search on the KL)."""
+        observations, actions, advantages, base_stats, self.running_score = self.process_paths(paths)
+        if self.save_logs:
+            self.log_rollout_statistics(paths)
+        eng = self.engine
+        self._bind(observations, actions, advantages)
+        t0 = timer.time()
+        g, surr_before = eng.surr_vpg()
+        eng.x.copy_(g)
+        t_gLL = timer.time() - t0
+        alpha = self.alpha
+        eng.apply_step(alpha, self.policy.min_log_std)
+        if self.desired_kl is not None:
+            for _ in range(100):
+                if eng.eval_surr_kl()[1] <= self.desired_kl:
+                    break
+                print("backtracking")
+                alpha = alpha / 2.0
+                eng.apply_step(alpha, self.policy.min_log_std)
+        surr_after, kl_dist = eng.eval_surr_kl()
+        self.policy.set_param_values(eng.theta_new.cpu().numpy(), set_new=True, set_old=True)
+        if self.save_logs:
+            self.logger.log_kv('alpha', self.alpha)
+            self.logger.log_kv('time_vpg', t_gLL)
+            self.logger.log_kv('kl_dist', kl_dist)
+            self.logger.log_kv('surr_improvement', surr_after - surr_before)
+            self.logger.log_kv('running_score', self.running_score)
+            self._log_success(paths)
+        return base_stats
+
+    # ------------------------------------------------------------------ path bookkeeping
+    def process_paths(self, paths):
+        """batch_reinforce.py:178-197: concatenate, whiten advantages (population std + 1e-6),
+        return statistics, running score.  With torch.distributed initialised, `paths` is this
+        rank's trajectory shard and mean / std / return statistics are taken over all ranks."""
+        observations = np.concatenate([path["observations"] for path in paths])
+        actions = np.concatenate([path["actions"] for path in paths])
+        advantages = np.concatenate([path["advantages"] for path in paths])
+        path_returns = np.array([float(np.sum(p["rewards"])) for p in paths])
+        d = _dist()
+        if d is None:
+            mean, std = np.mean(advantages), np.std(advantages)
+        else:
+            torch = self.engine.torch
+            gathered = [None] * d.get_world_size()
+            d.all_gather_object(gathered, path_returns)
+            path_returns = np.concatenate(gathered)
+            s = torch.tensor([advantages.sum(), float(advantages.size)], dtype=torch.float64, device=self.engine.device)
+            d.all_reduce(s)
+            mean = float(s[0] / s[1])
+            q = torch.tensor([((advantages - mean) ** 2).sum()], dtype=torch.float64, device=self.engine.device)
+            d.all_reduce(q)
+            std = float(np.sqrt(q.item() / s[1].item()))
+        advantages = (advantages - mean) / (std + 1e-6)
+        mean_return = np.mean(path_returns)
+        base_stats = [mean_return, np.std(path_returns), np.amin(path_returns), np.amax(path_returns)]
+        running_score = mean_return if self.running_score is None else 0.9 * self.running_score + 0.1 * mean_return
+        return observations, actions, advantages, base_stats, running_score
+
+    def log_rollout_statistics(self, paths):
+        """batch_reinforce.py:200-214"""
+        path_returns = [float(np.sum(p["rewards"])) for p in paths]
+        self.logger.log_kv('stoc_pol_mean', np.mean(path_returns))
+        self.logger.log_kv('stoc_pol_std', np.std(path_returns))
+        self.logger.log_kv('stoc_pol_max', np.amax(path_returns))
+        self.logger.log_kv('stoc_pol_min', np.amin(path_returns))
+        try:
+            self.logger.log_kv('rollout_success', self.env.env.env.evaluate_success(paths))
+        except Exception:
+            pass
+
+    def _log_success(self, paths):
+        try:
+            self.env.env.env.evaluate_success(paths, self.logger)
+        except Exception:
+            try:
+                self.logger.log_kv('success_rate', self.env.env.env.evaluate_success(paths))
+            except Exception:
+                pass

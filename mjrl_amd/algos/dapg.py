@@ -1,0 +1,98 @@
+"""Demo-augmented policy gradient (DAPG) on the GPU.
+
+Mirrors ``mjrl.algos.dapg.DAPG`` (reference mjrl/algos/dapg.py:25-141): the gradient is the
+vanilla gradient over [on-policy ; demonstrations] with demo "advantages"
+lam_0 * lam_1^iter, rescaled by N_all / N; the Fisher metric and the surrogate / KL use the
+on-policy block only.  Both blocks are uploaded once; K1 runs over all rows, K2/K3 over the
+on-policy prefix of the same device arrays.
+"""
+import time as timer
+
+import numpy as np
+
+from ..utils.logger import DataLog
+from .npg_cg import NPG
+
+
+class DAPG(NPG):
+    def __init__(self, env, policy, baseline, demo_paths=None, normalized_step_size=0.01,
+                 FIM_invert_args={'iters': 10, 'damping': 1e-4}, hvp_sample_frac=1.0, seed=123, save_logs=False,
+                 kl_dist=None, lam_0=1.0, lam_1=0.95, **kwargs):
+        """Arguments as in the reference (dapg.py:26-52)."""
+        self.env = env
+        self.policy = policy
+        self.baseline = baseline
+        self.kl_dist = kl_dist if kl_dist is not None else 0.5 * normalized_step_size
+        self.seed = seed
+        self.save_logs = save_logs
+        self.FIM_invert_args = FIM_invert_args
+        self.hvp_subsample = hvp_sample_frac
+        self.running_score = None
+        self.demo_paths = demo_paths
+        self.lam_0 = lam_0
+        self.lam_1 = lam_1
+        self.iter_count = 0.0
+        self.input_normalization = None
+        self.alpha = None
+        if save_logs:
+            self.logger = DataLog()
+
+    def train_from_paths(self, paths):
+        """dapg.py:54-141"""
+        observations, actions, advantages, base_stats, self.running_score = self.process_paths(paths)
+        if self.save_logs:
+            self.log_rollout_statistics(paths)
+        N = observations.shape[0]
+        use_demos = self.demo_paths is not None and self.lam_0 > 0.0
+        if use_demos:                                          # dapg.py:62-70
+            demo_obs = np.concatenate([p["observations"] for p in self.demo_paths])
+            demo_act = np.concatenate([p["actions"] for p in self.demo_paths])
+            demo_adv = self.lam_0 * (self.lam_1 ** self.iter_count) * np.ones(demo_obs.shape[0])
+            self.iter_count += 1
+            all_obs = np.concatenate([observations, demo_obs])
+            all_act = np.concatenate([actions, demo_act])
+            all_adv = 1e-2 * np.concatenate([advantages / (np.std(advantages) + 1e-8), demo_adv])
+        else:
+            all_obs, all_act, all_adv = observations, actions, advantages
+
+        eng = self.engine
+        self._push_policy()
+        # on-policy rows first: surrogate before the step (dapg.py:92)
+        eng.set_batch(all_obs, all_act, all_adv)
+        N_all_global, N_all_local = eng.N_global, eng.N_local
+        on_global = N_all_global - (N_all_local - N)           # single rank: == N
+        d = None
+        from ..engine import _dist
+        d = _dist()
+        if d is not None:
+            t = eng.torch.tensor([float(N)], dtype=eng.torch.float64, device=eng.device)
+            d.all_reduce(t)
+            on_global = int(t.item())
+        adv_on = eng.to_device_f32(advantages)
+
+        t0 = timer.time()
+        g, _ = eng.surr_vpg()                                  # K1 over [on-policy ; demos], mean over N_all
+        sample_coef = N_all_global / on_global                 # dapg.py:97-98
+        g.mul_(sample_coef)
+        t_gLL = timer.time() - t0
+
+        adv_all_dev = eng.adv
+        eng.N_global = on_global                               # Fisher / surrogate / KL: on-policy prefix only
+        eng.bind_rows(N, adv=adv_on)
+        surr_before = eng.eval_surr_kl()[0]
+        t0 = timer.time()
+        _, gdotx = self.CG_solve(g)                            # dapg.py:103-106
+        t_FIM = timer.time() - t0
+
+        n_step_size = 2.0 * self.kl_dist                       # dapg.py:111-112
+        alpha = np.sqrt(np.abs(n_step_size / (gdotx + 1e-20)))
+        eng.apply_step(alpha, self.policy.min_log_std)
+        surr_after, kl_dist = eng.eval_surr_kl()
+        self.policy.set_param_values(eng.theta_new.cpu().numpy(), set_new=True, set_old=True)
+        del adv_all_dev
+
+        if self.save_logs:
+            self._log_update(paths, alpha, n_step_size, t_gLL, t_FIM, kl_dist, surr_before, surr_after)
+        self.last_update = dict(alpha=float(alpha), kl_dist=kl_dist, surr_before=surr_before, surr_after=surr_after,
+                                gdotx=gdotx)
+        return base_stats

@@ -1,0 +1,473 @@
+// layerwise.h -- layer-by-layer path for policies the fused kernel cannot hold on chip
+// (hidden sizes > 64, obs dim > 31, any number of hidden layers incl. none).
+//
+// Same math as fused_policy.h, organised as fp32-MFMA GEMMs with fused epilogues over
+// activations that stay resident in HBM for the whole update:
+//   forward   H_{l+1} = tanh(H_l W_l^T + b_l)                        (NT GEMM + epilogue)
+//   tangent   T_{l+1} = (H_l V_l^T + T_l W_l^T + c_l) (1 - H_{l+1}^2) (two NT GEMMs, one acc)
+//   backward  D_l     = (D_{l+1} W_l) (1 - H_l^2)                     (NN GEMM + epilogue)
+//   wgrad     gW_l    = D_{l+1}^T H_l                                  (TN GEMM, split over samples)
+// Forward activations are cached per (batch, policy) binding, so the 10-25 Fisher-vector
+// products of one CG solve reuse them (theta is fixed during CG).
+//
+// Reference semantics: mjrl/utils/fc_network.py:39-52, mjrl/policies/gaussian_mlp.py:99-145,
+// mjrl/algos/batch_reinforce.py:40-58, mjrl/algos/npg_cg.py:62-81.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "fused_policy.h"
+#include "vecops.h"
+
+namespace mjx {
+
+enum { EPI_STORE = 0, EPI_BIAS_TANH, EPI_BIAS_AFFINE, EPI_TANGENT, EPI_BACK };
+
+struct GemmArgs {
+  int M, N, npairs;
+  int K[2];
+  const float* A[2]; int64_t a_rs[2], a_ks[2];   // A(i,k) = A[i*a_rs + k*a_ks]
+  const float* B[2]; int64_t b_cs[2], b_ks[2];   // B(k,j) = B[j*b_cs + k*b_ks]
+  float* C; int64_t ldc;                          // C(i,j) = C[i*ldc + j] (+ z*c_zs for split-K)
+  int64_t c_zs;
+  const float* bias;                              // per column
+  const float* aux; int64_t ld_aux;               // activation for the (1 - y^2) factor
+  const float* osc; const float* osh;             // per-column affine (EPI_BIAS_AFFINE)
+  int epi;
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;
+
+// C = sum_p A_p * B_p with v_mfma_f32_32x32x2_f32; 4 waves in a 2x2 grid of 64x64 sub-tiles.
+// blockIdx.z splits the K range of pair 0 (wgrad: K = samples).
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+  __shared__ float As[GBK * GLD];
+  __shared__ float Bs[GBK * GLD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x16)(0.f);
+
+  for (int p = 0; p < g.npairs; ++p) {
+    const float* __restrict__ Ap = g.A[p];
+    const float* __restrict__ Bp = g.B[p];
+    const int64_t ars = g.a_rs[p], aks = g.a_ks[p], bcs = g.b_cs[p], bks = g.b_ks[p];
+    int kbeg = 0, kend = g.K[p];
+    if (gridDim.z > 1) {
+      int chunk = (g.K[p] + gridDim.z - 1) / gridDim.z;
+      chunk = ((chunk + GBK - 1) / GBK) * GBK;
+      kbeg = blockIdx.z * chunk;
+      kend = min(g.K[p], kbeg + chunk);
+    }
+    float ra[8], rb[8];
+    auto gload = [&](int k0) {
+      if (aks == 1) {
+        const int kk = tid & 15, r = tid >> 4;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          int row = m0 + r + 16 * c, k = k0 + kk;
+          ra[c] = (row < g.M && k < kend) ? Ap[(int64_t)row * ars + k] : 0.f;
+        }
+      } else {
+        const int r = tid & 127, kq = tid >> 7;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          int row = m0 + r, k = k0 + kq + 2 * c;
+          ra[c] = (row < g.M && k < kend) ? Ap[(int64_t)row * ars + (int64_t)k * aks] : 0.f;
+        }
+      }
+      if (bks == 1) {
+        const int kk = tid & 15, r = tid >> 4;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          int col = n0 + r + 16 * c, k = k0 + kk;
+          rb[c] = (col < g.N && k < kend) ? Bp[(int64_t)col * bcs + k] : 0.f;
+        }
+      } else {
+        const int r = tid & 127, kq = tid >> 7;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          int col = n0 + r, k = k0 + kq + 2 * c;
+          rb[c] = (col < g.N && k < kend) ? Bp[(int64_t)col * bcs + (int64_t)k * bks] : 0.f;
+        }
+      }
+    };
+    auto lstore = [&]() {
+      if (aks == 1) {
+        const int kk = tid & 15, r = tid >> 4;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) As[kk * GLD + r + 16 * c] = ra[c];
+      } else {
+        const int r = tid & 127, kq = tid >> 7;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) As[(kq + 2 * c) * GLD + r] = ra[c];
+      }
+      if (bks == 1) {
+        const int kk = tid & 15, r = tid >> 4;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) Bs[kk * GLD + r + 16 * c] = rb[c];
+      } else {
+        const int r = tid & 127, kq = tid >> 7;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) Bs[(kq + 2 * c) * GLD + r] = rb[c];
+      }
+    };
+    if (kbeg < kend) gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+      lstore();
+      __syncthreads();
+      if (k0 + GBK < kend) gload(k0 + GBK);
+#pragma unroll
+      for (int s = 0; s < GBK / 2; ++s) {
+        float a0 = As[(2 * s + hi) * GLD + wm * 64 + j], a1 = As[(2 * s + hi) * GLD + wm * 64 + 32 + j];
+        float b0 = Bs[(2 * s + hi) * GLD + wn * 64 + j], b1 = Bs[(2 * s + hi) * GLD + wn * 64 + 32 + j];
+        acc[0][0] = MJX_MFMA(a0, b0, acc[0][0]);
+        acc[0][1] = MJX_MFMA(a0, b1, acc[0][1]);
+        acc[1][0] = MJX_MFMA(a1, b0, acc[1][0]);
+        acc[1][1] = MJX_MFMA(a1, b1, acc[1][1]);
+      }
+      __syncthreads();
+    }
+  }
+  float* Cz = g.C + (int64_t)blockIdx.z * g.c_zs;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + mt * 32 + unit_of(r, hi), col = n0 + wn * 64 + nt * 32 + j;
+        if (row < g.M && col < g.N) {
+          float v = acc[mt][nt][r];
+          if (g.epi == EPI_BIAS_TANH) v = tanhf(v + g.bias[col]);
+          else if (g.epi == EPI_BIAS_AFFINE) v = (v + g.bias[col]) * g.osc[col] + (g.osh ? g.osh[col] : 0.f);
+          else if (g.epi == EPI_TANGENT) { float y = g.aux[(int64_t)row * g.ld_aux + col]; v = (v + g.bias[col]) * fmaf(-y, y, 1.0f); }
+          else if (g.epi == EPI_BACK) { float y = g.aux[(int64_t)row * g.ld_aux + col]; v = v * fmaf(-y, y, 1.0f); }
+          Cz[(int64_t)row * g.ldc + col] = v;
+        }
+      }
+}
+
+// x~ = (x - in_shift) / (in_scale + 1e-8)    fc_network.py:46
+__global__ void k_normalize(const float* __restrict__ x, int64_t N, int n, const float* __restrict__ tr, float* __restrict__ o) {
+  const int64_t tot = N * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+    int f = (int)(i % n);
+    o[i] = (x[i] - tr[f]) / (tr[n + f] + 1e-8f);
+  }
+}
+
+// per-sample likelihood head (mean_LL / likelihood_ratio / mean_kl / CPI surrogate).
+// mode 0 (VPG): writes d3 = out_scale * adv*LR/N * (a-mu)/sigma^2, partial sums [surr, count, gls(m)...]
+// mode 2 (EVAL): partial sums [surr, kl]
+// part: [gridDim.x][2 + MPH] doubles
+constexpr int MPH = 64;   // max action dim of the layer-wise head
+__global__ __launch_bounds__(256) void k_head(int mode, const float* __restrict__ mu, const float* __restrict__ mu_old,
+                                              const float* __restrict__ act, const float* __restrict__ adv, int64_t N, int m,
+                                              const float* __restrict__ ls_new, const float* __restrict__ ls_old,
+                                              const float* __restrict__ osc, float inv_N, float* __restrict__ d3,
+                                              double* __restrict__ part) {
+  __shared__ double sh[17];
+  __shared__ float sgn[MPH], sgo[MPH], lsn[MPH], lso[MPH];
+  if (threadIdx.x < m) {
+    lsn[threadIdx.x] = ls_new[threadIdx.x]; lso[threadIdx.x] = ls_old[threadIdx.x];
+    sgn[threadIdx.x] = expf(ls_new[threadIdx.x]); sgo[threadIdx.x] = expf(ls_old[threadIdx.x]);
+  }
+  __syncthreads();
+  float sumn = 0.f, sumo = 0.f;
+  for (int a = 0; a < m; ++a) { sumn += lsn[a]; sumo += lso[a]; }
+  double s_surr = 0.0, s_b = 0.0;
+  double gl[4] = {0, 0, 0, 0};                 // log_std grads handled 4 at a time below
+  const float c = 0.5f * (float)m * 1.8378770664093453f;
+  for (int a0 = 0; a0 < ((mode == 0) ? m : 1); a0 += 4) {
+    gl[0] = gl[1] = gl[2] = gl[3] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+      float lln = 0.f, llo = 0.f, kl = 0.f;
+      for (int a = 0; a < m; ++a) {
+        float x = act[i * m + a], mn = mu[i * m + a];
+        float zn = (x - mn) / sgn[a];
+        lln = fmaf(-0.5f * zn, zn, lln);
+        if (mu_old) {
+          float mo = mu_old[i * m + a];
+          float zo = (x - mo) / sgo[a];
+          llo = fmaf(-0.5f * zo, zo, llo);
+          float Nr = (mo - mn) * (mo - mn) + sgo[a] * sgo[a] - sgn[a] * sgn[a];
+          kl += Nr / (2.0f * sgn[a] * sgn[a] + 1e-8f) + lsn[a] - lso[a];
+        }
+      }
+      lln = lln - sumn - c;
+      llo = mu_old ? (llo - sumo - c) : lln;
+      float LR = expf(lln - llo), ad = adv[i];
+      if (a0 == 0) { s_surr += (double)(LR * ad); s_b += (mode == 0) ? 1.0 : (double)kl; }
+      if (mode == 0) {
+        float w = ad * LR * inv_N;
+        for (int a = 0; a < m; ++a) {
+          float zn = (act[i * m + a] - mu[i * m + a]) / sgn[a];
+          if (a0 == 0) d3[i * m + a] = osc[a] * (w * zn / sgn[a]);
+          if (a >= a0 && a < a0 + 4) gl[a - a0] += (double)(w * (zn * zn - 1.0f));
+        }
+      }
+    }
+    if (mode == 0)
+      for (int k = 0; k < 4 && a0 + k < m; ++k) {
+        double t = block_sum(gl[k], sh);
+        if (threadIdx.x == 0) part[(size_t)blockIdx.x * (2 + MPH) + 2 + a0 + k] = t;
+      }
+  }
+  s_surr = block_sum(s_surr, sh);
+  s_b = block_sum(s_b, sh);
+  if (threadIdx.x == 0) { part[(size_t)blockIdx.x * (2 + MPH)] = s_surr; part[(size_t)blockIdx.x * (2 + MPH) + 1] = s_b; }
+}
+
+// FVP head: d3 = out_scale * D * mudot / N,  D = 2/(2 sigma^2 + 1e-8)   (in place on mudot)
+__global__ void k_fvp_head(float* __restrict__ mudot, int64_t N, int m, const float* __restrict__ ls,
+                           const float* __restrict__ osc, float inv_N) {
+  const int64_t tot = N * m;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+    int a = (int)(i % m);
+    float s = expf(ls[a]);
+    float Dk = 2.0f / (2.0f * s * s + 1e-8f);
+    mudot[i] = osc[a] * (Dk * mudot[i] * inv_N);
+  }
+}
+
+// column sums of a (N x h) matrix, split over row ranges: part[z][h]
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ D, int64_t N, int h, int64_t ld, float* __restrict__ part) {
+  __shared__ float sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  int64_t chunk = (N + gridDim.y - 1) / gridDim.y;
+  int64_t lo = blockIdx.y * chunk, hi = min(N, lo + chunk);
+  float a = 0.f;
+  if (c < h)
+    for (int64_t r = lo + rg; r < hi; r += 4) a += D[r * ld + c];
+  sh[rg][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rg == 0 && c < h) part[(size_t)blockIdx.y * h + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// out[i] = sum_z part[z][i]   (fp64 accumulate, fixed order)
+__global__ void k_reduce_split(const float* __restrict__ part, int Z, int64_t cnt, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) {
+    double a = 0.0;
+    for (int z = 0; z < Z; ++z) a += (double)part[(size_t)z * cnt + i];
+    out[i] = (float)a;
+  }
+}
+
+__global__ void k_reduce_head(const double* __restrict__ part, int G, int m, int mode, double* __restrict__ scal, float* __restrict__ gls) {
+  __shared__ double sh[17];
+  for (int k = 0; k < 2 + ((mode == 0) ? m : 0); ++k) {
+    double a = 0.0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) a += part[(size_t)g * (2 + MPH) + k];
+    a = block_sum(a, sh);
+    if (threadIdx.x == 0) {
+      if (k < 2) scal[k] = a;
+      else gls[k - 2] = (float)a;
+    }
+  }
+  if (threadIdx.x == 0) { scal[2] = (mode == 0) ? scal[1] : 0.0; scal[3] = 0.0; }
+}
+
+// log_std block of the FVP: frac * c(sigma) * v_s   
+__global__ void k_fvp_logstd(const float* __restrict__ ls, const float* __restrict__ vs, int m, float frac, float* __restrict__ out) {
+  int a = threadIdx.x;
+  if (a >= m) return;
+  float s = expf(ls[a]);
+  float u = s * s, den = 2.0f * u + 1e-8f;
+  out[a] = frac * (16.0f * u * u / (den * den) - 4.0f * u / den) * vs[a];
+}
+
+struct LayerwiseWS {
+  int n = 0, m = 0;
+  std::vector<int> sizes;            // n, h..., m
+  std::vector<int64_t> oW, ob;       // offsets in the flat vector
+  int64_t oS = 0, d = 0;
+  int64_t cap = 0;                   // rows allocated
+  float* Xn = nullptr;               // normalised obs (N x n)
+  std::vector<float*> H;             // hidden activations of the NEW net (cached)
+  std::vector<float*> T;             // tangent / delta buffers per hidden layer
+  float *mu = nullptr, *mu2 = nullptr, *d3 = nullptr;   // (N x m)
+  float* part = nullptr; int64_t part_cap = 0;          // split-K partials
+  double* hpart = nullptr;           // head partials
+  bool fwd_valid = false;
+  int nL() const { return (int)sizes.size() - 1; }   // number of affine layers
+
+  void init(int n_, int m_, const std::vector<int>& hid) {
+    n = n_; m = m_;
+    sizes.clear(); sizes.push_back(n); for (int h : hid) sizes.push_back(h); sizes.push_back(m);
+    oW.clear(); ob.clear();
+    int64_t k = 0;
+    for (int l = 0; l < nL(); ++l) { oW.push_back(k); k += (int64_t)sizes[l] * sizes[l + 1]; ob.push_back(k); k += sizes[l + 1]; }
+    oS = k; d = k + m;
+    H.assign(hid.size(), nullptr); T.assign(hid.size(), nullptr);
+  }
+  void invalidate() { fwd_valid = false; }
+  void release() {
+    hipFree(Xn); Xn = nullptr;
+    for (auto& p : H) { hipFree(p); p = nullptr; }
+    for (auto& p : T) { hipFree(p); p = nullptr; }
+    hipFree(mu); hipFree(mu2); hipFree(d3); hipFree(part); hipFree(hpart);
+    mu = mu2 = d3 = part = nullptr; hpart = nullptr; cap = 0; part_cap = 0;
+  }
+  static constexpr int HEAD_G = 512;
+  int reserve(int64_t N) {
+    fwd_valid = false;
+    if (m > MPH) return -3;
+    if (N <= cap) return 0;
+    int64_t newcap = N;
+    std::vector<int> hid(sizes.begin() + 1, sizes.end() - 1);
+    release();
+    if (hipMalloc(&Xn, (size_t)newcap * n * 4) != hipSuccess) return 2;
+    for (size_t l = 0; l < hid.size(); ++l) {
+      if (hipMalloc(&H[l], (size_t)newcap * hid[l] * 4) != hipSuccess) return 2;
+      if (hipMalloc(&T[l], (size_t)newcap * hid[l] * 4) != hipSuccess) return 2;
+    }
+    if (hipMalloc(&mu, (size_t)newcap * m * 4) != hipSuccess) return 2;
+    if (hipMalloc(&mu2, (size_t)newcap * m * 4) != hipSuccess) return 2;
+    if (hipMalloc(&d3, (size_t)newcap * m * 4) != hipSuccess) return 2;
+    if (hipMalloc(&hpart, (size_t)HEAD_G * (2 + MPH) * sizeof(double)) != hipSuccess) return 2;
+    cap = newcap;
+    return 0;
+  }
+
+  static void launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
+    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, splits);
+    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, g);
+  }
+  static int ew_grid(int64_t cnt) { int64_t g = (cnt + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+
+  // forward pass of one parameter set; acts[l] receives hidden layer l, out receives mu
+  void forward(const float* theta, const float* tr, const float* obs, int64_t N, std::vector<float*>& acts, float* out,
+               hipStream_t st) {
+    hipLaunchKernelGGL(k_normalize, dim3(ew_grid(N * n)), dim3(256), 0, st, obs, N, n, tr, Xn);
+    const float* in = Xn;
+    for (int l = 0; l < nL(); ++l) {
+      const bool last = (l == nL() - 1);
+      GemmArgs g{};
+      g.M = (int)N; g.N = sizes[l + 1]; g.npairs = 1; g.K[0] = sizes[l];
+      g.A[0] = in; g.a_rs[0] = sizes[l]; g.a_ks[0] = 1;
+      g.B[0] = theta + oW[l]; g.b_cs[0] = sizes[l]; g.b_ks[0] = 1;
+      g.C = last ? out : acts[l]; g.ldc = sizes[l + 1]; g.c_zs = 0;
+      g.bias = theta + ob[l];
+      g.epi = last ? EPI_BIAS_AFFINE : EPI_BIAS_TANH;
+      g.osc = tr + 2 * n + m; g.osh = tr + 2 * n;
+      launch_gemm(g, 1, st);
+      in = g.C;
+    }
+  }
+
+  int ensure_part(int64_t floats) {
+    if (floats <= part_cap) return 0;
+    hipFree(part); part = nullptr; part_cap = 0;
+    if (hipMalloc(&part, (size_t)floats * 4) != hipSuccess) return 2;
+    part_cap = floats;
+    return 0;
+  }
+
+  // backward from d3 (N x m cotangent on the pre-affine output) into grad (flat, W and b blocks)
+  int backward(const float* theta, int64_t N, float* grad, hipStream_t st) {
+    const float* delta = d3;
+    for (int l = nL() - 1; l >= 0; --l) {
+      const int ho = sizes[l + 1], hi_ = sizes[l];
+      const float* in = (l == 0) ? Xn : H[l - 1];
+      // weight gradient: gW[ho x hi] = delta^T (ho x N) * in (N x hi), split over samples
+      int tiles = ((ho + GBM - 1) / GBM) * ((hi_ + GBN - 1) / GBN);
+      int splits = (int)((N + 2047) / 2048);
+      int maxs = (1024 + tiles - 1) / tiles;
+      if (splits > maxs) splits = maxs;
+      if (splits < 1) splits = 1;
+      int csplits = splits;
+      if (ensure_part((int64_t)splits * ho * hi_ + (int64_t)csplits * ho)) return 2;
+      GemmArgs g{};
+      g.M = ho; g.N = hi_; g.npairs = 1; g.K[0] = (int)N;
+      g.A[0] = delta; g.a_rs[0] = 1; g.a_ks[0] = ho;
+      g.B[0] = in; g.b_cs[0] = 1; g.b_ks[0] = hi_;
+      g.C = part; g.ldc = hi_; g.c_zs = (int64_t)ho * hi_;
+      g.epi = EPI_STORE;
+      launch_gemm(g, splits, st);
+      hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid((int64_t)ho * hi_)), dim3(256), 0, st, part, splits, (int64_t)ho * hi_, grad + oW[l]);
+      float* bpart = part + (int64_t)splits * ho * hi_;
+      hipLaunchKernelGGL(k_colsum, dim3((ho + 63) / 64, csplits), dim3(256), 0, st, delta, N, ho, (int64_t)ho, bpart);
+      hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid(ho)), dim3(256), 0, st, bpart, csplits, (int64_t)ho, grad + ob[l]);
+      if (l > 0) {
+        // delta_{l} = (delta_{l+1} W_l) (1 - H_{l-1}^2)   -> T[l-1]
+        GemmArgs b{};
+        b.M = (int)N; b.N = hi_; b.npairs = 1; b.K[0] = ho;
+        b.A[0] = delta; b.a_rs[0] = ho; b.a_ks[0] = 1;
+        b.B[0] = theta + oW[l]; b.b_cs[0] = 1; b.b_ks[0] = hi_;
+        b.C = T[l - 1]; b.ldc = hi_; b.c_zs = 0;
+        b.aux = H[l - 1]; b.ld_aux = hi_;
+        b.epi = EPI_BACK;
+        launch_gemm(b, 1, st);
+        delta = T[l - 1];
+      }
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+  }
+
+  int surr_vpg(const float* obs, const float* act, const float* adv, int64_t N, int64_t Ng, const float* th_new,
+               const float* th_old, const float* tr_new, const float* tr_old, int old_is_new, float* grad, double* scal,
+               hipStream_t st) {
+    if (N > cap) return 1;
+    const float* mo = nullptr;
+    if (!old_is_new) {          // old net first (its hidden activations are scratch in T)
+      forward(th_old, tr_old, obs, N, T, mu2, st);
+      mo = mu2;
+    }
+    forward(th_new, tr_new, obs, N, H, mu, st);
+    fwd_valid = true;
+    hipLaunchKernelGGL(k_head, dim3(HEAD_G), dim3(256), 0, st, 0, mu, mo, act, adv, N, m, th_new + oS, th_old + oS,
+                       tr_new + 2 * n + m, (float)(1.0 / (double)Ng), d3, hpart);
+    hipLaunchKernelGGL(k_reduce_head, dim3(1), dim3(256), 0, st, hpart, HEAD_G, m, 0, scal, grad + oS);
+    return backward(th_new, N, grad, st);
+  }
+
+  int fvp(const float* obs, int64_t N, int64_t Ng, const float* theta, const float* tr, const float* v, float* out, hipStream_t st) {
+    if (N > cap) return 1;
+    if (!fwd_valid) { forward(theta, tr, obs, N, H, mu, st); fwd_valid = true; }
+    // tangent pass
+    const float* tin = nullptr;
+    for (int l = 0; l < nL(); ++l) {
+      const bool last = (l == nL() - 1);
+      const float* in = (l == 0) ? Xn : H[l - 1];
+      GemmArgs g{};
+      g.M = (int)N; g.N = sizes[l + 1];
+      g.npairs = tin ? 2 : 1;
+      g.K[0] = sizes[l]; g.A[0] = in; g.a_rs[0] = sizes[l]; g.a_ks[0] = 1;
+      g.B[0] = v + oW[l]; g.b_cs[0] = sizes[l]; g.b_ks[0] = 1;
+      if (tin) {
+        g.K[1] = sizes[l]; g.A[1] = tin; g.a_rs[1] = sizes[l]; g.a_ks[1] = 1;
+        g.B[1] = theta + oW[l]; g.b_cs[1] = sizes[l]; g.b_ks[1] = 1;
+      }
+      g.bias = v + ob[l];
+      g.c_zs = 0;
+      if (last) { g.C = d3; g.ldc = m; g.epi = EPI_BIAS_AFFINE; g.osc = tr + 2 * n + m; g.osh = nullptr; }
+      else { g.C = T[l]; g.ldc = sizes[l + 1]; g.epi = EPI_TANGENT; g.aux = H[l]; g.ld_aux = sizes[l + 1]; }
+      launch_gemm(g, 1, st);
+      tin = last ? nullptr : T[l];
+    }
+    hipLaunchKernelGGL(k_fvp_head, dim3(ew_grid(N * m)), dim3(256), 0, st, d3, N, m, theta + oS, tr + 2 * n + m, (float)(1.0 / (double)Ng));
+    hipLaunchKernelGGL(k_fvp_logstd, dim3(1), dim3(64), 0, st, theta + oS, v + oS, m, (float)((double)N / (double)Ng), out + oS);
+    return backward(theta, N, out, st);
+  }
+
+  int eval(const float* obs, const float* act, const float* adv, int64_t N, const float* th_new, const float* th_old,
+           const float* tr_new, const float* tr_old, double* scal, hipStream_t st) {
+    if (N > cap) return 1;
+    forward(th_old, tr_old, obs, N, T, mu2, st);
+    forward(th_new, tr_new, obs, N, T, mu, st);       // hidden activations are scratch here
+    fwd_valid = false;
+    hipLaunchKernelGGL(k_head, dim3(HEAD_G), dim3(256), 0, st, 2, mu, mu2, act, adv, N, m, th_new + oS, th_old + oS,
+                       tr_new + 2 * n + m, 0.f, (float*)nullptr, hpart);
+    hipLaunchKernelGGL(k_reduce_head, dim3(1), dim3(256), 0, st, hpart, HEAD_G, m, 2, scal, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+  }
+};
+
+}  // namespace mjx

@@ -1,0 +1,416 @@
+// mjx.hip -- C ABI (include/mjx.h) over the gfx950 kernels.  Host side only orchestrates:
+// it owns the workspace, picks the kernel instance and enqueues launches on the caller's
+// stream.  No host<->device synchronisation happens here unless an entry point says so.
+#include "../../include/mjx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fused_policy.h"
+#include "layerwise.h"
+#include "vecops.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) return fail((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+}  // namespace
+
+struct mjx_ctx {
+  int device = 0;
+  int n = 0, m = 0;
+  std::vector<int> hidden;
+  int64_t d = 0;
+  int oS = 0;                      // offset of log_std in the flat vector
+  int n_cu = 256;
+  // fused path
+  int fused = 0;                   // 0 = layer-wise, else variant id
+  int grid = 256;
+  size_t lds_bytes = 0;
+  // bound inputs
+  const float *obs = nullptr, *act = nullptr, *adv = nullptr;
+  int64_t N_local = 0, N_global = 0;
+  const float *theta_new = nullptr, *theta_old = nullptr, *tr_new = nullptr, *tr_old = nullptr;
+  int old_is_new = 1;
+  // workspace (device)
+  float* partials = nullptr;       // [grid][d]
+  double* spartials = nullptr;     // [grid][4]
+  float* ident_tr = nullptr;       // identity transforms
+  float *cg_x = nullptr, *cg_r = nullptr, *cg_p = nullptr, *cg_z = nullptr, *cg_Ap = nullptr;
+  double* cg_scal = nullptr;       // 8 doubles
+  float* dbg = nullptr;
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;   // pairs
+  size_t prof_used = 0;
+  mjx::LayerwiseWS lw;             // layer-wise path workspace
+};
+
+namespace {
+
+using namespace mjx;
+
+template <int H1, int H2, int NT1, int MP, bool DBG = false>
+int launch_fused(mjx_ctx* c, int mode, const FusedArgs& a, hipStream_t st) {
+  FusedLayout<H1, H2, NT1, MP> L(c->n);
+  size_t bytes = L.bytes();
+  void (*k)(FusedArgs) = nullptr;
+  if (mode == MODE_VPG) k = k_fused<H1, H2, NT1, MP, MODE_VPG, DBG>;
+  else if (mode == MODE_FVP) k = k_fused<H1, H2, NT1, MP, MODE_FVP, DBG>;
+  else k = k_fused<H1, H2, NT1, MP, MODE_EVAL, false>;
+  static thread_local const void* configured[3] = {nullptr, nullptr, nullptr};
+  if (configured[mode] != (const void*)k) {
+    HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    configured[mode] = (const void*)k;
+  }
+  hipLaunchKernelGGL(k, dim3(c->grid), dim3(256), bytes, st, a);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+// variant table: id -> (H1, H2, NT1, MP)
+template <int H1, int H2, int NT1, int MP>
+bool variant_fits(int n, int m, int h1, int h2, int64_t d, size_t* bytes) {
+  if (h1 != H1 || h2 != H2 || m > MP || n + 1 > 32 * NT1) return false;
+  FusedLayout<H1, H2, NT1, MP> L(n);
+  if (L.bytes() > 160 * 1024) return false;
+  if ((size_t)(4 * d + 64) * 4 > L.bytes()) return false;   // end-of-kernel reduction region
+  *bytes = L.bytes();
+  return true;
+}
+
+int pick_variant(int n, int m, const std::vector<int>& hid, int64_t d, size_t* bytes) {
+  if (hid.size() != 2) return 0;
+  int h1 = hid[0], h2 = hid[1];
+  if (variant_fits<64, 64, 1, 8>(n, m, h1, h2, d, bytes)) return 1;
+  if (variant_fits<32, 32, 1, 8>(n, m, h1, h2, d, bytes)) return 2;
+  if (variant_fits<64, 64, 1, 16>(n, m, h1, h2, d, bytes)) return 3;
+  if (variant_fits<32, 32, 1, 16>(n, m, h1, h2, d, bytes)) return 4;
+  if (variant_fits<32, 32, 2, 8>(n, m, h1, h2, d, bytes)) return 5;
+  return 0;
+}
+
+int dispatch_fused(mjx_ctx* c, int mode, const FusedArgs& a, hipStream_t st) {
+  switch (c->fused) {
+    case 1: return c->dbg ? launch_fused<64, 64, 1, 8, true>(c, mode, a, st) : launch_fused<64, 64, 1, 8>(c, mode, a, st);
+    case 2: return launch_fused<32, 32, 1, 8>(c, mode, a, st);
+    case 3: return launch_fused<64, 64, 1, 16>(c, mode, a, st);
+    case 4: return launch_fused<32, 32, 1, 16>(c, mode, a, st);
+    case 5: return launch_fused<32, 32, 2, 8>(c, mode, a, st);
+  }
+  return fail(MJX_ERR_STATE, "no fused variant");
+}
+
+FusedArgs make_args(mjx_ctx* c, const float* thetaB) {
+  FusedArgs a;
+  a.obs = c->obs; a.act = c->act; a.adv = c->adv;
+  a.N = c->N_local;
+  a.inv_N = (float)(1.0 / (double)c->N_global);
+  a.thetaA = c->theta_new; a.thetaB = thetaB;
+  a.trA = c->tr_new ? c->tr_new : c->ident_tr;
+  a.trB = c->tr_old ? c->tr_old : c->ident_tr;
+  a.old_is_new = c->old_is_new;
+  a.partials = c->partials; a.spartials = c->spartials;
+  a.dbg = c->dbg;
+  a.n = c->n; a.m = c->m;
+  return a;
+}
+
+int check_bound(mjx_ctx* c, bool need_act) {
+  if (!c) return fail(MJX_ERR_ARG, "null context");
+  if (!c->obs || c->N_local < 0 || c->N_global <= 0) return fail(MJX_ERR_STATE, "mjx_bind_batch has not been called");
+  if (need_act && (!c->act || !c->adv)) return fail(MJX_ERR_STATE, "actions / advantages not bound");
+  if (!c->theta_new || !c->theta_old) return fail(MJX_ERR_STATE, "mjx_bind_policy has not been called");
+  return MJX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mjx_last_error(void) { return g_err.c_str(); }
+int mjx_version(void) { return 1; }
+
+int mjx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int mjx_create(mjx_ctx** out, int device, int n, int m, const int* hidden, int n_hidden) {
+  if (!out || n <= 0 || m <= 0 || n_hidden < 0 || (n_hidden > 0 && !hidden)) return fail(MJX_ERR_ARG, "bad arguments");
+  if (mjx_device_count() <= device) return fail(MJX_ERR_NOGPU, "HIP device %d not available", device);
+  HIPCHK(hipSetDevice(device));
+  mjx_ctx* c = new mjx_ctx();
+  c->device = device; c->n = n; c->m = m;
+  c->hidden.assign(hidden, hidden + n_hidden);
+  int prev = n; int64_t d = 0;
+  for (int h : c->hidden) { if (h <= 0) { delete c; return fail(MJX_ERR_ARG, "bad hidden size"); } d += (int64_t)prev * h + h; prev = h; }
+  d += (int64_t)prev * m + m;
+  c->oS = (int)d;
+  d += m;
+  c->d = d;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  c->n_cu = prop.multiProcessorCount;
+  c->grid = c->n_cu;
+  c->fused = pick_variant(n, m, c->hidden, d, &c->lds_bytes);
+  if (const char* e = getenv("MJX_FORCE_LAYERWISE")) if (e[0] == '1') c->fused = 0;
+  HIPCHK(hipMalloc(&c->partials, (size_t)c->grid * d * sizeof(float)));
+  HIPCHK(hipMalloc(&c->spartials, (size_t)c->grid * 4 * sizeof(double)));
+  HIPCHK(hipMalloc(&c->cg_x, d * 4)); HIPCHK(hipMalloc(&c->cg_r, d * 4)); HIPCHK(hipMalloc(&c->cg_p, d * 4));
+  HIPCHK(hipMalloc(&c->cg_z, d * 4)); HIPCHK(hipMalloc(&c->cg_Ap, d * 4));
+  HIPCHK(hipMalloc(&c->cg_scal, 8 * sizeof(double)));
+  std::vector<float> id(2 * n + 2 * m, 0.f);
+  for (int i = 0; i < n; ++i) id[n + i] = 1.f;
+  for (int i = 0; i < m; ++i) id[2 * n + m + i] = 1.f;
+  HIPCHK(hipMalloc(&c->ident_tr, id.size() * 4));
+  HIPCHK(hipMemcpy(c->ident_tr, id.data(), id.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(c->spartials, 0, (size_t)c->grid * 4 * sizeof(double)));
+  c->lw.init(n, m, c->hidden);
+  *out = c;
+  return MJX_OK;
+}
+
+void mjx_destroy(mjx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  c->lw.release();
+  for (auto& e : c->prof_ev) hipEventDestroy(e);
+  hipFree(c->partials); hipFree(c->spartials); hipFree(c->ident_tr);
+  hipFree(c->cg_x); hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_z); hipFree(c->cg_Ap); hipFree(c->cg_scal);
+  delete c;
+}
+
+int64_t mjx_num_params(const mjx_ctx* c) { return c ? c->d : -1; }
+int mjx_uses_fused_path(const mjx_ctx* c) { return c ? (c->fused != 0) : 0; }
+
+int mjx_malloc(void** p, int64_t bytes) { if (!p || bytes < 0) return fail(MJX_ERR_ARG, "bad arguments"); HIPCHK(hipMalloc(p, (size_t)bytes)); return MJX_OK; }
+int mjx_free(void* p) { HIPCHK(hipFree(p)); return MJX_OK; }
+int mjx_memcpy_h2d(void* dst, const void* src, int64_t bytes, void* stream) {
+  HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream)); return MJX_OK; }
+int mjx_memcpy_d2h(void* dst, const void* src, int64_t bytes, void* stream) {
+  HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream)); return MJX_OK; }
+int mjx_stream_sync(void* stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return MJX_OK; }
+
+int mjx_bind_batch(mjx_ctx* c, const float* obs, const float* act, const float* adv, int64_t N_local, int64_t N_global) {
+  if (!c || (!obs && N_local > 0) || N_local < 0 || N_global < N_local || N_global <= 0) return fail(MJX_ERR_ARG, "bad batch");
+  c->obs = obs; c->act = act; c->adv = adv; c->N_local = N_local; c->N_global = N_global;
+  c->lw.invalidate();
+  if (!c->fused) { int rc = c->lw.reserve(N_local); if (rc) return fail(rc, "layer-wise workspace allocation failed"); }
+  return MJX_OK;
+}
+
+int mjx_bind_policy(mjx_ctx* c, const float* theta_new, const float* theta_old, const float* tr_new,
+                    const float* tr_old, int old_is_new) {
+  if (!c || !theta_new || !theta_old) return fail(MJX_ERR_ARG, "bad policy");
+  c->theta_new = theta_new; c->theta_old = theta_old; c->tr_new = tr_new; c->tr_old = tr_old;
+  c->old_is_new = old_is_new ? 1 : 0;
+  c->lw.invalidate();
+  return MJX_OK;
+}
+
+int mjx_profile_enable(mjx_ctx* c, int on) {
+  if (!c) return fail(MJX_ERR_ARG, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  if (on && c->prof_ev.empty()) {
+    c->prof_ev.resize(2 * 2048);
+    for (auto& e : c->prof_ev) HIPCHK(hipEventCreate(&e));
+  }
+  c->prof_on = on != 0;
+  if (on) c->prof_used = 0;
+  return MJX_OK;
+}
+
+int mjx_profile_read(mjx_ctx* c, double* out) {
+  if (!c || !out) return fail(MJX_ERR_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
+    HIPCHK(hipEventSynchronize(c->prof_ev[i + 1]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]));
+    tot += ms;
+  }
+  out[0] = tot; out[1] = (double)(c->prof_used / 2);
+  return MJX_OK;
+}
+
+int mjx_set_debug_buffer(mjx_ctx* c, float* dbg, int64_t floats) {
+  if (!c || (dbg && floats < 2048 * 8)) return fail(MJX_ERR_ARG, "debug buffer too small");
+  c->dbg = dbg;
+  return MJX_OK;
+}
+
+int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
+  if (int rc = check_bound(c, true)) return rc;
+  if (!grad_out || !scal_out) return fail(MJX_ERR_ARG, "null output");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->fused)
+    return c->lw.surr_vpg(c->obs, c->act, c->adv, c->N_local, c->N_global, c->theta_new, c->theta_old,
+                          c->tr_new ? c->tr_new : c->ident_tr, c->tr_old ? c->tr_old : c->ident_tr, c->old_is_new,
+                          grad_out, scal_out, st) ? fail(MJX_ERR_STATE, "layer-wise surr_vpg failed") : MJX_OK;
+  FusedArgs a = make_args(c, c->theta_old);
+  if (int rc = dispatch_fused(c, MODE_VPG, a, st)) return rc;
+  hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 63) / 64), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
+                     grad_out, (const float*)nullptr, (const float*)nullptr, c->oS, 0.f);
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, c->grid, scal_out);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
+  if (int rc = check_bound(c, false)) return rc;
+  if (!v || !out) return fail(MJX_ERR_ARG, "null vector");
+  if (!c->old_is_new) return fail(MJX_ERR_UNSUPPORTED, "mjx_fvp needs theta_new == theta_old (Gauss-Newton form); general Hessian not implemented");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(c->device));
+  const float frac = (float)((double)c->N_local / (double)c->N_global);
+  const bool prof = c->prof_on && c->prof_used + 2 <= c->prof_ev.size();
+  if (prof) HIPCHK(hipEventRecord(c->prof_ev[c->prof_used], st));
+  if (!c->fused) {
+    int rc = c->lw.fvp(c->obs, c->N_local, c->N_global, c->theta_new, c->tr_new ? c->tr_new : c->ident_tr, v, out, st);
+    if (prof) { HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], st)); c->prof_used += 2; }
+    return rc ? fail(MJX_ERR_STATE, "layer-wise fvp failed") : MJX_OK;
+  }
+  FusedArgs a = make_args(c, v);
+  if (int rc = dispatch_fused(c, MODE_FVP, a, st)) return rc;
+  if (prof) { HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], st)); c->prof_used += 2; }
+  hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 63) / 64), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
+                     out, c->theta_new, v, c->oS, frac);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_eval_surr_kl(mjx_ctx* c, double* scal_out, void* stream) {
+  if (int rc = check_bound(c, true)) return rc;
+  if (!scal_out) return fail(MJX_ERR_ARG, "null output");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->fused)
+    return c->lw.eval(c->obs, c->act, c->adv, c->N_local, c->theta_new, c->theta_old,
+                      c->tr_new ? c->tr_new : c->ident_tr, c->tr_old ? c->tr_old : c->ident_tr, scal_out, st)
+               ? fail(MJX_ERR_STATE, "layer-wise eval failed") : MJX_OK;
+  FusedArgs a = make_args(c, c->theta_old);
+  if (int rc = dispatch_fused(c, MODE_EVAL, a, st)) return rc;
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, c->grid, scal_out);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_cg_init(mjx_ctx* c, const float* b, void* stream) {
+  if (!c || !b) return fail(MJX_ERR_ARG, "bad arguments");
+  hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1024), 0, (hipStream_t)stream, b, c->cg_x, c->cg_r, c->cg_p, c->cg_scal, (int)c->d);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+const float* mjx_cg_p(mjx_ctx* c) { return c ? c->cg_p : nullptr; }
+int mjx_cg_step(mjx_ctx* c, const float* Ap, float damping, double tol, void* stream) {
+  if (!c || !Ap) return fail(MJX_ERR_ARG, "bad arguments");
+  hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(1024), 0, (hipStream_t)stream, Ap, damping, tol, c->cg_x, c->cg_r, c->cg_p,
+                     c->cg_z, c->cg_scal, (int)c->d);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+int mjx_cg_finish(mjx_ctx* c, const float* b, float* x_out, double* bdotx_out, void* stream) {
+  if (!c || !b) return fail(MJX_ERR_ARG, "bad arguments");
+  hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, b, c->cg_x, x_out, bdotx_out, (int)c->d);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_cg_solve(mjx_ctx* c, const float* b, int iters, float damping, double tol, float* x_out, double* bdotx_out,
+                 mjx_allreduce_fn allreduce, void* user, void* stream) {
+  if (!c || !b || iters < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (int rc = mjx_cg_init(c, b, stream)) return rc;
+  for (int i = 0; i < iters; ++i) {
+    if (int rc = mjx_fvp(c, c->cg_p, c->cg_Ap, stream)) return rc;
+    if (allreduce) if (int rc = allreduce(user, c->cg_Ap, c->d, stream)) return fail(rc, "allreduce callback failed (%d)", rc);
+    if (int rc = mjx_cg_step(c, c->cg_Ap, damping, tol, stream)) return rc;
+  }
+  return mjx_cg_finish(c, b, x_out, bdotx_out, stream);
+}
+
+int mjx_apply_step(mjx_ctx* c, const float* theta, const float* x, float alpha, float min_log_std, float* theta_out, void* stream) {
+  if (!c || !theta || !x || !theta_out) return fail(MJX_ERR_ARG, "bad arguments");
+  hipLaunchKernelGGL(k_apply_step, dim3((c->d + 255) / 256), dim3(256), 0, (hipStream_t)stream, theta, x, alpha, min_log_std,
+                     theta_out, (int)c->d, c->oS);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_discount_scan(const double* x, const int64_t* offsets, int64_t n_traj, double gamma, double* y, void* stream) {
+  if (n_traj == 0) return MJX_OK;
+  if (!x || !offsets || !y || n_traj < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  hipLaunchKernelGGL(k_traj_scan<0>, dim3((unsigned)n_traj), dim3(256), 0, (hipStream_t)stream, x, (const double*)nullptr,
+                     offsets, (const uint8_t*)nullptr, gamma, gamma, y);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_gae(const double* rewards, const double* baseline, const int64_t* offsets, const uint8_t* terminated,
+            int64_t n_traj, double gamma, double lam, double* adv, void* stream) {
+  if (n_traj == 0) return MJX_OK;
+  if (!rewards || !baseline || !offsets || !adv || n_traj < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (lam < 0.0 || lam > 1.0 || std::isnan(lam))
+    hipLaunchKernelGGL(k_traj_scan<2>, dim3((unsigned)n_traj), dim3(256), 0, (hipStream_t)stream, rewards, baseline, offsets,
+                       terminated, gamma, 0.0, adv);
+  else
+    hipLaunchKernelGGL(k_traj_scan<1>, dim3((unsigned)n_traj), dim3(256), 0, (hipStream_t)stream, rewards, baseline, offsets,
+                       terminated, gamma, gamma * lam, adv);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_sum_stats(const double* x, int64_t N, double shift, double* stats_out, void* stream) {
+  if (!x || !stats_out || N < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  static thread_local double* part = nullptr;
+  const int G = 512;
+  if (!part) HIPCHK(hipMalloc(&part, G * 2 * sizeof(double)));
+  hipLaunchKernelGGL(k_sum_stats_partial, dim3(G), dim3(256), 0, (hipStream_t)stream, x, N, shift, part);
+  hipLaunchKernelGGL(k_sum_stats_final, dim3(1), dim3(256), 0, (hipStream_t)stream, part, G, N, stats_out);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_whiten_cast(const double* adv, int64_t N, double mean, double std, double eps, float* out32, void* stream) {
+  if (!adv || !out32 || N < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (N == 0) return MJX_OK;
+  int grid = (int)((N + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_whiten_cast, dim3(grid), dim3(256), 0, (hipStream_t)stream, adv, N, mean, std + eps, out32);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_cast_f64_f32(const double* x, int64_t count, float* out32, void* stream) {
+  if (!x || !out32 || count < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (count == 0) return MJX_OK;
+  int grid = (int)((count + 255) / 256); if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_cast_f64_f32, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, count, out32);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+// vecops.h -- small deterministic reductions, the device-side CG bookkeeping (K4) and the
+// trajectory scans (K5).  All reductions use a fixed order (no atomics) so that results do
+// not depend on dispatch order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mjx {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// sum over a whole (<=1024-thread) block; every thread gets the result
+__device__ __forceinline__ double block_sum(double v, double* sh /* >= 17 doubles */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    sh[16] = t;
+  }
+  __syncthreads();
+  return sh[16];
+}
+
+// out[c] = sum_g partials[g][c]  (fp64 accumulate, fixed order).  64 columns x 4 row-groups
+// per 256-thread block.  FVP epilogue: the log_std block of the Hessian is diagonal,
+// H_ss = c(sigma); its per-sample mean contributes frac*c*v_s locally.
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials, int G, int d,
+                                                          float* __restrict__ out, const float* theta,
+                                                          const float* v, int oS, float frac) {
+  __shared__ double sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (c < d)
+    for (int g = rg; g < G; g += 4) acc += (double)partials[(size_t)g * d + c];
+  sh[rg][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rg == 0 && c < d) {
+    double t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (v != nullptr && c >= oS) {
+      float s = expf(theta[c]);
+      float u = s * s, e = 1e-8f;
+      float den = 2.0f * u + e;
+      float cc = 16.0f * u * u / (den * den) - 4.0f * u / den;
+      t = (double)(frac * cc * v[c]);
+    }
+    out[c] = (float)t;
+  }
+}
+
+__global__ void k_reduce_scalars(const double* __restrict__ sp, int G, double* __restrict__ out) {
+  __shared__ double sh[17];
+  for (int k = 0; k < 4; ++k) {
+    double a = 0.0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) a += sp[(size_t)g * 4 + k];
+    a = block_sum(a, sh);
+    if (threadIdx.x == 0) out[k] = a;
+  }
+}
+
+// ---- conjugate gradient (mjrl/utils/cg_solve.py:3-22); vectors fp32, dots fp64 ----
+// scal: [0]=r.r  [1]=done flag  [2]=p.z  [3]=iterations performed
+__global__ __launch_bounds__(1024) void k_cg_init(const float* __restrict__ b, float* x, float* r, float* p,
+                                                   double* scal, int d) {
+  __shared__ double sh[17];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    float bi = b[i];
+    x[i] = 0.f; r[i] = bi; p[i] = bi;
+    a += (double)bi * (double)bi;
+  }
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) { scal[0] = a; scal[1] = 0.0; scal[2] = 0.0; scal[3] = 0.0; }
+}
+
+__global__ __launch_bounds__(1024) void k_cg_step(const float* __restrict__ Ap, float damping, double tol,
+                                                   float* x, float* r, float* p, float* z, double* scal, int d) {
+  __shared__ double sh[17];
+  if (scal[1] != 0.0) return;                       // converged earlier: cg_solve.py:19-20 `break`
+  double pz = 0.0;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    float zi = Ap[i] + damping * p[i];              // npg_cg.py:81  hvp_flat + regu_coef*vector
+    z[i] = zi;
+    pz += (double)p[i] * (double)zi;
+  }
+  pz = block_sum(pz, sh);
+  const double rr = scal[0];
+  const float alpha = (float)(rr / pz);
+  double nrr = 0.0;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    x[i] = fmaf(alpha, p[i], x[i]);
+    float ri = fmaf(-alpha, z[i], r[i]);
+    r[i] = ri;
+    nrr += (double)ri * (double)ri;
+  }
+  nrr = block_sum(nrr, sh);
+  const float mu = (float)(nrr / rr);
+  for (int i = threadIdx.x; i < d; i += blockDim.x) p[i] = fmaf(mu, p[i], r[i]);
+  if (threadIdx.x == 0) {
+    scal[0] = nrr; scal[2] = pz; scal[3] += 1.0;
+    if (nrr < tol) scal[1] = 1.0;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_cg_finish(const float* __restrict__ b, const float* __restrict__ x,
+                                                     float* x_out, double* bdotx, int d) {
+  __shared__ double sh[17];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    float xi = x[i];
+    if (x_out) x_out[i] = xi;
+    a += (double)b[i] * (double)xi;
+  }
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0 && bdotx) bdotx[0] = a;
+}
+
+// theta_out = theta + alpha*x ; log_std clamp (gaussian_mlp.py:73-75)
+__global__ void k_apply_step(const float* __restrict__ theta, const float* __restrict__ x, float alpha,
+                             float min_log_std, float* out, int d, int oS) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d) return;
+  float v = __fadd_rn(theta[i], __fmul_rn(alpha, x[i]));   // numpy: separate multiply and add
+  if (i >= oS) v = fmaxf(v, min_log_std);
+  out[i] = v;
+}
+
+// ---- K5: reverse discounted scans over ragged trajectories (process_samples.py:21-44) ----
+// One 256-thread block per trajectory; the trajectory is cut into 256 contiguous segments,
+// pass 1 reduces every segment with zero carry, thread 0 chains the 256 carries, pass 2
+// replays each segment sequentially from its true carry (so within a segment the arithmetic
+// is exactly the reference's recurrence).
+// MODE 0: y[t] = x[t] + g*y[t+1]                       (discount_sum)
+// MODE 1: x[t] := r[t] + gamma*b1[t+1] - b1[t]         (GAE td residual), g = gamma*lam
+// MODE 2: y[t] = x[t] - b[t]                           (non-GAE branch, no scan)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_traj_scan(const double* __restrict__ x, const double* __restrict__ bl,
+                                                    const int64_t* __restrict__ off, const uint8_t* __restrict__ term,
+                                                    double gamma, double g, double* __restrict__ y) {
+  __shared__ double loc[256], pw[256], cin[256];
+  const int64_t o = off[blockIdx.x];
+  const int T = (int)(off[blockIdx.x + 1] - o);
+  if (T <= 0) return;
+  const double* xr = x + o;
+  const double* br = (MODE != 0) ? bl + o : nullptr;
+  double* yr = y + o;
+  if (MODE == 2) {
+    for (int t = threadIdx.x; t < T; t += 256) yr[t] = xr[t] - br[t];
+    return;
+  }
+  const double blast = (MODE == 1) ? ((term && term[blockIdx.x]) ? 0.0 : br[T - 1]) : 0.0;
+  const int seg = (T + 255) / 256;
+  const int lo = min(T, (int)threadIdx.x * seg), hi = min(T, lo + seg);
+  auto val = [&](int t) -> double {
+    if (MODE == 0) return xr[t];
+    double bn = (t + 1 < T) ? br[t + 1] : blast;
+    return xr[t] + gamma * bn - br[t];
+  };
+  double run = 0.0, f = 1.0;
+  for (int t = hi - 1; t >= lo; --t) { run = val(t) + g * run; f *= g; }
+  loc[threadIdx.x] = run; pw[threadIdx.x] = f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double c = 0.0;
+    for (int k = 255; k >= 0; --k) { cin[k] = c; c = loc[k] + pw[k] * c; }
+  }
+  __syncthreads();
+  run = cin[threadIdx.x];
+  for (int t = hi - 1; t >= lo; --t) { run = val(t) + g * run; yr[t] = run; }
+}
+
+// ---- statistics / casts used by process_paths (batch_reinforce.py:178-197) ----
+__global__ __launch_bounds__(256) void k_sum_stats_partial(const double* __restrict__ x, int64_t N, double shift,
+                                                            double* __restrict__ part) {
+  __shared__ double sh[17];
+  double s = 0.0, q = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+    double v = x[i] - shift;
+    s += v; q += v * v;
+  }
+  s = block_sum(s, sh);
+  q = block_sum(q, sh);
+  if (threadIdx.x == 0) { part[blockIdx.x * 2] = s; part[blockIdx.x * 2 + 1] = q; }
+}
+__global__ void k_sum_stats_final(const double* __restrict__ part, int G, int64_t N, double* out) {
+  __shared__ double sh[17];
+  double s = 0.0, q = 0.0;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) { s += part[g * 2]; q += part[g * 2 + 1]; }
+  s = block_sum(s, sh);
+  q = block_sum(q, sh);
+  if (threadIdx.x == 0) { out[0] = s; out[1] = q; out[2] = (double)N; }
+}
+__global__ void k_whiten_cast(const double* __restrict__ a, int64_t N, double mean, double denom, float* __restrict__ o) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+    o[i] = (float)((a[i] - mean) / denom);
+}
+__global__ void k_cast_f64_f32(const double* __restrict__ a, int64_t N, float* __restrict__ o) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+    o[i] = (float)a[i];
+}
+
+}  // namespace mjx

@@ -1,0 +1,289 @@
+"""GPU parity tests: the HIP path (through the C ABI / ctypes) vs the golden fixtures produced by
+the unmodified reference and vs the fp64 oracle.
+
+Tolerances (relative L2 unless noted), from SURVEY section 6: the reference's own fp32 path sits
+4.9e-7 (VPG) / 1e-7 (HVP) / 1.6e-6 (CG step direction) from fp64 truth; north-star bar is 1e-5
+on the NPG step direction.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import npg_oracle as O
+from oracle import synth
+from tests._cases import NPG_CASES, NpgCase, load
+
+pytestmark = pytest.mark.gpu
+
+TOL_VPG = 3e-6
+TOL_FVP = 3e-6
+TOL_STEP = 1e-5          # the north-star bar
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def make_engine(c, layerwise=False):
+    import torch  # noqa: F401
+    from mjrl_amd.engine import UpdateEngine
+    if layerwise:
+        os.environ["MJX_FORCE_LAYERWISE"] = "1"
+    try:
+        eng = UpdateEngine(c.n, c.m, c.hidden)
+    finally:
+        os.environ.pop("MJX_FORCE_LAYERWISE", None)
+    return eng
+
+
+def packed_tr(c):
+    if c.tr is None:
+        return np.concatenate([np.zeros(c.n), np.ones(c.n), np.zeros(c.m), np.ones(c.m)]).astype(np.float32)
+    return np.concatenate([np.float32(x).ravel() for x in c.tr])
+
+
+@pytest.mark.parametrize("layerwise", [False, True])
+@pytest.mark.parametrize("name", NPG_CASES)
+def test_kernels_vs_reference(name, layerwise):
+    import torch
+    c = NpgCase(name)
+    eng = make_engine(c, layerwise)
+    if not layerwise and len(c.hidden) == 2 and max(c.hidden) <= 64:
+        assert eng.fused, "fused kernel should serve this shape"
+    tr = packed_tr(c)
+    eng.set_policy(c.theta0, c.theta0, tr, tr)
+    eng.set_batch(c.obs, c.act, c.adv_w)
+    g, surr = eng.surr_vpg()
+    assert rel(g.cpu().numpy(), c.g["vpg"]) < TOL_VPG
+    assert abs(surr - float(c.g["surr_before"])) < 1e-6
+    v = torch.from_numpy(c.g["vpg"]).to(eng.device)
+    hv = eng.fvp(v).cpu().numpy() + np.float32(1e-4) * c.g["vpg"]
+    assert rel(hv, c.g["hvp_of_vpg"]) < TOL_FVP
+    x, gx = eng.cg_solve(v, c.cg_iters, 1e-4)
+    assert rel(x.cpu().numpy(), c.g["cg_x"]) < TOL_STEP
+    assert abs(gx - float(np.dot(c.g["vpg"].astype(np.float64), c.g["cg_x"]))) < 1e-5 * abs(gx)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", NPG_CASES)
+def test_npg_agent_update_vs_reference(name):
+    """NPG.train_from_paths through the mjrl-shaped classes == the reference's train_from_paths."""
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.policies.gaussian_mlp import MLP, LinearPolicy
+    c = NpgCase(name)
+    spec = type("Spec", (), dict(observation_dim=c.n, action_dim=c.m, horizon=1000))
+    pol = MLP(spec, hidden_sizes=c.hidden, seed=1, init_log_std=-0.5) if c.hidden else LinearPolicy(spec, seed=1, init_log_std=-0.5)
+    pol.set_param_values(c.theta0)
+    if c.tr is not None:
+        pol.model.set_transformations(*c.tr)
+        pol.old_model.set_transformations(*c.tr)
+    agent = NPG(None, pol, None, normalized_step_size=float(c.g["step"]), FIM_invert_args={'iters': c.cg_iters, 'damping': 1e-4},
+                save_logs=True)
+    stats = agent.train_from_paths(c.paths)
+    step, ref = pol.get_param_values().astype(np.float64) - c.theta0, c.g["new_params"].astype(np.float64) - c.theta0
+    assert rel(step, ref) < TOL_STEP, rel(step, ref)
+    lg = agent.logger.get_current_log()
+    assert abs(lg["alpha"] - float(c.g["alpha"])) < 1e-5 * float(c.g["alpha"])
+    assert abs(lg["kl_dist"] - float(c.g["kl"])) < 1e-4 * float(c.g["kl"])
+    assert abs(lg["surr_improvement"] - float(c.g["surr_improvement"])) < 2e-5
+    np.testing.assert_allclose(stats, c.g["base_stats"], rtol=1e-12)
+    assert pol.old_equals_new()
+
+
+def test_trpo_line_search_vs_reference():
+    from mjrl_amd.algos.trpo import TRPO
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    c = NpgCase("trpo_cfg3_small")
+    spec = type("Spec", (), dict(observation_dim=c.n, action_dim=c.m, horizon=1000))
+    pol = MLP(spec, hidden_sizes=c.hidden, seed=1, init_log_std=-0.5)
+    pol.set_param_values(c.theta0)
+    agent = TRPO(None, pol, None, kl_dist=float(c.g["kl_dist"]), FIM_invert_args={'iters': c.cg_iters, 'damping': 1e-4})
+    agent.train_from_paths(c.paths)
+    assert agent.last_update["trials"] == 2                  # the fixture backtracks exactly once
+    assert abs(agent.last_update["alpha"] - float(c.g["alpha"])) < 1e-5 * float(c.g["alpha"])
+    assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < 1e-4 * float(c.g["kl"])
+    step, ref = pol.get_param_values().astype(np.float64) - c.theta0, c.g["new_params"].astype(np.float64) - c.theta0
+    assert rel(step, ref) < TOL_STEP
+
+
+def test_big_net_layerwise_vs_reference():
+    """cfg4 shapes (obs 376, act 17, 256x256, 25 CG iterations) on the layer-wise path."""
+    import torch
+    c = NpgCase("npg_cfg4_small")
+    eng = make_engine(c)
+    assert not eng.fused
+    tr = packed_tr(c)
+    eng.set_policy(c.theta0, c.theta0, tr, tr)
+    eng.set_batch(c.obs, c.act, c.adv_w)
+    g, _ = eng.surr_vpg()
+    gh = g.cpu().numpy()
+    c.check("vpg", gh, TOL_VPG)
+    hv = eng.fvp(g).cpu().numpy() + np.float32(1e-4) * gh
+    c.check("hvp_of_vpg", hv, 1e-5)
+    x, gx = eng.cg_solve(g, c.cg_iters, 1e-4)
+    c.check("cg_x", x.cpu().numpy(), 5e-5)      # 25 fp32 CG iterations on an N << d problem amplify round-off
+    alpha = np.sqrt(abs(float(c.g["step"]) / (gx + 1e-20)))
+    assert abs(alpha - float(c.g["alpha"])) < 2e-5 * float(c.g["alpha"])
+    eng.close()
+
+
+def test_dapg_vs_reference():
+    from mjrl_amd.algos.dapg import DAPG
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    c = NpgCase("dapg_cfg5_small")
+    spec = type("Spec", (), dict(observation_dim=c.n, action_dim=c.m, horizon=1000))
+    pol = MLP(spec, hidden_sizes=c.hidden, seed=1, init_log_std=-0.5)
+    pol.set_param_values(c.theta0)
+    agent = DAPG(None, pol, None, demo_paths=c.demo_paths, kl_dist=float(c.g["kl_dist"]), lam_0=float(c.g["lam_0"]),
+                 lam_1=float(c.g["lam_1"]), FIM_invert_args={'iters': c.cg_iters, 'damping': 1e-4})
+    agent.train_from_paths(c.paths)
+    assert abs(agent.last_update["alpha"] - float(c.g["alpha"])) < 5e-5 * float(c.g["alpha"])
+    assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < 1e-3 * float(c.g["kl"])
+    c.check("new_params", pol.get_param_values(), 1e-5)
+
+
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 1000, 4097])
+def test_ragged_tails_vs_oracle(N):
+    """N not a multiple of the 32-sample tile, N smaller than one tile, N == 1."""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    n, m, hid = 11, 3, (32, 32)
+    rng = np.random.RandomState(N)
+    th = synth.perturbed_params(synth.init_params(n, m, hid))
+    obs, act, adv = rng.randn(N, n), rng.randn(N, m), rng.randn(N)
+    eng = UpdateEngine(n, m, hid)
+    tr = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    eng.set_policy(th, th, tr, tr)
+    eng.set_batch(obs, act, adv)
+    th64 = th.astype(np.float64)
+    g, surr = eng.surr_vpg()
+    assert rel(g.cpu().numpy(), O.vpg(th64, th64, obs, act, adv, n, m, hid)) < TOL_VPG
+    assert abs(surr - adv.mean()) < 1e-6
+    v = rng.randn(th.size).astype(np.float32)
+    hv = eng.fvp(torch.from_numpy(v).to(eng.device)).cpu().numpy()
+    assert rel(hv, O.fvp(th64, obs, v.astype(np.float64), n, m, hid)) < TOL_FVP
+    eng.close()
+
+
+def test_old_neq_new_surrogate_kl_and_vpg():
+    """K1 / K3 with theta_new != theta_old and different input transforms (the input_normalization
+    situation, npg_cg.py:101-107) against the reference's own outputs."""
+    from mjrl_amd.engine import UpdateEngine
+    g = load("hvp_general_64x64")
+    n, m, hid = int(g["n"]), int(g["m"]), tuple(int(h) for h in g["hidden"])
+    paths = synth.make_paths(int(g["n_traj"]), int(g["T"]), n, m, seed=0)
+    from tests._cases import fake_advantages
+    fake_advantages(paths, 5)
+    obs = np.concatenate([p["observations"] for p in paths]); act = np.concatenate([p["actions"] for p in paths])
+    adv = O.whiten(np.concatenate([p["advantages"] for p in paths]))
+    eng = UpdateEngine(n, m, hid)
+    ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    trn = np.concatenate([np.float32(g["in_shift"]), np.float32(g["in_scale"]), np.zeros(m, np.float32), np.ones(m, np.float32)])
+    eng.set_policy(g["theta_new"], g["theta_old"], trn, ident)
+    eng.set_batch(obs, act, adv)
+    assert not eng.old_is_new
+    surr, kl = eng.eval_surr_kl()
+    assert abs(surr - float(g["surr"])) < 2e-6 and abs(kl - float(g["kl"])) < 1e-5 * float(g["kl"])
+    gv, surr2 = eng.surr_vpg()
+    assert rel(gv.cpu().numpy(), g["vpg"]) < TOL_VPG and abs(surr2 - float(g["surr"])) < 2e-6
+    eng.close()
+
+
+def test_shard_sum_parity():
+    """Multi-GPU math on one device: R trajectory shards bound one after the other with the global
+    N; the sum of their partial gradients / Fisher-vector products equals the unsharded result."""
+    import torch
+    c = NpgCase("npg_cfg2_small")
+    eng = make_engine(c)
+    tr = packed_tr(c)
+    eng.set_policy(c.theta0, c.theta0, tr, tr)
+    eng.set_batch(c.obs, c.act, c.adv_w)
+    g_full = eng.surr_vpg()[0].clone()
+    v = g_full.clone()
+    h_full = eng.fvp(v).clone()
+    N = c.obs.shape[0]
+    cuts = [0, 1500, 4000, 4001, N]
+    g_sum, h_sum = torch.zeros_like(g_full), torch.zeros_like(h_full)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        eng.set_batch(c.obs[lo:hi], c.act[lo:hi], c.adv_w[lo:hi], N_global=N)
+        g_sum += eng.surr_vpg()[0]
+        h_sum += eng.fvp(v)
+    assert rel(g_sum.cpu().numpy(), g_full.cpu().numpy()) < 5e-7
+    assert rel(h_sum.cpu().numpy(), h_full.cpu().numpy()) < 5e-7
+    eng.close()
+
+
+def test_fvp_properties_full_size():
+    """BASELINE size (1M x 17, 64x64): size-independent properties of the Fisher-vector product --
+    linearity, symmetry, positive semi-definiteness, and fused == layer-wise."""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    n, m, hid, N = 17, 6, (64, 64), 1000 * 1000
+    rng = np.random.RandomState(0)
+    obs = rng.randn(N, n).astype(np.float32)
+    th = synth.perturbed_params(synth.init_params(n, m, hid))
+    tr = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    eng = UpdateEngine(n, m, hid)
+    eng.set_policy(th, th, tr, tr)
+    eng.set_batch(obs)
+    v1 = torch.from_numpy(rng.randn(th.size).astype(np.float32)).to(eng.device)
+    v2 = torch.from_numpy(rng.randn(th.size).astype(np.float32)).to(eng.device)
+    h1, h2 = eng.fvp(v1).clone(), eng.fvp(v2).clone()
+    h12 = eng.fvp(2.0 * v1 - 0.5 * v2).clone()
+    assert rel(h12.cpu().numpy(), (2.0 * h1 - 0.5 * h2).cpu().numpy()) < 2e-6          # linearity
+    a, b = float(torch.dot(v1.double(), h2.double())), float(torch.dot(v2.double(), h1.double()))
+    assert abs(a - b) < 1e-5 * max(abs(a), abs(b), 1e-12)                               # symmetry
+    assert float(torch.dot(v1.double(), h1.double())) > 0                                # PSD
+    assert rel(eng.fvp(v1).cpu().numpy(), h1.cpu().numpy()) == 0.0                      # deterministic
+    os.environ["MJX_FORCE_LAYERWISE"] = "1"
+    try:
+        lw = UpdateEngine(n, m, hid)
+    finally:
+        os.environ.pop("MJX_FORCE_LAYERWISE", None)
+    lw.set_policy(th, th, tr, tr)
+    lw.set_batch(obs)
+    assert rel(lw.fvp(v1).cpu().numpy(), h1.cpu().numpy()) < 2e-6                       # two independent kernels agree
+    # and a 20k-sample slice against the fp64 oracle
+    eng.set_batch(obs[:20000])
+    hv = eng.fvp(v1).cpu().numpy()
+    assert rel(hv, O.fvp(th.astype(np.float64), obs[:20000].astype(np.float64), v1.cpu().numpy().astype(np.float64), n, m, hid)) < TOL_FVP
+    eng.close(); lw.close()
+
+
+@pytest.mark.parametrize("kind", ["mlp", "quadratic", "linear"])
+def test_returns_and_gae_vs_reference(kind):
+    """K5 against the reference's compute_returns / compute_advantages (ragged, terminated paths)."""
+    from mjrl_amd.utils import process_samples
+    g = load("gae_" + kind)
+    n, m = int(g["n"]), int(g["m"])
+    paths = synth.make_paths(int(g["n_traj"]), int(g["T"]), n, m, seed=int(g["path_seed"]), ragged=True)
+    gamma, lam = float(g["gamma"]), float(g["lam"])
+    process_samples.compute_returns(paths, gamma)
+    np.testing.assert_allclose(np.concatenate([p["returns"] for p in paths]), g["returns"], rtol=1e-12, atol=1e-12)
+
+    class Frozen:                      # baseline predictions taken from the fixture
+        def __init__(self):
+            self.k = 0
+        def predict(self, path):
+            T = len(path["rewards"]); out = g["baseline_pred"][self.k:self.k + T]; self.k += T
+            return np.asarray(out, np.float64)
+    process_samples.compute_advantages(paths, Frozen(), gamma, lam)
+    np.testing.assert_allclose(np.concatenate([p["advantages"] for p in paths]), g["advantages"], rtol=1e-10, atol=1e-10)
+    process_samples.compute_advantages(paths, Frozen(), gamma, None)
+    np.testing.assert_allclose(np.concatenate([p["advantages"] for p in paths]), g["advantages_nogae"], rtol=1e-10, atol=1e-10)
+    x = np.random.RandomState(1).randn(777)
+    np.testing.assert_allclose(process_samples.discount_sum(x, 0.9), O.discount_sum(x, 0.9), rtol=1e-12, atol=1e-12)
+
+
+def test_scan_full_size_properties():
+    """1M timesteps: linearity of the scan and the one-step recurrence y[t] - g*y[t+1] == x[t]."""
+    from mjrl_amd.utils import process_samples
+    rng = np.random.RandomState(3)
+    paths = [dict(rewards=rng.randn(1000)) for _ in range(1000)]
+    process_samples.compute_returns(paths, 0.995)
+    for p in paths[::97]:
+        y, x = p["returns"], p["rewards"]
+        np.testing.assert_allclose(y[:-1] - 0.995 * y[1:], x[:-1], rtol=0, atol=1e-12)
+        assert y[-1] == x[-1]

@@ -1,0 +1,109 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/mjx.h declares, host
+classes behave like the reference's (pickle / deepcopy / RNG stream), and the product path fails
+loudly without a GPU."""
+import copy
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from mjrl_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "mjx.h")).read()
+    declared = set(re.findall(r"\b(mjx_[a-z0-9_]+)\s*\(", hdr)) - {"mjx_allreduce_fn"}
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mjx_version() >= 1
+    assert lib.mjx_device_count() >= 0
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mjrl_amd import _lib
+    from mjrl_amd.engine import UpdateEngine
+    with pytest.raises(_lib.MjxError):
+        UpdateEngine(17, 6, (64, 64))
+    import ctypes
+    lib = _lib.load()
+    ctx = ctypes.c_void_p()
+    rc = lib.mjx_create(ctypes.byref(ctx), 0, 17, 6, (ctypes.c_int * 2)(64, 64), 2)
+    assert rc == -4 and b"not available" in lib.mjx_last_error()
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mjrl_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle", ""), (dirpath, f)
+
+
+def _spec(n, m):
+    return type("Spec", (), dict(observation_dim=n, action_dim=m, horizon=100))
+
+
+def test_policy_surface_and_lifecycle():
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    from mjrl_amd.policies.gaussian_linear import LinearPolicy
+    p = MLP(_spec(17, 6), hidden_sizes=(64, 64), seed=7, init_log_std=-0.5)
+    assert p.d == 17 * 64 + 64 + 64 * 64 + 64 + 64 * 6 + 6 + 6 == sum(p.param_sizes)
+    th = p.get_param_values()
+    assert th.dtype == np.float32 and th is not p.get_param_values()
+    new = th.copy(); new[-6:] = -10.0
+    p.set_param_values(new, set_new=True, set_old=False)
+    assert np.all(p.get_param_values()[-6:] == -3.0) and not p.old_equals_new()      # clamp at min_log_std
+    assert np.allclose(p.log_std_val, -3.0)
+    p.set_param_values(new, set_new=True, set_old=True)
+    assert p.old_equals_new()
+    q, r = pickle.loads(pickle.dumps(p)), copy.deepcopy(p)
+    o = np.random.RandomState(0).randn(17)
+    np.random.seed(3); a = p.get_action(o)
+    np.random.seed(3); b = q.get_action(o)
+    np.random.seed(3); c = r.get_action(o)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[0], c[0])
+    assert set(a[1]) == {"mean", "log_std", "evaluation"}
+    lin = LinearPolicy(_spec(6, 2), seed=1)
+    assert lin.d == 6 * 2 + 2 + 2 and lin.hidden_sizes == ()
+    # host operators agree with the oracle
+    from oracle import npg_oracle as O
+    obs, act = np.random.RandomState(1).randn(50, 17), np.random.RandomState(2).randn(50, 6)
+    ll = p.log_likelihood(obs, act)
+    ll_o, _ = O.log_likelihood(p.get_param_values().astype(np.float64), obs, act, 17, 6, (64, 64))
+    assert np.allclose(ll, ll_o, rtol=1e-5, atol=1e-5)
+    assert abs(p.mean_kl(p.new_dist_info(obs, act), p.old_dist_info(obs, act))) < 1e-6
+
+
+def test_host_cg_matches_oracle():
+    from mjrl_amd.utils.cg_solve import cg_solve
+    from oracle import npg_oracle as O
+    rng = np.random.RandomState(0)
+    A = rng.randn(30, 30); A = A @ A.T + 0.1 * np.eye(30)
+    b = rng.randn(30)
+    x = cg_solve(lambda v: A @ v, b, x_0=b.copy(), cg_iters=7)
+    np.testing.assert_allclose(x, O.cg_solve(lambda v: A @ v, b, 7), rtol=1e-12)
+
+
+def test_agent_pickles_without_engine():
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.algos.trpo import TRPO
+    from mjrl_amd.algos.dapg import DAPG
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    pol = MLP(_spec(5, 2), hidden_sizes=(32, 32), seed=0)
+    for cls, kw in ((NPG, dict(normalized_step_size=0.05, hvp_sample_frac=0.5, input_normalization=0.9)),
+                    (TRPO, dict(kl_dist=0.01)), (DAPG, dict(demo_paths=None, lam_0=0.1))):
+        a = cls(None, pol, None, save_logs=True, seed=5, some_unknown_kwarg=1, **kw)
+        b = pickle.loads(pickle.dumps(a))
+        assert b.seed == 5 and b._engine_obj is None
+    assert NPG(None, pol, None, kl_dist=0.02).n_step_size == 0.04          # kl_dist overrides (npg_cg.py:49)
+    assert NPG(None, pol, None, input_normalization=1.5).input_normalization is None
