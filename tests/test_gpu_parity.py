@@ -187,7 +187,12 @@ def test_old_neq_new_surrogate_kl_and_vpg():
     surr, kl = eng.eval_surr_kl()
     assert abs(surr - float(g["surr"])) < 2e-6 and abs(kl - float(g["kl"])) < 1e-5 * float(g["kl"])
     gv, surr2 = eng.surr_vpg()
-    assert rel(gv.cpu().numpy(), g["vpg"]) < TOL_VPG and abs(surr2 - float(g["surr"])) < 2e-6
+    # likelihood ratios span 7e-5 .. 1.3e3 here; the reference's own fp32 gradient sits 3.3e-6 from the
+    # fp64 oracle on this case, so compare with the oracle tightly and with the reference at 1e-5
+    tr64 = O.Transforms(n, m, g["in_shift"], g["in_scale"])
+    truth = O.vpg(g["theta_new"].astype(np.float64), g["theta_old"].astype(np.float64), obs, act, adv, n, m, hid, tr64, None)
+    assert rel(gv.cpu().numpy(), truth) < 5e-6
+    assert rel(gv.cpu().numpy(), g["vpg"]) < 1e-5 and abs(surr2 - float(g["surr"])) < 2e-6
     eng.close()
 
 
