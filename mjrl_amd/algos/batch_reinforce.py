@@ -146,24 +146,29 @@ class BatchREINFORCE:
         advantages = np.concatenate([path["advantages"] for path in paths])
         path_returns = np.array([float(np.sum(p["rewards"])) for p in paths])
         d = _dist()
-        if d is None:
-            mean, std = np.mean(advantages), np.std(advantages)
-        else:
-            torch = self.engine.torch
+        if d is not None:
             gathered = [None] * d.get_world_size()
             d.all_gather_object(gathered, path_returns)
             path_returns = np.concatenate(gathered)
-            s = torch.tensor([advantages.sum(), float(advantages.size)], dtype=torch.float64, device=self.engine.device)
-            d.all_reduce(s)
-            mean = float(s[0] / s[1])
-            q = torch.tensor([((advantages - mean) ** 2).sum()], dtype=torch.float64, device=self.engine.device)
-            d.all_reduce(q)
-            std = float(np.sqrt(q.item() / s[1].item()))
+        mean, std = self._global_mean_std(advantages)
         advantages = (advantages - mean) / (std + 1e-6)
         mean_return = np.mean(path_returns)
         base_stats = [mean_return, np.std(path_returns), np.amin(path_returns), np.amax(path_returns)]
         running_score = mean_return if self.running_score is None else 0.9 * self.running_score + 0.1 * mean_return
         return observations, actions, advantages, base_stats, running_score
+
+    def _global_mean_std(self, x):
+        """population mean / std of a sample vector that is sharded over the ranks"""
+        d = _dist()
+        if d is None:
+            return np.mean(x), np.std(x)
+        torch = self.engine.torch
+        s = torch.tensor([x.sum(), float(x.size)], dtype=torch.float64, device=self.engine.device)
+        d.all_reduce(s)
+        mean = float(s[0] / s[1])
+        q = torch.tensor([((x - mean) ** 2).sum()], dtype=torch.float64, device=self.engine.device)
+        d.all_reduce(q)
+        return mean, float(np.sqrt(q.item() / s[1].item()))
 
     def log_rollout_statistics(self, paths):
         """batch_reinforce.py:200-214"""

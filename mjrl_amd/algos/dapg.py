@@ -45,41 +45,33 @@ class DAPG(NPG):
         N = observations.shape[0]
         use_demos = self.demo_paths is not None and self.lam_0 > 0.0
         if use_demos:                                          # dapg.py:62-70
-            demo_obs = np.concatenate([p["observations"] for p in self.demo_paths])
-            demo_act = np.concatenate([p["actions"] for p in self.demo_paths])
+            from ..engine import _dist
+            d = _dist()
+            demos = self.demo_paths if d is None else self.demo_paths[d.get_rank()::d.get_world_size()]   # shard demos too
+            demo_obs = np.concatenate([p["observations"] for p in demos]) if demos else np.zeros((0, observations.shape[1]))
+            demo_act = np.concatenate([p["actions"] for p in demos]) if demos else np.zeros((0, actions.shape[1]))
             demo_adv = self.lam_0 * (self.lam_1 ** self.iter_count) * np.ones(demo_obs.shape[0])
             self.iter_count += 1
             all_obs = np.concatenate([observations, demo_obs])
             all_act = np.concatenate([actions, demo_act])
-            all_adv = 1e-2 * np.concatenate([advantages / (np.std(advantages) + 1e-8), demo_adv])
+            all_adv = 1e-2 * np.concatenate([advantages / (self._global_mean_std(advantages)[1] + 1e-8), demo_adv])
         else:
             all_obs, all_act, all_adv = observations, actions, advantages
 
         eng = self.engine
         self._push_policy()
-        # on-policy rows first: surrogate before the step (dapg.py:92)
-        eng.set_batch(all_obs, all_act, all_adv)
-        N_all_global, N_all_local = eng.N_global, eng.N_local
-        on_global = N_all_global - (N_all_local - N)           # single rank: == N
-        d = None
-        from ..engine import _dist
-        d = _dist()
-        if d is not None:
-            t = eng.torch.tensor([float(N)], dtype=eng.torch.float64, device=eng.device)
-            d.all_reduce(t)
-            on_global = int(t.item())
-        adv_on = eng.to_device_f32(advantages)
+        eng.set_batch(all_obs, all_act, all_adv)               # [on-policy ; demos] uploaded once
+        N_all_global = eng.N_global
+        N_on_global = eng.global_count(N)
 
         t0 = timer.time()
-        g, _ = eng.surr_vpg()                                  # K1 over [on-policy ; demos], mean over N_all
-        sample_coef = N_all_global / on_global                 # dapg.py:97-98
-        g.mul_(sample_coef)
+        g, _ = eng.surr_vpg()                                  # K1 over all rows, mean over N_all
+        g.mul_(N_all_global / N_on_global)                     # sample_coef, dapg.py:97-98
         t_gLL = timer.time() - t0
 
-        adv_all_dev = eng.adv
-        eng.N_global = on_global                               # Fisher / surrogate / KL: on-policy prefix only
-        eng.bind_rows(N, adv=adv_on)
-        surr_before = eng.eval_surr_kl()[0]
+        # Fisher / surrogate / KL: on-policy prefix only, means over the on-policy count
+        eng.bind_rows(N, adv=advantages, N_global=N_on_global)
+        surr_before = eng.eval_surr_kl()[0]                    # dapg.py:92 (theta_new == theta_old here)
         t0 = timer.time()
         _, gdotx = self.CG_solve(g)                            # dapg.py:103-106
         t_FIM = timer.time() - t0
@@ -89,7 +81,6 @@ class DAPG(NPG):
         eng.apply_step(alpha, self.policy.min_log_std)
         surr_after, kl_dist = eng.eval_surr_kl()
         self.policy.set_param_values(eng.theta_new.cpu().numpy(), set_new=True, set_old=True)
-        del adv_all_dev
 
         if self.save_logs:
             self._log_update(paths, alpha, n_step_size, t_gLL, t_FIM, kl_dist, surr_before, surr_after)

@@ -74,22 +74,22 @@ class NPG(BatchREINFORCE):
     def _cg_subsampled(self, b, iters, damping):
         """hvp_sample_frac < 0.99: a fresh with-replacement row sample per product, drawn from
         NumPy's global RNG exactly like npg_cg.py:65-69."""
-        from .._lib import check, ptr
-        import ctypes
-        eng, lib, torch = self.engine, self.engine.lib, self.engine.torch
-        full_obs, full_act, full_adv, Nl, Ng = eng.obs, eng.act, eng.adv, eng.N_local, eng.N_global
-        st = eng.stream()
-        check(lib.mjx_cg_init(eng.ctx, ptr(b), st))
-        p = ctypes.c_void_p(lib.mjx_cg_p(eng.ctx))
+        eng, be, torch = self.engine, self.engine.backend, self.engine.torch
+        full = (eng.obs, eng.act, eng.adv, eng.N_local, eng.N_global)
+        Nl, Ng = full[3], full[4]
         k = int(self.hvp_subsample * Nl)
+        from ..engine import _dist
+        d = _dist()
+        be.cg_init(b)
         for _ in range(int(iters)):
             idx = torch.from_numpy(np.random.choice(Nl, size=k)).to(eng.device)
-            sub = full_obs.index_select(0, idx)
-            check(lib.mjx_bind_batch(eng.ctx, ptr(sub), None, None, k, int(round(k * Ng / max(Nl, 1)))))
-            eng.fvp(p, eng.Ap)
-            check(lib.mjx_cg_step(eng.ctx, ptr(eng.Ap), float(damping), 1e-10, st))
-        check(lib.mjx_cg_finish(eng.ctx, ptr(b), ptr(eng.x), ptr(eng.bdotx), st))
-        eng.obs, eng.act, eng.adv = full_obs, full_act, full_adv
+            sub = full[0].index_select(0, idx)
+            be.bind_batch(sub, None, None, k, eng.global_count(k))
+            be.fvp_of_cg_direction(eng.Ap)
+            if d is not None:
+                d.all_reduce(eng.Ap)
+            be.cg_step(eng.Ap, damping, 1e-10)
+        be.cg_finish(b, eng.x, eng.bdotx)
         eng.bind_rows(Nl)
         return eng.x, float(eng.bdotx.item())
 

@@ -25,7 +25,10 @@ def _dist():
     return None
 
 
-class UpdateEngine:
+class HipBackend:
+    """Local (this-rank) compute: thin ctypes shim over libmjx.so.  All arguments are torch tensors
+    living on ``self.device``; nothing here communicates or synchronises."""
+
     def __init__(self, n, m, hidden_sizes, device=None):
         import torch
         self.torch = torch
@@ -33,13 +36,85 @@ class UpdateEngine:
         if self.lib.mjx_device_count() < 1 or not torch.cuda.is_available():
             raise _lib.MjxError("mjrl_amd needs an AMD GPU (gfx950): no HIP device visible and there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.n, self.m, self.hidden = int(n), int(m), tuple(int(h) for h in hidden_sizes)
         ctx = ctypes.c_void_p()
-        harr = (ctypes.c_int * max(1, len(self.hidden)))(*self.hidden)
-        check(self.lib.mjx_create(ctypes.byref(ctx), self.device.index or 0, self.n, self.m, harr, len(self.hidden)))
+        hidden = tuple(int(h) for h in hidden_sizes)
+        harr = (ctypes.c_int * max(1, len(hidden)))(*hidden)
+        check(self.lib.mjx_create(ctypes.byref(ctx), self.device.index or 0, int(n), int(m), harr, len(hidden)))
         self.ctx = ctx
         self.d = int(self.lib.mjx_num_params(ctx))
         self.fused = bool(self.lib.mjx_uses_fused_path(ctx))
+
+    def close(self):
+        if getattr(self, "ctx", None) is not None:
+            self.torch.cuda.synchronize(self.device)
+            self.lib.mjx_destroy(self.ctx)
+            self.ctx = None
+
+    def stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def upload_f32(self, a):
+        """host ndarray (fp64 or fp32) -> fp32 device tensor.  fp64 input is cast on the device
+        (one PCIe pass of the raw fp64 rollouts; the reference re-casts on the CPU at every
+        call, gaussian_mlp.py:102-109)."""
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.float32).contiguous()
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        if t.dtype == torch.float64:
+            out = torch.empty(t.shape, dtype=torch.float32, device=self.device)
+            check(self.lib.mjx_cast_f64_f32(ptr(t), t.numel(), ptr(out), self.stream()))
+            return out
+        return t.to(torch.float32)
+
+    def bind_policy(self, theta_new, theta_old, tr_new, tr_old, old_is_new):
+        check(self.lib.mjx_bind_policy(self.ctx, ptr(theta_new), ptr(theta_old), ptr(tr_new), ptr(tr_old), int(old_is_new)))
+
+    def bind_batch(self, obs, act, adv, rows, N_global):
+        check(self.lib.mjx_bind_batch(self.ctx, ptr(obs), ptr(act), ptr(adv), int(rows), int(N_global)))
+
+    def surr_vpg(self, grad_out, scal_out):
+        check(self.lib.mjx_surr_vpg(self.ctx, ptr(grad_out), ptr(scal_out), self.stream()))
+
+    def fvp(self, v, out):
+        check(self.lib.mjx_fvp(self.ctx, ptr(v), ptr(out), self.stream()))
+
+    def eval_surr_kl(self, scal_out):
+        check(self.lib.mjx_eval_surr_kl(self.ctx, ptr(scal_out), self.stream()))
+
+    def cg_solve_local(self, b, iters, damping, tol, x_out, bdotx_out):
+        check(self.lib.mjx_cg_solve(self.ctx, ptr(b), int(iters), float(damping), float(tol), ptr(x_out), ptr(bdotx_out),
+                                    None, None, self.stream()))
+
+    def cg_init(self, b):
+        check(self.lib.mjx_cg_init(self.ctx, ptr(b), self.stream()))
+
+    def fvp_of_cg_direction(self, out):
+        check(self.lib.mjx_fvp(self.ctx, ctypes.c_void_p(self.lib.mjx_cg_p(self.ctx)), ptr(out), self.stream()))
+
+    def cg_step(self, Ap, damping, tol):
+        check(self.lib.mjx_cg_step(self.ctx, ptr(Ap), float(damping), float(tol), self.stream()))
+
+    def cg_finish(self, b, x_out, bdotx_out):
+        check(self.lib.mjx_cg_finish(self.ctx, ptr(b), ptr(x_out), ptr(bdotx_out), self.stream()))
+
+    def apply_step(self, base, x, alpha, min_log_std, out):
+        check(self.lib.mjx_apply_step(self.ctx, ptr(base), ptr(x), float(alpha), float(min_log_std), ptr(out), self.stream()))
+
+
+class UpdateEngine:
+    """Orchestration of one policy update over (possibly) several ranks: owns the tensors, binds
+    batch / policy, and places the all-reduces.  ``backend`` does this rank's arithmetic
+    (``HipBackend`` in production; the multi-rank logic is exercised on CPU/gloo in
+    tests/test_distributed_gloo.py with an oracle-backed stand-in)."""
+
+    def __init__(self, n, m, hidden_sizes, device=None, backend=None):
+        self.n, self.m, self.hidden = int(n), int(m), tuple(int(h) for h in hidden_sizes)
+        self.backend = backend if backend is not None else HipBackend(n, m, hidden_sizes, device)
+        self.torch = torch = self.backend.torch
+        self.device = self.backend.device
+        self.d = self.backend.d
+        self.fused = getattr(self.backend, "fused", False)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.theta_new = torch.zeros(self.d, **f32)
         self.theta_old = torch.zeros(self.d, **f32)
@@ -55,11 +130,21 @@ class UpdateEngine:
         self.old_is_new = True
         self._dbg = None
 
+    # convenience handles used by bench / tests
+    @property
+    def lib(self):
+        return self.backend.lib
+
+    @property
+    def ctx(self):
+        return self.backend.ctx
+
+    def stream(self):
+        return self.backend.stream()
+
     def close(self):
-        if getattr(self, "ctx", None) is not None:
-            self.torch.cuda.synchronize(self.device)
-            self.lib.mjx_destroy(self.ctx)
-            self.ctx = None
+        if getattr(self, "backend", None) is not None:
+            self.backend.close()
 
     def __del__(self):
         try:
@@ -67,24 +152,8 @@ class UpdateEngine:
         except Exception:
             pass
 
-    # ------------------------------------------------------------------ helpers
-    def stream(self):
-        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
-
     def to_device_f32(self, a):
-        """host ndarray (fp64 or fp32) -> fp32 device tensor.  fp64 input is cast on the device
-        (one PCIe pass of the raw fp64 rollouts; the reference re-casts on the CPU at every
-        call, gaussian_mlp.py:102-109)."""
-        torch = self.torch
-        if isinstance(a, torch.Tensor):
-            return a.to(device=self.device, dtype=torch.float32).contiguous()
-        a = np.ascontiguousarray(a)
-        t = torch.from_numpy(a).to(self.device, non_blocking=False)
-        if t.dtype == torch.float64:
-            out = torch.empty(t.shape, dtype=torch.float32, device=self.device)
-            check(self.lib.mjx_cast_f64_f32(ptr(t), t.numel(), ptr(out), self.stream()))
-            return out
-        return t.to(torch.float32)
+        return self.backend.upload_f32(a)
 
     # ------------------------------------------------------------------ binding
     def set_policy(self, theta_new, theta_old, tr_new, tr_old):
@@ -100,8 +169,15 @@ class UpdateEngine:
         self._bind_policy()
 
     def _bind_policy(self):
-        check(self.lib.mjx_bind_policy(self.ctx, ptr(self.theta_new), ptr(self.theta_old), ptr(self.tr_new),
-                                       ptr(self.tr_old), int(self.old_is_new)))
+        self.backend.bind_policy(self.theta_new, self.theta_old, self.tr_new, self.tr_old, self.old_is_new)
+
+    def global_count(self, local_count):
+        d = _dist()
+        if d is None:
+            return int(local_count)
+        t = self.torch.tensor([float(local_count)], dtype=self.torch.float64, device=self.device)
+        d.all_reduce(t)
+        return int(round(t.item()))
 
     def set_batch(self, obs, act=None, adv=None, N_global=None):
         """obs (N,n), act (N,m), adv (N,) of THIS rank's shard; host arrays or device tensors."""
@@ -109,32 +185,23 @@ class UpdateEngine:
         self.act = None if act is None else self.to_device_f32(act)
         self.adv = None if adv is None else self.to_device_f32(adv)
         self.N_local = int(self.obs.shape[0])
-        if N_global is None:
-            N_global = self.N_local
-            d = _dist()
-            if d is not None:
-                t = self.torch.tensor([float(self.N_local)], dtype=self.torch.float64, device=self.device)
-                d.all_reduce(t)
-                N_global = int(t.item())
-        self.N_global = int(N_global)
+        self.N_global = self.global_count(self.N_local) if N_global is None else int(N_global)
         self.bind_rows(self.N_local)
 
-    def bind_rows(self, rows, adv=None):
+    def bind_rows(self, rows, adv=None, N_global=None):
         """(re)bind the first `rows` samples of the uploaded block (DAPG runs the Fisher on the
         on-policy prefix of the demo-augmented block, dapg.py:97-103)."""
         if adv is not None:
             self.adv = self.to_device_f32(adv)
-        check(self.lib.mjx_bind_batch(self.ctx, ptr(self.obs), ptr(self.act), ptr(self.adv), int(rows), int(self.N_global)))
+        if N_global is not None:
+            self.N_global = int(N_global)
+        self.backend.bind_batch(self.obs, self.act, self.adv, int(rows), int(self.N_global))
 
-    def set_N_global(self, N_global, rows=None):
-        self.N_global = int(N_global)
-        self.bind_rows(self.N_local if rows is None else rows)
-
-    # ------------------------------------------------------------------ kernels
+    # ------------------------------------------------------------------ kernels + collectives
     def surr_vpg(self):
         """K1 -> (grad device tensor, surrogate float).  flat_vpg + CPI_surrogate
         (batch_reinforce.py:40-58)."""
-        check(self.lib.mjx_surr_vpg(self.ctx, ptr(self.grad), ptr(self.scal), self.stream()))
+        self.backend.surr_vpg(self.grad, self.scal)
         d = _dist()
         if d is not None:
             d.all_reduce(self.grad)
@@ -145,40 +212,39 @@ class UpdateEngine:
     def fvp(self, v, out=None):
         """K2: (H v) without damping, reduced over ranks (npg_cg.py:62-81)."""
         out = self.Ap if out is None else out
-        check(self.lib.mjx_fvp(self.ctx, ptr(v), ptr(out), self.stream()))
+        self.backend.fvp(v, out)
         d = _dist()
         if d is not None:
             d.all_reduce(out)
         return out
 
     def cg_solve(self, b, iters, damping, tol=1e-10):
-        """K4: x = CG(H + damping I, b), x0 = 0 (cg_solve.py:3-22) -> (x device tensor, b.x)."""
+        """K4: x = CG(H + damping I, b), x0 = 0 (cg_solve.py:3-22) -> (x device tensor, b.x).
+        One all-reduce of the d-float Fisher-vector product per iteration; the vector updates
+        and dot products are recomputed identically on every rank."""
         d = _dist()
-        st = self.stream()
+        be = self.backend
         if d is None:
-            check(self.lib.mjx_cg_solve(self.ctx, ptr(b), int(iters), float(damping), float(tol), ptr(self.x),
-                                        ptr(self.bdotx), None, None, st))
+            be.cg_solve_local(b, iters, damping, tol, self.x, self.bdotx)
         else:
-            check(self.lib.mjx_cg_init(self.ctx, ptr(b), st))
-            p = ctypes.c_void_p(self.lib.mjx_cg_p(self.ctx))
+            be.cg_init(b)
             for _ in range(int(iters)):
-                check(self.lib.mjx_fvp(self.ctx, p, ptr(self.Ap), st))
+                be.fvp_of_cg_direction(self.Ap)
                 d.all_reduce(self.Ap)
-                check(self.lib.mjx_cg_step(self.ctx, ptr(self.Ap), float(damping), float(tol), st))
-            check(self.lib.mjx_cg_finish(self.ctx, ptr(b), ptr(self.x), ptr(self.bdotx), st))
+                be.cg_step(self.Ap, damping, tol)
+            be.cg_finish(b, self.x, self.bdotx)
         return self.x, float(self.bdotx.item())
 
     def apply_step(self, alpha, min_log_std, base=None):
         """theta_new <- base + alpha * x with the log_std clamp (npg_cg.py:137-139)."""
         base = self.theta_old if base is None else base
-        check(self.lib.mjx_apply_step(self.ctx, ptr(base), ptr(self.x), float(alpha), float(min_log_std),
-                                      ptr(self.theta_new), self.stream()))
+        self.backend.apply_step(base, self.x, alpha, min_log_std, self.theta_new)
         self.old_is_new = False
         self._bind_policy()
 
     def eval_surr_kl(self):
         """K3 -> (surrogate, mean KL) (batch_reinforce.py:40-52)."""
-        check(self.lib.mjx_eval_surr_kl(self.ctx, ptr(self.scal), self.stream()))
+        self.backend.eval_surr_kl(self.scal)
         d = _dist()
         if d is not None:
             d.all_reduce(self.scal)
