@@ -70,6 +70,8 @@ int mjx_stream_sync(void* stream);
  * blocks of THIS rank's trajectory shard, fp32 row-major -- the arrays
  * process_paths concatenates (mjrl/algos/batch_reinforce.py:178-185).
  * N_global = total samples over all ranks (means are taken over N_global).
+ * obs must be 16-byte aligned (it is read with 16-byte loads, and up to 12 bytes past its
+ * end may be read -- always inside the allocation for hipMalloc / torch memory).
  * act / adv may be NULL when only mjx_fvp is used. */
 int mjx_bind_batch(mjx_ctx* ctx, const float* obs, const float* act, const float* adv,
                    int64_t N_local, int64_t N_global);

@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace mjx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -75,6 +77,7 @@ struct FusedLayout {
   static constexpr int MT1 = H1 / 32, MT2 = H2 / 32;
   static constexpr int S2 = H1 + 4;             // row stride of W2 (ds_read_b128, S2/4 odd)
   static constexpr int ST = 36;                 // row stride of [unit][sample] scratch
+  static constexpr int S3 = H2 + 4;             // row stride of W3 ([MP][S3])
   static constexpr int HM = (H1 > H2 ? H1 : H2);
   int NP;                                       // features + ones column, padded to 4
   int S1;                                       // row stride of xs / W1a (ds_read_b64, == 2 mod 4)
@@ -87,8 +90,8 @@ struct FusedLayout {
     S1 = NP + 2;
     oW1 = 0;
     oW2 = oW1 + H1 * S1;
-    oW3 = oW2 + H2 * S2;                        // [MP][H2]
-    oB2 = oW3 + MP * H2;
+    oW3 = oW2 + H2 * S2;                        // [MP][S3]
+    oB2 = oW3 + MP * S3;
     oB3 = oB2 + H2;
     SLOT = ((oB3 + MP + 3) / 4) * 4;
     oXS = 0;                                    // [32][S1]
@@ -117,7 +120,8 @@ struct FlatOff {
 template <int H1, int H2, int NT1, int MP, int MODE, bool DBG = false>
 __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   using LT = FusedLayout<H1, H2, NT1, MP>;
-  constexpr int MT1 = LT::MT1, MT2 = LT::MT2, S2 = LT::S2, ST = LT::ST;
+  constexpr int MT1 = LT::MT1, MT2 = LT::MT2, S2 = LT::S2, S3 = LT::S3, ST = LT::ST;
+  constexpr int RA = MP / 2;                      // accumulator rows per lane that map to actions: a = unit_of(r, hi), r < RA
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
   const int n = A.n, m = A.m;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       int u = idx / H1, k = idx - u * H1;
       slot[L.oW2 + u * S2 + k] = th[fo.W2 + idx];
     }
-    for (int idx = tid; idx < m * H2; idx += 256) slot[L.oW3 + idx] = th[fo.W3 + idx];
+    for (int idx = tid; idx < m * H2; idx += 256) { int a = idx / H2, k = idx - a * H2; slot[L.oW3 + a * S3 + k] = th[fo.W3 + idx]; }
     for (int idx = tid; idx < H2; idx += 256) slot[L.oB2 + idx] = th[fo.b2 + idx];
     for (int idx = tid; idx < m; idx += 256) slot[L.oB3 + idx] = th[fo.b3 + idx];
   }
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 
   // ---------------- persistent accumulators ----------------
   f32x16 gW1[MT1][NT1], gW2[MT2][MT1], gW3[MT2];
-  float sb2 = 0.f, sb3 = 0.f, gls[MP];   // lane u < H2: grad b2[u]; lane a < m: grad b3[a]
+  float sb2[MT2], sb3 = 0.f, gls[RA];     // grad b2[32*nt + j] (every lane), grad b3[lane], grad log_std[unit_of(r,hi)]
 #pragma unroll
   for (int a = 0; a < MT1; ++a)
 #pragma unroll
@@ -197,24 +201,28 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     for (int b = 0; b < MT1; ++b) gW2[a][b] = (f32x16)(0.f);
   }
 #pragma unroll
-  for (int a = 0; a < MP; ++a) gls[a] = 0.f;
+  for (int a = 0; a < RA; ++a) gls[a] = 0.f;
+#pragma unroll
+  for (int a = 0; a < MT2; ++a) sb2[a] = 0.f;
   double s_surr = 0.0, s_kl = 0.0, s_cnt = 0.0;
 
   const int64_t ntiles = (A.N + 31) / 32;
   const int64_t tstride = (int64_t)gridDim.x * 4;
-  constexpr int XL = 16 * NT1;                   // obs loads per lane per tile (32*n/64 <= XL)
-  float xr[XL];
+  // One tile's observations are 32*n contiguous floats = 8*n aligned float4 (128*n bytes per tile, so
+  // every tile starts 16-byte aligned when obs is): each lane fetches up to XL4 float4, one tile ahead,
+  // straight into its final registers (no select on the loaded value, so the loads issue back to back).
+  constexpr int XL4 = 4 * NT1;
+  f32x4 xr[XL4];
   const float inv_n = 1.0f / (float)n;
 
   auto load_x = [&](int64_t tile) {
-    const int64_t base = tile * 32 * (int64_t)n;
-    const int64_t lim = A.N * (int64_t)n;
+    const float* base = A.obs + tile * 32 * (int64_t)n;
+    const int64_t rem4 = ((A.N - tile * 32) * (int64_t)n + 3) >> 2;      // float4 left in the batch (rounded up)
 #pragma unroll
-    for (int c = 0; c < XL; ++c) {
-      int e = c * 64 + lane;
-      bool ok = (e < 32 * n) && (base + e < lim);
-      float v = A.obs[ok ? base + e : 0];
-      xr[c] = ok ? v : 0.0f;
+    for (int c = 0; c < XL4; ++c) {
+      const int e4 = c * 64 + lane;
+      const bool ok = (e4 < 8 * n) && (e4 < rem4);
+      xr[c] = *(const f32x4*)(base + 4 * (ok ? e4 : 0));
     }
   };
 
@@ -224,59 +232,83 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   for (; tile < ntiles; tile += tstride) {
     const int64_t s0 = tile * 32;
     const bool valid = (s0 + j) < A.N;
-    // ---- 0. stage observations (raw) into xs [sample][feature] and xT [feature][sample]
+    // ---- 0. stage observations (raw) into xs [sample][feature]; rows past the batch end are zeroed so
+    // that their activations stay finite (their cotangents are masked to zero further down).
+    const int nvalid = (int)((A.N - s0 < 32) ? (A.N - s0) : 32);
 #pragma unroll
-    for (int c = 0; c < XL; ++c) {
-      int e = c * 64 + lane;
-      if (e < 32 * n) {
-        int sidx = (int)(((float)e + 0.5f) * inv_n);
-        int f = e - sidx * n;
-        xs[sidx * S1 + f] = xr[c];
+    for (int c = 0; c < XL4; ++c) {
+      const int e4 = c * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = 4 * e4 + k;
+        const int sidx = (int)(((float)e + 0.5f) * inv_n);
+        const int f = e - sidx * n;
+        const bool inb = e4 < 8 * n;
+        const float v = (sidx < nvalid) ? xr[c][k] : 0.0f;
+        xs[inb ? sidx * S1 + f : NP] = v;                     // out-of-range lanes hit an unused pad slot
       }
     }
     if (tile + tstride < ntiles) load_x(tile + tstride);
-    // per-sample action / advantage loads for this tile (used late; issue early)
-    float av[MP];
-    float advv = 0.f;
-    if (MODE != MODE_FVP) {
-#pragma unroll
-      for (int a = 0; a < MP; ++a) {
-        bool ok = valid && (a < m);
-        float v = A.act[ok ? (s0 + j) * m + a : 0];
-        av[a] = ok ? v : 0.f;
-      }
-      {
-        float v = A.adv[valid ? s0 + j : 0];
-        advv = valid ? v : 0.f;
-      }
-    }
     wave_sync();
 
-    // forward of one parameter set: fills h1 / h2 (activations, lane = sample)
-    auto forward = [&](const float* slot, const float* tsh, const float* tsc, bool writeT,
-                       f32x16 (&h1)[MT1], f32x16 (&h2)[MT2]) {
-      // normalise this lane-pair's features on the fly: x~ = (x - shift)/(scale + 1e-8)
+    // ---- layers 1 and 2 of one parameter set (and, for the FVP, the tangent pass riding on the
+    // same operand fetches).  Every MFMA loop prefetches the next LDS operand group before issuing
+    // the current group's MFMAs, so ds_read latency hides under the matrix pipe.
+    //   TAN == false: h1 = tanh(W1a x~), h2 = tanh(W2 h1 + b2)                      (slot)
+    //   TAN == true : additionally t1 = (V1a x~)(1-h1^2), t2 = (V2 h1 + W2 t1 + c2)(1-h2^2) (slotB)
+    auto layers12 = [&](auto tan_tag, const float* slot, const float* tsh, const float* tsc, bool writeT,
+                        f32x16 (&h1)[MT1], f32x16 (&h2)[MT2], f32x16 (&t1)[MT1], f32x16 (&t2)[MT2]) {
+      constexpr bool TAN = decltype(tan_tag)::value;
       f32x16 z1[MT1];
 #pragma unroll
-      for (int mt = 0; mt < MT1; ++mt) z1[mt] = (f32x16)(0.f);
-      for (int q = 0; q < NP / 4; ++q) {
-        int f0 = 4 * q + 2 * hi;
-        f32x2 xb = *(const f32x2*)&xs[j * S1 + f0];
-        // the ones column (f == n) and the zero pad must pass through unchanged
-        float x0 = (f0 < n) ? (xb.x - tsh[f0]) / (tsc[f0] + 1e-8f) : xb.x;
-        float x1 = (f0 + 1 < n) ? (xb.y - tsh[f0 + 1]) / (tsc[f0 + 1] + 1e-8f) : xb.y;
-        if (writeT) { xT[f0 * ST + j] = x0; xT[(f0 + 1) * ST + j] = x1; }
+      for (int mt = 0; mt < MT1; ++mt) { z1[mt] = (f32x16)(0.f); if (TAN) t1[mt] = (f32x16)(0.f); }
+      // layer 1: K = features (+ ones column carrying the bias), operands by ds_read_b64
+      {
+        f32x2 wc[MT1], vc[MT1], xb;
+        const int f00 = 2 * hi;
+        xb = *(const f32x2*)&xs[j * S1 + f00];
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt) {
-          f32x2 wa = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f0];
-          z1[mt] = MJX_MFMA(wa.x, x0, z1[mt]);
-          z1[mt] = MJX_MFMA(wa.y, x1, z1[mt]);
+          wc[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f00];
+          if (TAN) vc[mt] = *(const f32x2*)&slotB[L.oW1 + (32 * mt + j) * S1 + f00];
+        }
+        for (int q = 0; q < NP / 4; ++q) {
+          const int f0 = 4 * q + 2 * hi;
+          const int f1 = (q + 1 < NP / 4) ? f0 + 4 : f0;        // next group (clamped on the last trip)
+          f32x2 wn[MT1], vn[MT1], xn;
+          xn = *(const f32x2*)&xs[j * S1 + f1];
+#pragma unroll
+          for (int mt = 0; mt < MT1; ++mt) {
+            wn[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f1];
+            if (TAN) vn[mt] = *(const f32x2*)&slotB[L.oW1 + (32 * mt + j) * S1 + f1];
+          }
+          // x~ = (x - shift)/(scale + 1e-8); the ones column (f == n) and the zero pad pass through
+          float x0 = (f0 < n) ? (xb.x - tsh[f0]) / (tsc[f0] + 1e-8f) : xb.x;
+          float x1 = (f0 + 1 < n) ? (xb.y - tsh[f0 + 1]) / (tsc[f0 + 1] + 1e-8f) : xb.y;
+          if (writeT) { xT[f0 * ST + j] = x0; xT[(f0 + 1) * ST + j] = x1; }
+#pragma unroll
+          for (int mt = 0; mt < MT1; ++mt) {
+            z1[mt] = MJX_MFMA(wc[mt].x, x0, z1[mt]);
+            if (TAN) t1[mt] = MJX_MFMA(vc[mt].x, x0, t1[mt]);
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT1; ++mt) {
+            z1[mt] = MJX_MFMA(wc[mt].y, x1, z1[mt]);
+            if (TAN) t1[mt] = MJX_MFMA(vc[mt].y, x1, t1[mt]);
+          }
+          xb = xn;
+#pragma unroll
+          for (int mt = 0; mt < MT1; ++mt) { wc[mt] = wn[mt]; if (TAN) vc[mt] = vn[mt]; }
         }
       }
 #pragma unroll
       for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h1[mt][r] = fast_tanh(z1[mt][r]);
+        for (int r = 0; r < 16; ++r) {
+          h1[mt][r] = fast_tanh(z1[mt][r]);
+          if (TAN) t1[mt][r] *= fmaf(-h1[mt][r], h1[mt][r], 1.0f);
+        }
+      // layer 2: accumulators start at the bias (b2 / c2), K = h1 units chained from registers
       f32x16 z2[MT2];
 #pragma unroll
       for (int mt = 0; mt < MT2; ++mt)
@@ -284,104 +316,102 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         for (int q = 0; q < 4; ++q) {
           f32x4 b = *(const f32x4*)&slot[L.oB2 + 32 * mt + 8 * q + 4 * hi];
           z2[mt][4 * q + 0] = b.x; z2[mt][4 * q + 1] = b.y; z2[mt][4 * q + 2] = b.z; z2[mt][4 * q + 3] = b.w;
-        }
-#pragma unroll
-      for (int kb = 0; kb < MT1; ++kb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int mt = 0; mt < MT2; ++mt) {
-            f32x4 wa = *(const f32x4*)&slot[L.oW2 + (32 * mt + j) * S2 + 32 * kb + 8 * q + 4 * hi];
-            z2[mt] = MJX_MFMA(wa.x, h1[kb][4 * q + 0], z2[mt]);
-            z2[mt] = MJX_MFMA(wa.y, h1[kb][4 * q + 1], z2[mt]);
-            z2[mt] = MJX_MFMA(wa.z, h1[kb][4 * q + 2], z2[mt]);
-            z2[mt] = MJX_MFMA(wa.w, h1[kb][4 * q + 3], z2[mt]);
+          if (TAN) {
+            f32x4 c = *(const f32x4*)&slotB[L.oB2 + 32 * mt + 8 * q + 4 * hi];
+            t2[mt][4 * q + 0] = c.x; t2[mt][4 * q + 1] = c.y; t2[mt][4 * q + 2] = c.z; t2[mt][4 * q + 3] = c.w;
           }
+        }
+      constexpr int NS = MT1 * 4;                               // (kb, q) operand groups
+      {
+        // pass A: z2 += W2 h1   and (TAN)  t2 += W2 t1   -- one W2 fragment feeds both
+        f32x4 wc[MT2], wn[MT2];
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) wc[mt] = *(const f32x4*)&slot[L.oW2 + (32 * mt + j) * S2 + 4 * hi];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          const int kb = st >> 2, q = st & 3;
+          if (st + 1 < NS) {
+            const int kb1 = (st + 1) >> 2, q1 = (st + 1) & 3;
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) wn[mt] = *(const f32x4*)&slot[L.oW2 + (32 * mt + j) * S2 + 32 * kb1 + 8 * q1 + 4 * hi];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+              z2[mt] = MJX_MFMA(wc[mt][t], h1[kb][4 * q + t], z2[mt]);
+              if (TAN) t2[mt] = MJX_MFMA(wc[mt][t], t1[kb][4 * q + t], t2[mt]);
+            }
+#pragma unroll
+          for (int mt = 0; mt < MT2; ++mt) wc[mt] = wn[mt];
+        }
+      }
+      if (TAN) {
+        // pass B: t2 += V2 h1 ; independent of z2, so tanh(z2) below can issue in its shadow
+        f32x4 vc[MT2], vn[MT2];
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) vc[mt] = *(const f32x4*)&slotB[L.oW2 + (32 * mt + j) * S2 + 4 * hi];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          const int kb = st >> 2, q = st & 3;
+          if (st + 1 < NS) {
+            const int kb1 = (st + 1) >> 2, q1 = (st + 1) & 3;
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) vn[mt] = *(const f32x4*)&slotB[L.oW2 + (32 * mt + j) * S2 + 32 * kb1 + 8 * q1 + 4 * hi];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) t2[mt] = MJX_MFMA(vc[mt][t], h1[kb][4 * q + t], t2[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MT2; ++mt) vc[mt] = vn[mt];
+        }
+      }
 #pragma unroll
       for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h2[mt][r] = fast_tanh(z2[mt][r]);
+      if (TAN) {
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t2[mt][r] *= fmaf(-h2[mt][r], h2[mt][r], 1.0f);
+      }
     };
 
-    // output layer on the VALU: out[a] = sum_k W3[a][k] * v[k]  (cross-half reduced)
-    auto out_layer = [&](const float* slot, const f32x16 (&v)[MT2], float (&o)[MP]) {
+    // output layer on the matrix pipe: acc[r] (r < RA) = bias[a] + sum_k W[a][k] v[k], a = unit_of(r, hi);
+    // rows >= MP of the 32-row tile are fed zeros.  v = accumulators of the previous layer (chained).
+    auto out_mfma = [&](f32x16& acc, const float* slot, const f32x16 (&v)[MT2]) {
+      const float* arow = &slot[L.oW3 + (j < MP ? j : 0) * S3 + 4 * hi];
+      f32x4 wc = *(const f32x4*)arow, wn;
+      constexpr int NS = MT2 * 4;
 #pragma unroll
-      for (int a = 0; a < MP; ++a) {
-        float acc = 0.f;
-        {
+      for (int st = 0; st < NS; ++st) {
+        const int kb = st >> 2, q = st & 3;
+        if (st + 1 < NS) wn = *(const f32x4*)(arow + 32 * ((st + 1) >> 2) + 8 * ((st + 1) & 3));
+        f32x4 a4 = (j < MP) ? wc : (f32x4)(0.f);
 #pragma unroll
-          for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              f32x4 w = *(const f32x4*)&slot[L.oW3 + a * H2 + 32 * mt + 8 * q + 4 * hi];
-              acc = fmaf(w.x, v[mt][4 * q + 0], acc);
-              acc = fmaf(w.y, v[mt][4 * q + 1], acc);
-              acc = fmaf(w.z, v[mt][4 * q + 2], acc);
-              acc = fmaf(w.w, v[mt][4 * q + 3], acc);
-            }
-        }
-        o[a] = acc;
+        for (int t = 0; t < 4; ++t) acc = MJX_MFMA(a4[t], v[kb][4 * q + t], acc);
+        wc = wn;
       }
+    };
+    auto bias_rows = [&](const float* slot) {
+      f32x16 acc = (f32x16)(0.f);
 #pragma unroll
-      for (int a = 0; a < MP; ++a) o[a] += __shfl_xor(o[a], 32);
+      for (int r = 0; r < RA; ++r) acc[r] = slot[L.oB3 + unit_of(r, hi)];
+      return acc;
     };
 
     f32x16 h1[MT1], h2[MT2];
-    forward(slotA, trs, trs + NP, MODE != MODE_EVAL, h1, h2);
+    f32x16 t1[MT1], t2[MT2];                        // tangent activations (FVP only)
+    if (MODE == MODE_FVP) layers12(std::true_type{}, slotA, trs, trs + NP, true, h1, h2, t1, t2);
+    else layers12(std::false_type{}, slotA, trs, trs + NP, MODE != MODE_EVAL, h1, h2, t1, t2);
 
-    float d3[MP];                                 // delta on the (pre-scale) output layer
+    float d3r[RA];                                  // cotangent on the pre-scale output, rows a = unit_of(r, hi)
     if (MODE == MODE_FVP) {
-      // ---- tangent pass: t1 = (V1 x~ + c1)(1-h1^2); t2 = (V2 h1 + W2 t1 + c2)(1-h2^2)
-      wave_sync();                                // xT written above, read below
-      f32x16 t1[MT1], t2[MT2];
-#pragma unroll
-      for (int mt = 0; mt < MT1; ++mt) t1[mt] = (f32x16)(0.f);
-      for (int q = 0; q < NP / 4; ++q) {
-        int f0 = 4 * q + 2 * hi;
-        float x0 = xT[f0 * ST + j], x1 = xT[(f0 + 1) * ST + j];
-#pragma unroll
-        for (int mt = 0; mt < MT1; ++mt) {
-          f32x2 wa = *(const f32x2*)&slotB[L.oW1 + (32 * mt + j) * S1 + f0];
-          t1[mt] = MJX_MFMA(wa.x, x0, t1[mt]);
-          t1[mt] = MJX_MFMA(wa.y, x1, t1[mt]);
-        }
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT1; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t1[mt][r] *= fmaf(-h1[mt][r], h1[mt][r], 1.0f);
-#pragma unroll
-      for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 b = *(const f32x4*)&slotB[L.oB2 + 32 * mt + 8 * q + 4 * hi];
-          t2[mt][4 * q + 0] = b.x; t2[mt][4 * q + 1] = b.y; t2[mt][4 * q + 2] = b.z; t2[mt][4 * q + 3] = b.w;
-        }
-#pragma unroll
-      for (int kb = 0; kb < MT1; ++kb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int mt = 0; mt < MT2; ++mt) {
-            const int off = (32 * mt + j) * S2 + 32 * kb + 8 * q + 4 * hi;
-            f32x4 va = *(const f32x4*)&slotB[L.oW2 + off];
-            f32x4 wa = *(const f32x4*)&slotA[L.oW2 + off];
-            t2[mt] = MJX_MFMA(va.x, h1[kb][4 * q + 0], t2[mt]);
-            t2[mt] = MJX_MFMA(wa.x, t1[kb][4 * q + 0], t2[mt]);
-            t2[mt] = MJX_MFMA(va.y, h1[kb][4 * q + 1], t2[mt]);
-            t2[mt] = MJX_MFMA(wa.y, t1[kb][4 * q + 1], t2[mt]);
-            t2[mt] = MJX_MFMA(va.z, h1[kb][4 * q + 2], t2[mt]);
-            t2[mt] = MJX_MFMA(wa.z, t1[kb][4 * q + 2], t2[mt]);
-            t2[mt] = MJX_MFMA(va.w, h1[kb][4 * q + 3], t2[mt]);
-            t2[mt] = MJX_MFMA(wa.w, t1[kb][4 * q + 3], t2[mt]);
-          }
-#pragma unroll
-      for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t2[mt][r] *= fmaf(-h2[mt][r], h2[mt][r], 1.0f);
-      float o1[MP], o2[MP];
-      out_layer(slotB, h2, o1);                   // V3 h2
-      out_layer(slotA, t2, o2);                   // W3 t2
+      f32x16 md = bias_rows(slotB);                 // c3
+      out_mfma(md, slotB, h2);                      // + V3 h2
+      out_mfma(md, slotA, t2);                      // + W3 t2
       if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0) {
         float* g = A.dbg;
 #pragma unroll
@@ -400,49 +430,60 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
           }
       }
 #pragma unroll
-      for (int a = 0; a < MP; ++a) {
-        float c3 = slotB[L.oB3 + a];
-        float mudot = cst[C_OSC * MP + a] * (o1[a] + o2[a] + c3);
-        float u = cst[C_SG * MP + a] * cst[C_SG * MP + a];
-        float Dk = 2.0f / (2.0f * u + 1e-8f);
+      for (int r = 0; r < RA; ++r) {
+        const int a = unit_of(r, hi);
+        float osc = cst[C_OSC * MP + a], sg = cst[C_SG * MP + a];
+        float mudot = osc * md[r];
+        float Dk = 2.0f / (2.0f * sg * sg + 1e-8f);
         float dmu = valid ? Dk * mudot * A.inv_N : 0.f;
-        d3[a] = cst[C_OSC * MP + a] * dmu;
-        if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0 && hi == 0) A.dbg[2048 * 4 + a * 32 + j] = mudot;
+        d3r[r] = osc * dmu;
+        if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0) A.dbg[2048 * 4 + a * 32 + j] = mudot;
       }
     } else {
-      // ---- likelihoods (mean_LL, gaussian_mlp.py:99-115)
-      float o[MP], mu[MP];
-      out_layer(slotA, h2, o);
-      float llA = 0.f, sumls = 0.f;
-      float z[MP];
+      // ---- likelihoods (mean_LL, gaussian_mlp.py:99-115); each lane owns the actions a = unit_of(r, hi)
+      float sum_lsA = 0.f, sum_lsB = 0.f;
 #pragma unroll
-      for (int a = 0; a < MP; ++a) {
-        float b3 = slotA[L.oB3 + a];
-        mu[a] = (o[a] + b3) * cst[C_OSC * MP + a] + cst[C_OSH * MP + a];
-        z[a] = (av[a] - mu[a]) / cst[C_SG * MP + a];
-        llA = fmaf(-0.5f * z[a], z[a], llA);
-        sumls += cst[C_LS * MP + a];
+      for (int a = 0; a < MP; ++a) { sum_lsA += cst[C_LS * MP + a]; sum_lsB += cst[C_LSB * MP + a]; }
+      const float llc = 0.5f * (float)m * 1.8378770664093453f;
+      f32x16 mu = bias_rows(slotA);
+      out_mfma(mu, slotA, h2);
+      float av[RA], z[RA], muv[RA];
+      float llA = 0.f;
+#pragma unroll
+      for (int r = 0; r < RA; ++r) {
+        const int a = unit_of(r, hi);
+        const bool ok = valid && (a < m);
+        float x = A.act[ok ? (s0 + j) * m + a : 0];
+        av[r] = ok ? x : 0.f;
+        muv[r] = mu[r] * cst[C_OSC * MP + a] + cst[C_OSH * MP + a];
+        z[r] = (av[r] - muv[r]) / cst[C_SG * MP + a];
+        llA = fmaf(-0.5f * z[r], z[r], llA);
       }
-      llA = llA - sumls - 0.5f * (float)m * 1.8378770664093453f;
-      float llB = llA, muB[MP];
+      llA += __shfl_xor(llA, 32);
+      llA = llA - sum_lsA - llc;
+      float llB = llA, muB[RA];
 #pragma unroll
-      for (int a = 0; a < MP; ++a) muB[a] = mu[a];
+      for (int r = 0; r < RA; ++r) muB[r] = muv[r];
       if (MODE == MODE_EVAL || !A.old_is_new) {
         f32x16 g1[MT1], g2[MT2];
-        forward(slotB, trs + 2 * NP, trs + 3 * NP, false, g1, g2);
-        float ob[MP];
-        out_layer(slotB, g2, ob);
+        layers12(std::false_type{}, slotB, trs + 2 * NP, trs + 3 * NP, false, g1, g2, t1, t2);
+        f32x16 mo = bias_rows(slotB);
+        out_mfma(mo, slotB, g2);
         llB = 0.f;
-        float sumlsB = 0.f;
 #pragma unroll
-        for (int a = 0; a < MP; ++a) {
-          float b3 = slotB[L.oB3 + a];
-          muB[a] = (ob[a] + b3) * cst[C_OSCB * MP + a] + cst[C_OSHB * MP + a];
-          float zb = (av[a] - muB[a]) / cst[C_SGB * MP + a];
+        for (int r = 0; r < RA; ++r) {
+          const int a = unit_of(r, hi);
+          muB[r] = mo[r] * cst[C_OSCB * MP + a] + cst[C_OSHB * MP + a];
+          float zb = (av[r] - muB[r]) / cst[C_SGB * MP + a];
           llB = fmaf(-0.5f * zb, zb, llB);
-          sumlsB += cst[C_LSB * MP + a];
         }
-        llB = llB - sumlsB - 0.5f * (float)m * 1.8378770664093453f;
+        llB += __shfl_xor(llB, 32);
+        llB = llB - sum_lsB - llc;
+      }
+      float advv;
+      {
+        float v = A.adv[valid ? s0 + j : 0];
+        advv = valid ? v : 0.f;
       }
       float LR = expf(llA - llB);
       if (valid && hi == 0) { s_surr += (double)(LR * advv); s_cnt += 1.0; }
@@ -450,38 +491,41 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         // mean_kl(new, old), gaussian_mlp.py:135-145
         float kl = 0.f;
 #pragma unroll
-        for (int a = 0; a < MP; ++a) {
-            float so = cst[C_SGB * MP + a], sn = cst[C_SG * MP + a];
-            float Nr = (muB[a] - mu[a]) * (muB[a] - mu[a]) + so * so - sn * sn;
-            float Dr = 2.0f * sn * sn + 1e-8f;
-            kl += Nr / Dr + cst[C_LS * MP + a] - cst[C_LSB * MP + a];
-          }
+        for (int r = 0; r < RA; ++r) {
+          const int a = unit_of(r, hi);
+          float so = cst[C_SGB * MP + a], sn = cst[C_SG * MP + a];
+          float Nr = (muB[r] - muv[r]) * (muB[r] - muv[r]) + so * so - sn * sn;
+          float Dr = 2.0f * sn * sn + 1e-8f;
+          kl += Nr / Dr + cst[C_LS * MP + a] - cst[C_LSB * MP + a];
+        }
+        kl += __shfl_xor(kl, 32);
         if (valid && hi == 0) s_kl += (double)kl;
       } else {
         float w = valid ? advv * LR * A.inv_N : 0.f;
 #pragma unroll
-        for (int a = 0; a < MP; ++a) {
-          float dmu = w * z[a] / cst[C_SG * MP + a];
-          d3[a] = cst[C_OSC * MP + a] * dmu;
-          if (hi == 0) gls[a] += w * (z[a] * z[a] - 1.0f);
+        for (int r = 0; r < RA; ++r) {
+          const int a = unit_of(r, hi);
+          float sg = cst[C_SG * MP + a];
+          d3r[r] = cst[C_OSC * MP + a] * (w * z[r] / sg);
+          gls[r] += w * (z[r] * z[r] - 1.0f);
         }
-        if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0 && hi == 0) {
+        if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0) {
 #pragma unroll
-          for (int a = 0; a < MP; ++a) A.dbg[2048 * 4 + a * 32 + j] = mu[a];
-          A.dbg[2048 * 4 + MP * 32 + j] = llA;
+          for (int r = 0; r < RA; ++r) A.dbg[2048 * 4 + unit_of(r, hi) * 32 + j] = muv[r];
+          if (hi == 0) A.dbg[2048 * 4 + MP * 32 + j] = llA;
         }
       }
     }
 
     if (MODE != MODE_EVAL) {
       // ================= backward (shared by VPG and FVP) =================
-      // d3[a]: cotangent on the pre-scale output, lane = sample (both halves hold it).
-      // Park h2^T in bufA and h1^T in bufB ([unit][sample]); the register copies die here and
-      // the (1 - h^2) factors are read back from LDS in accumulator layout.
-      if (hi == 0) {
+      // Park h2^T in bufA, h1^T in bufB ([unit][sample]) and d3^T in d3T ([action][sample]).  The deltas
+      // are produced directly in the layout each consumer wants (swapping the MFMA operand roles
+      // transposes the product), so they never pass through LDS:
+      //   delta2s / (lane = sample)  feeds the next back-propagation step as a chained operand,
+      //   delta2u, delta1u (lane = unit) feed the weight-gradient products as A operands.
 #pragma unroll
-        for (int a = 0; a < MP; ++a) d3T[a * ST + j] = d3[a];
-      }
+      for (int r = 0; r < RA; ++r) d3T[unit_of(r, hi) * ST + j] = d3r[r];
 #pragma unroll
       for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
@@ -490,134 +534,155 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) bufB[(32 * mt + unit_of(r, hi)) * ST + j] = h1[mt][r];
-      wave_sync();
-      // gW3[a][k] += sum_s d3[s][a] * h2[s][k]
+      // delta2 in both layouts: K = actions, the W3 column fragment serves as A (-> lane = sample) and as B (-> lane = unit)
+      f32x16 dl2s[MT2], dl2u[MT2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 a4 = *(const f32x4*)&d3T[(j < MP ? j : 0) * ST + 8 * q + 4 * hi];
-        if (j >= MP) a4 = (f32x4)(0.f);
+      for (int mt = 0; mt < MT2; ++mt) { dl2s[mt] = (f32x16)(0.f); dl2u[mt] = (f32x16)(0.f); }
 #pragma unroll
-        for (int nt = 0; nt < MT2; ++nt) {
-          f32x4 b4 = *(const f32x4*)&bufA[(32 * nt + j) * ST + 8 * q + 4 * hi];
-          gW3[nt] = MJX_MFMA(a4.x, b4.x, gW3[nt]);
-          gW3[nt] = MJX_MFMA(a4.y, b4.y, gW3[nt]);
-          gW3[nt] = MJX_MFMA(a4.z, b4.z, gW3[nt]);
-          gW3[nt] = MJX_MFMA(a4.w, b4.w, gW3[nt]);
+      for (int sidx = 0; sidx < RA; ++sidx) {
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) {
+          float w = slotA[L.oW3 + unit_of(sidx, hi) * S3 + 32 * mt + j];
+          dl2s[mt] = MJX_MFMA(w, d3r[sidx], dl2s[mt]);
+          dl2u[mt] = MJX_MFMA(d3r[sidx], w, dl2u[mt]);
         }
       }
-      if (lane < MP) {                            // grad b3[a] = sum_s d3[s][a]
+#pragma unroll
+      for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dl2s[mt][r] *= fmaf(-h2[mt][r], h2[mt][r], 1.0f);
+      wave_sync();
+      // gW3[a][k] += sum_s d3[s][a] * h2[s][k]      (operands prefetched one group ahead)
+      {
+        const float* arow = &d3T[(j < MP ? j : 0) * ST + 4 * hi];
+        f32x4 ac = *(const f32x4*)arow, an, bc[MT2], bn[MT2];
+#pragma unroll
+        for (int nt = 0; nt < MT2; ++nt) bc[nt] = *(const f32x4*)&bufA[(32 * nt + j) * ST + 4 * hi];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q + 1 < 4) {
+            an = *(const f32x4*)(arow + 8 * (q + 1));
+#pragma unroll
+            for (int nt = 0; nt < MT2; ++nt) bn[nt] = *(const f32x4*)&bufA[(32 * nt + j) * ST + 8 * (q + 1) + 4 * hi];
+          }
+          f32x4 a4 = (j < MP) ? ac : (f32x4)(0.f);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < MT2; ++nt) gW3[nt] = MJX_MFMA(a4[t], bc[nt][t], gW3[nt]);
+          // delta2u *= (1 - h2^2): bc[nt][t] is h2[sample unit_of(4q+t, hi)][unit 32nt + j], the matching element
+#pragma unroll
+          for (int nt = 0; nt < MT2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dl2u[nt][4 * q + t] *= fmaf(-bc[nt][t], bc[nt][t], 1.0f);
+          ac = an;
+#pragma unroll
+          for (int nt = 0; nt < MT2; ++nt) bc[nt] = bn[nt];
+        }
+      }
+      if (lane < MP) {                              // grad b3[a] = sum_s d3[s][a]
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           f32x4 v = *(const f32x4*)&d3T[lane * ST + 4 * q];
           sb3 += (v.x + v.y) + (v.z + v.w);
         }
       }
-      // delta2 = (W3^T d3) (1 - h2^2)
-      f32x16 dl2[MT2];
+      // grad b2[32nt + j] = sum over this tile's samples (16 registers x 2 lane halves)
 #pragma unroll
-      for (int mt = 0; mt < MT2; ++mt) dl2[mt] = (f32x16)(0.f);
+      for (int nt = 0; nt < MT2; ++nt) {
+        float sacc = 0.f;
 #pragma unroll
-      for (int s = 0; s < MP / 2; ++s) {
-        {
-          float b = hi ? d3[2 * s + 1] : d3[2 * s];
-#pragma unroll
-          for (int mt = 0; mt < MT2; ++mt) {
-            float a = slotA[L.oW3 + (2 * s + hi) * H2 + 32 * mt + j];
-            dl2[mt] = MJX_MFMA(a, b, dl2[mt]);
-          }
-        }
+        for (int r = 0; r < 16; ++r) sacc += dl2u[nt][r];
+        sb2[nt] += sacc + __shfl_xor(sacc, 32);
       }
+      // gW2[u2][u1] += sum_s delta2[s][u2] * h1[s][u1]; delta1u = (delta2 W2)(1 - h1^2), lane = h1 unit.
+      // Both walk h1^T (bufB) group by group, so the (1 - h1^2) factors ride on the gW2 operand fetches.
+      f32x16 dl1u[MT1];
 #pragma unroll
-      for (int mt = 0; mt < MT2; ++mt)
+      for (int nt = 0; nt < MT1; ++nt) dl1u[nt] = (f32x16)(0.f);
+      {
+        constexpr int NG = MT2 * 4;                 // groups of 4 k-steps over the h2 units
+        float wc[4][MT1], wn[4][MT1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float y = bufA[(32 * mt + unit_of(r, hi)) * ST + j];
-          dl2[mt][r] *= fmaf(-y, y, 1.0f);
-        }
-      wave_sync();                                // all reads of h2^T done: bufA is free
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int mt = 0; mt < MT2; ++mt)
+          for (int nt = 0; nt < MT1; ++nt) wc[t][nt] = slotA[L.oW2 + (4 * hi + t) * S2 + 32 * nt + j];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bufA[(32 * mt + unit_of(r, hi)) * ST + j] = dl2[mt][r];
-      wave_sync();
-      if (lane < H2) {                            // grad b2[u] = sum_s delta2[s][u]
+        for (int g = 0; g < NG; ++g) {
+          const int kb = g >> 2, q = g & 3;
+          if (g + 1 < NG) {
+            const int kb1 = (g + 1) >> 2, q1 = (g + 1) & 3;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          f32x4 v = *(const f32x4*)&bufA[lane * ST + 4 * q];
-          sb2 += (v.x + v.y) + (v.z + v.w);
-        }
-      }
-      // gW2[u2][u1] += sum_s delta2[s][u2] * h1[s][u1]      (A = delta2^T in bufA, B = h1^T in bufB)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 b4[MT1];
-#pragma unroll
-        for (int nt = 0; nt < MT1; ++nt) b4[nt] = *(const f32x4*)&bufB[(32 * nt + j) * ST + 8 * q + 4 * hi];
-#pragma unroll
-        for (int mt = 0; mt < MT2; ++mt) {
-          f32x4 a4 = *(const f32x4*)&bufA[(32 * mt + j) * ST + 8 * q + 4 * hi];
-#pragma unroll
-          for (int nt = 0; nt < MT1; ++nt) {
-            gW2[mt][nt] = MJX_MFMA(a4.x, b4[nt].x, gW2[mt][nt]);
-            gW2[mt][nt] = MJX_MFMA(a4.y, b4[nt].y, gW2[mt][nt]);
-            gW2[mt][nt] = MJX_MFMA(a4.z, b4[nt].z, gW2[mt][nt]);
-            gW2[mt][nt] = MJX_MFMA(a4.w, b4[nt].w, gW2[mt][nt]);
-          }
-        }
-      }
-      // delta1 = (W2^T delta2) (1 - h1^2)   (A operand = W2 read column-wise, B = delta2 accumulators)
-      f32x16 dl1[MT1];
-#pragma unroll
-      for (int mt = 0; mt < MT1; ++mt) dl1[mt] = (f32x16)(0.f);
-#pragma unroll
-      for (int kb = 0; kb < MT2; ++kb)
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-          for (int mt = 0; mt < MT1; ++mt) {
-            float a = slotA[L.oW2 + (32 * kb + unit_of(s, hi)) * S2 + 32 * mt + j];
-            dl1[mt] = MJX_MFMA(a, dl2[kb][s], dl1[mt]);
+              for (int nt = 0; nt < MT1; ++nt) wn[t][nt] = slotA[L.oW2 + (32 * kb1 + 8 * q1 + 4 * hi + t) * S2 + 32 * nt + j];
           }
 #pragma unroll
-      for (int mt = 0; mt < MT1; ++mt)
+          for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float y = bufB[(32 * mt + unit_of(r, hi)) * ST + j];
-          dl1[mt][r] *= fmaf(-y, y, 1.0f);
+            for (int nt = 0; nt < MT1; ++nt) dl1u[nt] = MJX_MFMA(dl2s[kb][4 * q + t], wc[t][nt], dl1u[nt]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < MT1; ++nt) wc[t][nt] = wn[t][nt];
         }
+      }
+      {
+        f32x4 bc[MT1], bn[MT1];
+#pragma unroll
+        for (int nt = 0; nt < MT1; ++nt) bc[nt] = *(const f32x4*)&bufB[(32 * nt + j) * ST + 4 * hi];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q + 1 < 4) {
+#pragma unroll
+            for (int nt = 0; nt < MT1; ++nt) bn[nt] = *(const f32x4*)&bufB[(32 * nt + j) * ST + 8 * (q + 1) + 4 * hi];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < MT1; ++nt) gW2[mt][nt] = MJX_MFMA(dl2u[mt][4 * q + t], bc[nt][t], gW2[mt][nt]);
+#pragma unroll
+          for (int nt = 0; nt < MT1; ++nt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dl1u[nt][4 * q + t] *= fmaf(-bc[nt][t], bc[nt][t], 1.0f);
+#pragma unroll
+          for (int nt = 0; nt < MT1; ++nt) bc[nt] = bn[nt];
+        }
+      }
       if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0) {
         float* g = A.dbg + 2048 * 5;
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) g[(32 * mt + unit_of(r, hi)) * 32 + j] = dl2[mt][r];
+          for (int r = 0; r < 16; ++r) g[(32 * mt + unit_of(r, hi)) * 32 + j] = dl2s[mt][r];
 #pragma unroll
-        for (int mt = 0; mt < MT1; ++mt)
+        for (int nt = 0; nt < MT1; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) g[2048 + (32 * mt + unit_of(r, hi)) * 32 + j] = dl1[mt][r];
+          for (int r = 0; r < 16; ++r) g[2048 + (32 * nt + j) * 32 + unit_of(r, hi)] = dl1u[nt][r];
       }
-      wave_sync();                                // gW2 reads of bufA / (1-h1^2) reads of bufB done
+      // gW1a[u1][f] += sum_s delta1[s][u1] * x~a[s][f]   (column n = bias gradient); A from registers
+      {
+        f32x4 bc[NT1], bn[NT1];
 #pragma unroll
-      for (int mt = 0; mt < MT1; ++mt)
+        for (int nt = 0; nt < NT1; ++nt) { int f = 32 * nt + j; bc[nt] = *(const f32x4*)&xT[(f < NP ? f : 0) * ST + 4 * hi]; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bufA[(32 * mt + unit_of(r, hi)) * ST + j] = dl1[mt][r];
-      wave_sync();
-      // gW1a[u1][f] += sum_s delta1[s][u1] * x~a[s][f]   (column n = bias gradient)
+        for (int q = 0; q < 4; ++q) {
+          if (q + 1 < 4) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) {
-          int f = 32 * nt + j;
-          f32x4 b4 = *(const f32x4*)&xT[(f < NP ? f : 0) * ST + 8 * q + 4 * hi];
-          if (f >= NP) b4 = (f32x4)(0.f);
-#pragma unroll
-          for (int mt = 0; mt < MT1; ++mt) {
-            f32x4 a4 = *(const f32x4*)&bufA[(32 * mt + j) * ST + 8 * q + 4 * hi];
-            gW1[mt][nt] = MJX_MFMA(a4.x, b4.x, gW1[mt][nt]);
-            gW1[mt][nt] = MJX_MFMA(a4.y, b4.y, gW1[mt][nt]);
-            gW1[mt][nt] = MJX_MFMA(a4.z, b4.z, gW1[mt][nt]);
-            gW1[mt][nt] = MJX_MFMA(a4.w, b4.w, gW1[mt][nt]);
+            for (int nt = 0; nt < NT1; ++nt) { int f = 32 * nt + j; bn[nt] = *(const f32x4*)&xT[(f < NP ? f : 0) * ST + 8 * (q + 1) + 4 * hi]; }
           }
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt) {
+            f32x4 b4 = (32 * nt + j < NP) ? bc[nt] : (f32x4)(0.f);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int mt = 0; mt < MT1; ++mt) gW1[mt][nt] = MJX_MFMA(dl1u[mt][4 * q + t], b4[t], gW1[mt][nt]);
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt) bc[nt] = bn[nt];
         }
       }
     }
@@ -627,12 +692,12 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   // ---------------- workgroup reduction + partial write ----------------
   __syncthreads();
   if (MODE != MODE_EVAL) {
-    // log_std gradient: reduce over the 32 samples (lanes j) of the hi == 0 half
+    // log_std gradient: reduce over the 32 samples (lanes j) within each half (the halves own different actions)
     if (MODE == MODE_VPG) {
 #pragma unroll
       for (int off = 1; off < 32; off <<= 1)
 #pragma unroll
-        for (int a = 0; a < MP; ++a) gls[a] += __shfl_xor(gls[a], off);
+        for (int a = 0; a < RA; ++a) gls[a] += __shfl_xor(gls[a], off);
     }
     // each wave drops its partial gradient into its own LDS region [wave][d], then the
     // workgroup sums the four copies.  (weights in LDS are dead by now)
@@ -664,12 +729,17 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         int a = unit_of(r, hi);
         if (a < m) mine[fo.W3 + a * H2 + 32 * nt + j] = gW3[nt][r];
       }
-    if (lane < H2) mine[fo.b2 + lane] = sb2;
-    if (lane < m) mine[fo.b3 + lane] = sb3;
-    if (lane == 0) {
+    if (hi == 0) {
 #pragma unroll
-      for (int a = 0; a < MP; ++a)
-        if (a < m) mine[fo.S + a] = (MODE == MODE_VPG) ? gls[a] : 0.f;
+      for (int nt = 0; nt < MT2; ++nt) mine[fo.b2 + 32 * nt + j] = sb2[nt];
+    }
+    if (lane < m) mine[fo.b3 + lane] = sb3;
+    if (j == 0) {
+#pragma unroll
+      for (int r = 0; r < RA; ++r) {
+        const int a = unit_of(r, hi);
+        if (a < m) mine[fo.S + a] = (MODE == MODE_VPG) ? gls[r] : 0.f;
+      }
     }
     __syncthreads();
     float* outp = A.partials + (size_t)blockIdx.x * fo.d;

@@ -216,6 +216,7 @@ int mjx_stream_sync(void* stream) { HIPCHK(hipStreamSynchronize((hipStream_t)str
 
 int mjx_bind_batch(mjx_ctx* c, const float* obs, const float* act, const float* adv, int64_t N_local, int64_t N_global) {
   if (!c || (!obs && N_local > 0) || N_local < 0 || N_global < N_local || N_global <= 0) return fail(MJX_ERR_ARG, "bad batch");
+  if (((uintptr_t)obs & 15) != 0) return fail(MJX_ERR_ARG, "obs must be 16-byte aligned");
   c->obs = obs; c->act = act; c->adv = adv; c->N_local = N_local; c->N_global = N_global;
   c->lw.invalidate();
   if (!c->fused) { int rc = c->lw.reserve(N_local); if (rc) return fail(rc, "layer-wise workspace allocation failed"); }
