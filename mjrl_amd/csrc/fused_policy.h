@@ -383,8 +383,9 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     // rows >= MP of the 32-row tile are fed zeros.  v = accumulators of the previous layer (chained).
     auto out_mfma = [&](f32x16& acc, const float* slot, const f32x16 (&v)[MT2]) {
       const float* arow = &slot[L.oW3 + (j < MP ? j : 0) * S3 + 4 * hi];
-      f32x4 wc = *(const f32x4*)arow, wn;
       constexpr int NS = MT2 * 4;
+      __builtin_amdgcn_sched_barrier(0);            // own region: [read of group g+1][4 chained MFMAs of group g]
+      f32x4 wc = *(const f32x4*)arow, wn;
 #pragma unroll
       for (int st = 0; st < NS; ++st) {
         const int kb = st >> 2, q = st & 3;
@@ -394,6 +395,14 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         for (int t = 0; t < 4; ++t) acc = MJX_MFMA(a4[t], v[kb][4 * q + t], acc);
         wc = wn;
       }
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // the four selects that zero rows >= MP
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     };
     auto bias_rows = [&](const float* slot) {
       f32x16 acc = (f32x16)(0.f);
@@ -603,6 +612,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       {
         constexpr int NG = MT2 * 4;                 // groups of 4 k-steps over the h2 units
         float wc[4][MT1], wn[4][MT1];
+        __builtin_amdgcn_sched_barrier(0);          // own scheduling region: pin "next group's reads, then this group's MFMAs"
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -626,6 +636,14 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
             for (int nt = 0; nt < MT1; ++nt) wc[t][nt] = wn[t][nt];
         }
+        // pipeline: prologue reads, then per group [reads of g+1][MFMAs of g]
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * MT1, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 4 * MT1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       {
         f32x4 bc[MT1], bn[MT1];
