@@ -145,6 +145,36 @@ int mjx_whiten_cast(const double* adv, int64_t N, double mean, double std, doubl
                     float* out32, void* stream);
 int mjx_cast_f64_f32(const double* x, int64_t count, float* out32, void* stream);
 
+/* ---- K6: value baselines --------------------------------------------------- */
+/* Feature maps of the reference baselines over the concatenated fp64 observation block
+ * (N x n) with tpos[s] = time index of sample s inside its trajectory:
+ *   kind 0  MLP       clip(obs,-10,10)/10, tau^1..4                 F = n + 4   (mlp_baseline.py:36-58)
+ *   kind 1  LINEAR    clip/10, 1, tau^1..4                          F = n + 5   (linear_baseline.py:11-35)
+ *   kind 2  QUADRATIC clip/10, o_i*o_j (i<=j), 1, tau^1..4          F = n + n(n+1)/2 + 5 (quadratic_baseline.py:11-41)
+ * with tau = t / 1000. */
+int mjx_bl_num_features(int kind, int n);
+/* fp32 feature matrix (N x (n+4)) of the MLP baseline (computed in fp64, cast like mlp_baseline.py:65). */
+int mjx_bl_features_f32(const double* obs, const int32_t* tpos, int64_t N, int n, float* out, void* stream);
+/* Augmented normal equations in fp64 without materialising the feature matrix A (N x F):
+ * G_aug ((F+1) x (F+1), row-major) = [A y]^T [A y], i.e. A^T A, A^T y and y^T y
+ * (featmat.T.dot(featmat), featmat.T.dot(returns): quadratic_baseline.py:57-60, linear_baseline.py:48-51). */
+int mjx_bl_gram(int kind, const double* obs, const int32_t* tpos, const double* y, int64_t N, int n,
+                double* G_aug_out, void* stream);
+/* out[s] = features(s) . coef   (fp64; quadratic_baseline.py:71-74) */
+int mjx_bl_predict(int kind, const double* obs, const int32_t* tpos, int64_t N, int n, const double* coef,
+                   double* out, void* stream);
+/* ReLU MLP regressor d_in -> hidden... -> 1 (mlp_baseline.py:21-28), flat params [W1,b1,...]:
+ * out[N] = model(feat)                                     (MLPBaseline.predict :97-105) */
+int mjx_mlp_predict(const float* feat, int64_t N, int d_in, const int* hidden, int n_hidden, const float* params,
+                    float* out, void* stream);
+/* `epochs` x (N/batch - 1) minibatch steps of torch.optim.Adam(lr, weight_decay=wd) on the MSE loss
+ * (utils/optimize_model.py:7-36); perm holds epochs*N row indices (np.random.permutation per epoch,
+ * drawn by the caller to keep NumPy's RNG stream); params / m / v are updated in place, step0 = number
+ * of Adam steps already taken; epoch_loss_out[e] = sum of minibatch losses of epoch e (device). */
+int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, const int* hidden, int n_hidden,
+                     float* params, float* m, float* v, int64_t step0, const int32_t* perm, int epochs, int batch,
+                     float lr, float wd, double* epoch_loss_out, void* stream);
+
 /* ---- in-library kernel timing (bench.py roofline) ------------------------- */
 /* While enabled, every launch of the dominant Fisher-vector-product kernel (fused k_fused
  * MODE_FVP, or the whole layer-wise FVP chain) is bracketed by hipEvents recorded on the

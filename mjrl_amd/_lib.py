@@ -44,6 +44,13 @@ PROTOTYPES = {
     "mjx_sum_stats": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p]),
     "mjx_whiten_cast": (c_int, [c_void_p, c_int64, c_double, c_double, c_double, c_void_p, c_void_p]),
     "mjx_cast_f64_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "mjx_bl_num_features": (c_int, [c_int, c_int]),
+    "mjx_bl_features_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mjx_bl_gram": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mjx_bl_predict": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "mjx_mlp_predict": (c_int, [c_void_p, c_int64, c_int, ctypes.POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p]),
+    "mjx_mlp_fit_adam": (c_int, [c_void_p, c_void_p, c_int64, c_int, ctypes.POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p,
+                                 c_int64, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     "mjx_profile_enable": (c_int, [c_void_p, c_int]),
     "mjx_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_double)]),
     "mjx_set_debug_buffer": (c_int, [c_void_p, c_void_p, c_int64]),

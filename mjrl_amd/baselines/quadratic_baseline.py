@@ -1,0 +1,71 @@
+"""Ridge-regression value baselines on the GPU.
+
+``QuadraticBaseline`` mirrors mjrl/baselines/quadratic_baseline.py:4-74 and ``LinearBaseline``
+mirrors linear_baseline.py:5-65: same constructor, ``fit(paths, return_errors)``, ``predict(path)``,
+``_coeffs``.  The feature matrix A (N x F, fp64; 52.7 GB at BASELINE cfg5) is never materialised:
+``mjx_bl_gram`` accumulates A^T A and A^T y on the device from the raw observation block
+(csrc/baseline.h k_bl_gram); the F x F solve stays on the host with the reference's own
+``np.linalg.lstsq`` call and regularisation escalation.
+"""
+import copy
+
+import numpy as np
+
+from ._features import FEAT_LINEAR, FEAT_QUADRATIC, DeviceBlock
+
+
+class _RidgeBaseline:
+    _kind = None
+
+    def __init__(self, env_spec, inp_dim=None, inp='obs', reg_coeff=1e-3):
+        self.n = inp_dim if inp_dim is not None else env_spec.observation_dim
+        self.inp = inp
+        self._reg_coeff = reg_coeff
+        self._coeffs = None
+
+    def _solve(self, G, b):
+        """quadratic_baseline.py:54-63 / linear_baseline.py:45-54"""
+        reg_coeff = copy.deepcopy(self._reg_coeff)
+        for _ in range(10):
+            coeffs = np.linalg.lstsq(G + reg_coeff * np.identity(G.shape[0]), b, rcond=-1)[0]
+            if not np.any(np.isnan(coeffs)):
+                break
+            reg_coeff *= 10
+        return coeffs
+
+    def fit(self, paths, return_errors=False):
+        blk = DeviceBlock(paths, self.inp)
+        returns = np.concatenate([path["returns"] for path in paths])
+        if return_errors:
+            predictions = blk.predict_linear(self._kind, self._coeffs) if self._coeffs is not None else np.zeros(returns.shape)
+            error_before = np.sum((returns - predictions) ** 2) / np.sum(returns ** 2)
+        Gaug = blk.gram(self._kind, returns)
+        F = Gaug.shape[0] - 1
+        self._coeffs = self._solve(Gaug[:F, :F], Gaug[:F, F])
+        if return_errors:
+            predictions = blk.predict_linear(self._kind, self._coeffs)
+            error_after = np.sum((returns - predictions) ** 2) / np.sum(returns ** 2)
+            return error_before, error_after
+
+    def predict_batch(self, paths):
+        """concatenated predictions for a list of paths in one device pass"""
+        N = sum(len(p["rewards"]) for p in paths)
+        if self._coeffs is None:
+            return np.zeros(N)
+        return DeviceBlock(paths, self.inp).predict_linear(self._kind, self._coeffs)
+
+    def predict(self, path):
+        if self._coeffs is None:
+            return np.zeros(len(path["rewards"]))
+        return self.predict_batch([path])
+
+
+class QuadraticBaseline(_RidgeBaseline):
+    _kind = FEAT_QUADRATIC
+
+
+class LinearBaseline(_RidgeBaseline):
+    _kind = FEAT_LINEAR
+
+    def __init__(self, env_spec, inp_dim=None, inp='obs', reg_coeff=1e-5):
+        super().__init__(env_spec, inp_dim, inp, reg_coeff)

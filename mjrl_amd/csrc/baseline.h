@@ -1,0 +1,214 @@
+// baseline.h -- value-baseline kernels (K6): feature generation, fp64 normal equations for the
+// linear / quadratic baselines, batched prediction, and the minibatch-Adam MLP regressor.
+//
+// Reference semantics:
+//   mjrl/baselines/mlp_baseline.py:36-105   (features, fit via utils/optimize_model.py:7-36, predict)
+//   mjrl/baselines/quadratic_baseline.py:11-74, linear_baseline.py:11-65 (features, ridge normal equations)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "layerwise.h"
+#include "vecops.h"
+
+namespace mjx {
+
+enum { FEAT_MLP = 0, FEAT_LINEAR = 1, FEAT_QUADRATIC = 2 };
+
+__host__ __device__ inline int bl_num_features(int kind, int n) {
+  if (kind == FEAT_MLP) return n + 4;
+  if (kind == FEAT_LINEAR) return n + 5;
+  return n + n * (n + 1) / 2 + 5;
+}
+
+// feature c of one sample.  o[] = clip(obs, -10, 10) / 10, tau = t / 1000.
+// layouts: MLP [o, tau..tau^4]; LINEAR [o, 1, tau..tau^4]; QUADRATIC [o, o_i*o_j (i<=j, row-major), 1, tau..tau^4]
+struct FeatDesc { int16_t p, q; };   // p>=0,q<0: o[p];  p>=0,q>=0: o[p]*o[q];  p==-1: 1;  p==-2: tau^q
+
+__device__ __forceinline__ double feat_value(FeatDesc fd, const double* o, double tau) {
+  if (fd.p >= 0) return fd.q >= 0 ? o[fd.p] * o[fd.q] : o[fd.p];
+  if (fd.p == -1) return 1.0;
+  double t = tau;
+  for (int k = 1; k < fd.q; ++k) t *= tau;          // tau^q by repeated product; numpy uses pow: agree to ~1 ulp
+  return t;
+}
+
+inline std::vector<FeatDesc> build_feat_table(int kind, int n) {
+  std::vector<FeatDesc> t;
+  for (int i = 0; i < n; ++i) t.push_back({(int16_t)i, -1});
+  if (kind == FEAT_QUADRATIC)
+    for (int i = 0; i < n; ++i)
+      for (int j = i; j < n; ++j) t.push_back({(int16_t)i, (int16_t)j});
+  if (kind != FEAT_MLP) t.push_back({-1, -1});
+  for (int k = 1; k <= 4; ++k) t.push_back({-2, (int16_t)k});
+  return t;
+}
+
+// fp32 feature matrix of the MLP baseline (computed in fp64, then cast: mlp_baseline.py:65)
+__global__ void k_bl_features_f32(const double* __restrict__ obs, const int32_t* __restrict__ tpos, int64_t N, int n,
+                                  float* __restrict__ out) {
+  const int F = n + 4;
+  const int64_t tot = N * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t s = i / F; int c = (int)(i - s * F);
+    double v;
+    if (c < n) v = fmin(fmax(obs[s * n + c], -10.0), 10.0) / 10.0;
+    else { double tau = (double)tpos[s] / 1000.0; v = pow(tau, (double)(c - n + 1)); }
+    out[i] = (float)v;
+  }
+}
+
+// ---- augmented Gram matrix  G' = [A y]^T [A y]  in fp64, features generated on the fly ------------
+// grid: (tile pairs bi<=bj, sample chunks).  64x64 output tile per workgroup, 256 threads x 4x4 outputs.
+constexpr int GT = 64, GKS = 32;
+__global__ __launch_bounds__(256) void k_bl_gram(int nbt, const FeatDesc* __restrict__ table, int F, int n,
+                                                 const double* __restrict__ obs, const int32_t* __restrict__ tpos,
+                                                 const double* __restrict__ y, int64_t N, double* __restrict__ part) {
+  extern __shared__ double sm[];
+  double* so = sm;                       // [GKS][n] clipped obs
+  double* fi = so + GKS * n;             // [GKS][GT+1]
+  double* fj = fi + GKS * (GT + 1);      // [GKS][GT+1]
+  __shared__ double stau[GKS];
+  // decode the upper-triangular tile pair
+  int pid = blockIdx.x, bi = 0;
+  while (pid >= nbt - bi) { pid -= nbt - bi; ++bi; }
+  const int bj = bi + pid;
+  const int FA = F + 1;                  // augmented with y
+  const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+  double acc[4][4] = {{0}};
+  const int64_t chunk = (N + gridDim.y - 1) / gridDim.y;
+  const int64_t lo = blockIdx.y * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
+  for (int64_t s0 = lo; s0 < hi; s0 += GKS) {
+    const int ks = (int)((hi - s0 < GKS) ? hi - s0 : GKS);
+    for (int i = tid; i < ks * n; i += 256) so[i] = fmin(fmax(obs[s0 * n + i], -10.0), 10.0) / 10.0;
+    if (tid < ks) stau[tid] = (double)tpos[s0 + tid] / 1000.0;
+    __syncthreads();
+    for (int i = tid; i < GKS * GT; i += 256) {
+      const int k = i / GT, c = i - k * GT;
+      double vi = 0.0, vj = 0.0;
+      if (k < ks) {
+        const int ci = bi * GT + c, cj = bj * GT + c;
+        if (ci < F) vi = feat_value(table[ci], so + k * n, stau[k]); else if (ci == F) vi = y[s0 + k];
+        if (cj < F) vj = feat_value(table[cj], so + k * n, stau[k]); else if (cj == F) vj = y[s0 + k];
+      }
+      fi[k * (GT + 1) + c] = vi; fj[k * (GT + 1) + c] = vj;
+    }
+    __syncthreads();
+    for (int k = 0; k < GKS; ++k) {
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a[u] = fi[k * (GT + 1) + tr * 4 + u]; b[u] = fj[k * (GT + 1) + tc * 4 + u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc[u][w] = fma(a[u], b[w], acc[u][w]);
+    }
+    __syncthreads();
+  }
+  double* out = part + (size_t)blockIdx.y * FA * FA;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int r = bi * GT + tr * 4 + u, c = bj * GT + tc * 4 + w;
+      if (r < FA && c < FA) out[(size_t)r * FA + c] = acc[u][w];
+    }
+}
+
+// G[r][c] = sum_z part[z][min][max]  (upper-triangle tiles were computed; mirror)
+__global__ void k_bl_gram_reduce(const double* __restrict__ part, int Z, int FA, double* __restrict__ G) {
+  const int64_t tot = (int64_t)FA * FA;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(i / FA), c = (int)(i - (int64_t)r * FA);
+    int rr = r, cc = c;
+    if (r / GT > c / GT) { rr = c; cc = r; }       // tile (bi > bj) was not computed: take the mirrored element
+    double a = 0.0;
+    for (int z = 0; z < Z; ++z) a += part[(size_t)z * tot + (size_t)rr * FA + cc];
+    G[i] = a;
+  }
+}
+
+// out[s] = sum_c feat(s, c) * coef[c]   (fp64; quadratic_baseline.py:71-74)
+__global__ __launch_bounds__(256) void k_bl_predict(const FeatDesc* __restrict__ table, int F, int n,
+                                                    const double* __restrict__ obs, const int32_t* __restrict__ tpos,
+                                                    const double* __restrict__ coef, int64_t N, double* __restrict__ out) {
+  extern __shared__ double sm[];
+  double* o = sm + (size_t)threadIdx.x * n;
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < N; s += (int64_t)gridDim.x * 256) {
+    for (int i = 0; i < n; ++i) o[i] = fmin(fmax(obs[s * n + i], -10.0), 10.0) / 10.0;
+    const double tau = (double)tpos[s] / 1000.0;
+    double a = 0.0;
+    for (int c = 0; c < F; ++c) a += feat_value(table[c], o, tau) * coef[c];
+    out[s] = a;
+  }
+}
+
+// ---- MLP regressor (ReLU) : forward / minibatch Adam --------------------------------------------
+__global__ void k_gather_rows(const float* __restrict__ X, const float* __restrict__ y, const int32_t* __restrict__ idx,
+                              int bs, int dcols, float* __restrict__ Xb, float* __restrict__ yb) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bs * dcols; i += gridDim.x * blockDim.x) {
+    int r = i / dcols, c = i - r * dcols;
+    Xb[i] = X[(int64_t)idx[r] * dcols + c];
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bs; i += gridDim.x * blockDim.x) yb[i] = y[idx[i]];
+}
+
+// d = 2 (yhat - y) / bs   (MSELoss mean, optimize_model.py:31) ; loss_acc[0] += mean((yhat-y)^2)
+__global__ void k_mse_grad(const float* __restrict__ yhat, const float* __restrict__ y, int bs, float* __restrict__ d,
+                           double* __restrict__ loss_acc) {
+  __shared__ double sh[17];
+  double l = 0.0;
+  for (int i = threadIdx.x; i < bs; i += blockDim.x) {
+    float e = yhat[i] - y[i];
+    d[i] = 2.0f * e / (float)bs;
+    l += (double)e * (double)e;
+  }
+  l = block_sum(l, sh);
+  if (threadIdx.x == 0) loss_acc[0] += l / (double)bs;
+}
+
+// torch.optim.Adam (non-amsgrad, L2 weight decay folded into the gradient), fp32 state
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       int64_t cnt, float lr, float wd, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] + wd * p[i];
+    float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+    m[i] = mi; v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+  }
+}
+
+struct MlpRegressor {
+  std::vector<int> sizes;                 // d_in, h..., 1
+  std::vector<int64_t> oW, ob;
+  int64_t P = 0;
+  int nL() const { return (int)sizes.size() - 1; }
+  void init(int d_in, const int* hidden, int nh) {
+    sizes.clear(); sizes.push_back(d_in); for (int i = 0; i < nh; ++i) sizes.push_back(hidden[i]); sizes.push_back(1);
+    oW.clear(); ob.clear(); int64_t k = 0;
+    for (int l = 0; l < nL(); ++l) { oW.push_back(k); k += (int64_t)sizes[l] * sizes[l + 1]; ob.push_back(k); k += sizes[l + 1]; }
+    P = k;
+  }
+  // acts[l] (rows x sizes[l+1]) for hidden layers; out (rows)
+  void forward(const float* params, const float* X, int64_t rows, const std::vector<float*>& acts, float* out, hipStream_t st) {
+    const float* in = X;
+    for (int l = 0; l < nL(); ++l) {
+      const bool last = l == nL() - 1;
+      GemmArgs g{};
+      g.M = (int)rows; g.N = sizes[l + 1]; g.npairs = 1; g.K[0] = sizes[l];
+      g.A[0] = in; g.a_rs[0] = sizes[l]; g.a_ks[0] = 1;
+      g.B[0] = params + oW[l]; g.b_cs[0] = sizes[l]; g.b_ks[0] = 1;
+      g.C = last ? out : acts[l]; g.ldc = sizes[l + 1]; g.c_zs = 0;
+      g.bias = params + ob[l];
+      g.epi = last ? EPI_BIAS : EPI_BIAS_RELU;
+      LayerwiseWS::launch_gemm(g, 1, st);
+      in = g.C;
+    }
+  }
+};
+
+}  // namespace mjx

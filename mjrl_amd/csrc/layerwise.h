@@ -23,7 +23,7 @@
 
 namespace mjx {
 
-enum { EPI_STORE = 0, EPI_BIAS_TANH, EPI_BIAS_AFFINE, EPI_TANGENT, EPI_BACK };
+enum { EPI_STORE = 0, EPI_BIAS_TANH, EPI_BIAS_AFFINE, EPI_TANGENT, EPI_BACK, EPI_BIAS, EPI_BIAS_RELU, EPI_BACK_RELU };
 
 struct GemmArgs {
   int M, N, npairs;
@@ -149,6 +149,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
           else if (g.epi == EPI_BIAS_AFFINE) v = (v + g.bias[col]) * g.osc[col] + (g.osh ? g.osh[col] : 0.f);
           else if (g.epi == EPI_TANGENT) { float y = g.aux[(int64_t)row * g.ld_aux + col]; v = (v + g.bias[col]) * fmaf(-y, y, 1.0f); }
           else if (g.epi == EPI_BACK) { float y = g.aux[(int64_t)row * g.ld_aux + col]; v = v * fmaf(-y, y, 1.0f); }
+          else if (g.epi == EPI_BIAS) v = v + g.bias[col];
+          else if (g.epi == EPI_BIAS_RELU) v = fmaxf(v + g.bias[col], 0.f);
+          else if (g.epi == EPI_BACK_RELU) { float y = g.aux[(int64_t)row * g.ld_aux + col]; v = (y > 0.f) ? v : 0.f; }
           Cz[(int64_t)row * g.ldc + col] = v;
         }
       }

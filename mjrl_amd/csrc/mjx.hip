@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "baseline.h"
 #include "fused_policy.h"
 #include "layerwise.h"
 #include "vecops.h"
@@ -229,6 +230,158 @@ int mjx_bind_policy(mjx_ctx* c, const float* theta_new, const float* theta_old, 
   c->theta_new = theta_new; c->theta_old = theta_old; c->tr_new = tr_new; c->tr_old = tr_old;
   c->old_is_new = old_is_new ? 1 : 0;
   c->lw.invalidate();
+  return MJX_OK;
+}
+
+// ---------------------------------------------------------------------------- K6 baselines
+namespace {
+struct FeatTableCache { int kind = -1, n = -1, F = 0; FeatDesc* dev = nullptr; };
+int get_feat_table(int kind, int n, FeatTableCache** out) {
+  static thread_local FeatTableCache cache[3];
+  if (kind < 0 || kind > 2 || n <= 0 || n > 4096) return fail(MJX_ERR_ARG, "bad feature kind / obs dim");
+  FeatTableCache& c = cache[kind];
+  if (c.n != n) {
+    std::vector<FeatDesc> t = build_feat_table(kind, n);
+    if (c.dev) hipFree(c.dev);
+    HIPCHK(hipMalloc(&c.dev, t.size() * sizeof(FeatDesc)));
+    HIPCHK(hipMemcpy(c.dev, t.data(), t.size() * sizeof(FeatDesc), hipMemcpyHostToDevice));
+    c.kind = kind; c.n = n; c.F = (int)t.size();
+  }
+  *out = &c;
+  return MJX_OK;
+}
+struct Scratch { void* p = nullptr; size_t cap = 0; };
+int get_scratch(Scratch& s, size_t bytes) {
+  if (bytes <= s.cap) return MJX_OK;
+  if (s.p) hipFree(s.p);
+  s.p = nullptr; s.cap = 0;
+  HIPCHK(hipMalloc(&s.p, bytes));
+  s.cap = bytes;
+  return MJX_OK;
+}
+}  // namespace
+
+int mjx_bl_num_features(int kind, int n) { return (kind < 0 || kind > 2 || n <= 0) ? -1 : bl_num_features(kind, n); }
+
+int mjx_bl_features_f32(const double* obs, const int32_t* tpos, int64_t N, int n, float* out, void* stream) {
+  if (!obs || !tpos || !out || N < 0 || n <= 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (N == 0) return MJX_OK;
+  hipLaunchKernelGGL(k_bl_features_f32, dim3(LayerwiseWS::ew_grid(N * (n + 4))), dim3(256), 0, (hipStream_t)stream, obs, tpos, N, n, out);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_bl_gram(int kind, const double* obs, const int32_t* tpos, const double* y, int64_t N, int n, double* G, void* stream) {
+  if (!obs || !tpos || !y || !G || N <= 0) return fail(MJX_ERR_ARG, "bad arguments");
+  FeatTableCache* ft;
+  if (int rc = get_feat_table(kind, n, &ft)) return rc;
+  const int F = ft->F, FA = F + 1, nbt = (FA + GT - 1) / GT, npairs = nbt * (nbt + 1) / 2;
+  int Z = (int)((N + 4095) / 4096);
+  int maxz = (2048 + npairs - 1) / npairs;
+  if (Z > maxz) Z = maxz;
+  if (Z < 1) Z = 1;
+  static thread_local Scratch part;
+  if (int rc = get_scratch(part, (size_t)Z * FA * FA * sizeof(double))) return rc;
+  HIPCHK(hipMemsetAsync(part.p, 0, (size_t)Z * FA * FA * sizeof(double), (hipStream_t)stream));
+  size_t lds = ((size_t)GKS * n + 2 * (size_t)GKS * (GT + 1)) * sizeof(double);
+  if (lds > 64 * 1024) return fail(MJX_ERR_UNSUPPORTED, "obs dim too large for the Gram kernel's LDS staging");
+  hipLaunchKernelGGL(k_bl_gram, dim3(npairs, Z), dim3(256), lds, (hipStream_t)stream, nbt, ft->dev, F, n, obs, tpos, y, N, (double*)part.p);
+  hipLaunchKernelGGL(k_bl_gram_reduce, dim3(LayerwiseWS::ew_grid((int64_t)FA * FA)), dim3(256), 0, (hipStream_t)stream, (const double*)part.p, Z, FA, G);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_bl_predict(int kind, const double* obs, const int32_t* tpos, int64_t N, int n, const double* coef, double* out, void* stream) {
+  if (!obs || !tpos || !coef || !out || N < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (N == 0) return MJX_OK;
+  FeatTableCache* ft;
+  if (int rc = get_feat_table(kind, n, &ft)) return rc;
+  size_t lds = (size_t)256 * n * sizeof(double);
+  if (lds > 64 * 1024) return fail(MJX_ERR_UNSUPPORTED, "obs dim too large for the predict kernel's LDS staging");
+  int grid = (int)((N + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_bl_predict, dim3(grid), dim3(256), lds, (hipStream_t)stream, ft->dev, ft->F, n, obs, tpos, coef, N, out);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_mlp_predict(const float* feat, int64_t N, int d_in, const int* hidden, int n_hidden, const float* params, float* out, void* stream) {
+  if (!feat || !params || !out || N < 0 || d_in <= 0 || n_hidden < 0 || (n_hidden && !hidden)) return fail(MJX_ERR_ARG, "bad arguments");
+  if (N == 0) return MJX_OK;
+  MlpRegressor net; net.init(d_in, hidden, n_hidden);
+  const int64_t CH = 1 << 17;
+  size_t per_row = 0; for (int i = 0; i < n_hidden; ++i) per_row += hidden[i];
+  static thread_local Scratch sc;
+  if (int rc = get_scratch(sc, (size_t)CH * (per_row ? per_row : 1) * sizeof(float))) return rc;
+  std::vector<float*> acts(n_hidden);
+  { float* q = (float*)sc.p; for (int i = 0; i < n_hidden; ++i) { acts[i] = q; q += (size_t)CH * hidden[i]; } }
+  for (int64_t r0 = 0; r0 < N; r0 += CH) {
+    int64_t rows = (N - r0 < CH) ? N - r0 : CH;
+    net.forward(params, feat + r0 * d_in, rows, acts, out + r0, (hipStream_t)stream);
+  }
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, const int* hidden, int n_hidden, float* params,
+                     float* m, float* v, int64_t step0, const int32_t* perm, int epochs, int batch, float lr, float wd,
+                     double* epoch_loss_out, void* stream) {
+  if (!feat || !y || !params || !m || !v || !perm || !epoch_loss_out || N <= 0 || batch <= 0 || epochs < 0 || n_hidden < 0)
+    return fail(MJX_ERR_ARG, "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  MlpRegressor net; net.init(d_in, hidden, n_hidden);
+  const int L = net.nL(), bs = batch;
+  size_t hsum = 0; for (int i = 0; i < n_hidden; ++i) hsum += hidden[i];
+  // scratch: Xb, yb, yhat, d_out, acts (bs x h_l), deltas (bs x h_l), grads (P)
+  static thread_local Scratch sc;
+  size_t fl = (size_t)bs * d_in + 3 * (size_t)bs + 2 * (size_t)bs * hsum + (size_t)net.P;
+  if (int rc = get_scratch(sc, fl * sizeof(float))) return rc;
+  float* q = (float*)sc.p;
+  float* Xb = q; q += (size_t)bs * d_in;
+  float* yb = q; q += bs;
+  float* yhat = q; q += bs;
+  float* dout = q; q += bs;
+  std::vector<float*> acts(n_hidden), dl(n_hidden);
+  for (int i = 0; i < n_hidden; ++i) { acts[i] = q; q += (size_t)bs * hidden[i]; }
+  for (int i = 0; i < n_hidden; ++i) { dl[i] = q; q += (size_t)bs * hidden[i]; }
+  float* grads = q;
+  HIPCHK(hipMemsetAsync(epoch_loss_out, 0, sizeof(double) * (epochs > 0 ? epochs : 1), st));
+  const int64_t steps = N / bs - 1;                 // optimize_model.py:24
+  int64_t t = step0;
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  for (int ep = 0; ep < epochs; ++ep) {
+    for (int64_t mb = 0; mb < steps; ++mb) {
+      hipLaunchKernelGGL(k_gather_rows, dim3((bs * d_in + 255) / 256), dim3(256), 0, st, feat, y, perm + (int64_t)ep * N + mb * bs, bs, d_in, Xb, yb);
+      net.forward(params, Xb, bs, acts, yhat, st);
+      hipLaunchKernelGGL(k_mse_grad, dim3(1), dim3(256), 0, st, yhat, yb, bs, dout, epoch_loss_out + ep);
+      const float* delta = dout;
+      for (int l = L - 1; l >= 0; --l) {
+        const int ho = net.sizes[l + 1], hi_ = net.sizes[l];
+        const float* in = (l == 0) ? Xb : acts[l - 1];
+        GemmArgs g{};
+        g.M = ho; g.N = hi_; g.npairs = 1; g.K[0] = bs;
+        g.A[0] = delta; g.a_rs[0] = 1; g.a_ks[0] = ho;
+        g.B[0] = in; g.b_cs[0] = 1; g.b_ks[0] = hi_;
+        g.C = grads + net.oW[l]; g.ldc = hi_; g.c_zs = 0; g.epi = EPI_STORE;
+        LayerwiseWS::launch_gemm(g, 1, st);
+        hipLaunchKernelGGL(k_colsum, dim3((ho + 63) / 64, 1), dim3(256), 0, st, delta, (int64_t)bs, ho, (int64_t)ho, grads + net.ob[l]);
+        if (l > 0) {
+          GemmArgs b{};
+          b.M = bs; b.N = hi_; b.npairs = 1; b.K[0] = ho;
+          b.A[0] = delta; b.a_rs[0] = ho; b.a_ks[0] = 1;
+          b.B[0] = params + net.oW[l]; b.b_cs[0] = 1; b.b_ks[0] = hi_;
+          b.C = dl[l - 1]; b.ldc = hi_; b.c_zs = 0;
+          b.aux = acts[l - 1]; b.ld_aux = hi_; b.epi = EPI_BACK_RELU;
+          LayerwiseWS::launch_gemm(b, 1, st);
+          delta = dl[l - 1];
+        }
+      }
+      ++t;
+      const float bc1 = (float)(1.0 - std::pow((double)b1, (double)t));
+      const float bc2s = (float)std::sqrt(1.0 - std::pow((double)b2, (double)t));
+      hipLaunchKernelGGL(k_adam, dim3((unsigned)((net.P + 255) / 256)), dim3(256), 0, st, params, grads, m, v, net.P, lr, wd, b1, b2, eps, bc1, bc2s);
+    }
+  }
+  HIPCHK(hipGetLastError());
   return MJX_OK;
 }
 

@@ -292,3 +292,97 @@ def test_scan_full_size_properties():
         y, x = p["returns"], p["rewards"]
         np.testing.assert_allclose(y[:-1] - 0.995 * y[1:], x[:-1], rtol=0, atol=1e-12)
         assert y[-1] == x[-1]
+
+
+# ----------------------------------------------------------------------------- K6 baselines
+def _gae_paths(g):
+    n, m = int(g["n"]), int(g["m"])
+    paths = synth.make_paths(int(g["n_traj"]), int(g["T"]), n, m, seed=int(g["path_seed"]), ragged=True)
+    k = 0
+    for p in paths:
+        T = len(p["rewards"]); p["returns"] = g["returns"][k:k + T].copy(); k += T
+    return paths, n
+
+
+@pytest.mark.parametrize("kind", ["quadratic", "linear"])
+def test_ridge_baselines_vs_reference(kind):
+    from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+    from mjrl_amd.baselines.linear_baseline import LinearBaseline
+    g = load("gae_" + kind)
+    paths, n = _gae_paths(g)
+    spec = type("Spec", (), dict(observation_dim=n, action_dim=3, horizon=400))
+    bl = (QuadraticBaseline if kind == "quadratic" else LinearBaseline)(spec)
+    assert np.all(bl.predict(paths[0]) == 0.0)                     # unfitted: zeros (quadratic_baseline.py:72-73)
+    e0, e1 = bl.fit(paths, return_errors=True)
+    assert e0 == 1.0 and abs(e1 - float(g["err_after"])) < 1e-9
+    pred = bl.predict_batch(paths)
+    np.testing.assert_allclose(pred, g["baseline_pred"], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(bl.predict(paths[3]), pred[sum(len(p["rewards"]) for p in paths[:3]):][:len(paths[3]["rewards"])], rtol=0, atol=1e-12)
+    # the Gram matrix itself against the fp64 feature matrix of the oracle
+    from mjrl_amd.baselines._features import DeviceBlock, FEAT_QUADRATIC, FEAT_LINEAR
+    obs_list = [p["observations"] for p in paths]
+    F = O.quadratic_baseline_features(obs_list) if kind == "quadratic" else O.linear_baseline_features(obs_list)
+    G = DeviceBlock(paths, 'obs').gram(FEAT_QUADRATIC if kind == "quadratic" else FEAT_LINEAR, g["returns"])
+    Fa = np.concatenate([F, g["returns"][:, None]], axis=1)
+    np.testing.assert_allclose(G, Fa.T @ Fa, rtol=1e-11, atol=1e-9)
+    assert np.array_equal(G, G.T)
+
+
+def test_mlp_baseline_vs_reference():
+    import torch
+    from mjrl_amd.baselines.mlp_baseline import MLPBaseline
+    g = load("gae_mlp")
+    paths, n = _gae_paths(g)
+    spec = type("Spec", (), dict(observation_dim=n, action_dim=3, horizon=400))
+    torch.manual_seed(4); np.random.seed(4)
+    bl = MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3)
+    assert np.array_equal(bl.params, g["bl_params"])               # same seed -> the reference's initial weights
+    pred = bl.predict_batch(paths)
+    np.testing.assert_allclose(pred, g["baseline_pred"], rtol=2e-5, atol=2e-6)
+    np.random.seed(int(g["fit_seed"]))
+    e0, e1 = bl.fit(paths, return_errors=True)
+    assert abs(e0 - float(g["err_before"])) < 1e-6
+    # 2 epochs x 94 Adam steps with identical minibatches: fp32 round-off only
+    assert abs(e1 - float(g["err_after"])) < 2e-4 * float(g["err_after"])
+    assert rel(bl.params, g["bl_params_after"]) < 2e-4
+    assert bl.adam_steps == 2 * (len(g["returns"]) // 64 - 1)
+    import pickle
+    bl2 = pickle.loads(pickle.dumps(bl))
+    np.testing.assert_array_equal(bl2.predict(paths[0]), bl.predict(paths[0]))
+
+
+def test_train_step_plumbing_numpy_env():
+    """cfg1-style end-to-end train_step: NumPy point-mass stand-in env -> sampler -> returns/GAE ->
+    NPG update -> baseline fit, all through the mjrl-shaped classes."""
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.baselines.mlp_baseline import MLPBaseline
+    from mjrl_amd.policies.gaussian_mlp import MLP
+
+    class PointMass:                       # obs = [pos(2), vel(2), target(2)], act = force(2), horizon 25
+        horizon = 25
+        def __init__(self):
+            self.rng = np.random.RandomState(0)
+        def set_seed(self, s):
+            self.rng = np.random.RandomState(s)
+        def reset(self):
+            self.p, self.v, self.g, self.t = self.rng.uniform(-1, 1, 2), np.zeros(2), self.rng.uniform(-1, 1, 2), 0
+            return np.concatenate([self.p, self.v, self.g])
+        def step(self, a):
+            self.v = 0.9 * self.v + 0.1 * np.clip(a, -1, 1); self.p = self.p + 0.1 * self.v; self.t += 1
+            return np.concatenate([self.p, self.v, self.g]), -float(np.linalg.norm(self.p - self.g)), False, {}
+
+    spec = type("Spec", (), dict(observation_dim=6, action_dim=2, horizon=25))
+    pol = MLP(spec, hidden_sizes=(32, 32), seed=2, init_log_std=-0.5)
+    bl = MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3)
+    agent = NPG(PointMass(), pol, bl, normalized_step_size=0.05, seed=2, save_logs=True)
+    scores = []
+    for _ in range(8):
+        stats = agent.train_step(N=80, sample_mode='trajectories', gamma=0.95, gae_lambda=0.97, num_cpu=1)
+        scores.append(stats[0]); assert len(stats) == 5 and np.isfinite(stats[0])
+    lg = agent.logger.get_current_log()
+    for k in ("alpha", "delta", "time_vpg", "time_npg", "kl_dist", "surr_improvement", "running_score", "num_samples",
+              "time_VF", "VF_error_before", "VF_error_after", "stoc_pol_mean", "time_sampling"):
+        assert k in lg, k
+    assert 0 < lg["kl_dist"] < 0.1 and lg["surr_improvement"] > 0
+    assert scores[-1] > scores[0]          # it learns
+    assert agent.seed == 2 + 8 * 80
