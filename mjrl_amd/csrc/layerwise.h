@@ -23,7 +23,7 @@
 
 namespace mjx {
 
-enum { EPI_STORE = 0, EPI_BIAS_TANH, EPI_BIAS_AFFINE, EPI_TANGENT, EPI_BACK, EPI_BIAS, EPI_BIAS_RELU, EPI_BACK_RELU };
+enum { EPI_STORE = 0, EPI_BIAS_TANH, EPI_BIAS_AFFINE, EPI_TANGENT, EPI_BACK, EPI_BIAS, EPI_BIAS_RELU, EPI_BACK_RELU, EPI_RBACK };
 
 struct GemmArgs {
   int M, N, npairs;
@@ -34,6 +34,7 @@ struct GemmArgs {
   int64_t c_zs;
   const float* bias;                              // per column
   const float* aux; int64_t ld_aux;               // activation for the (1 - y^2) factor
+  const float* aux2; const float* aux3;           // EPI_RBACK: tangent activation t and the pre-activation cotangent
   const float* osc; const float* osh;             // per-column affine (EPI_BIAS_AFFINE)
   int epi;
 };
@@ -149,6 +150,11 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
           else if (g.epi == EPI_BIAS_AFFINE) v = (v + g.bias[col]) * g.osc[col] + (g.osh ? g.osh[col] : 0.f);
           else if (g.epi == EPI_TANGENT) { float y = g.aux[(int64_t)row * g.ld_aux + col]; v = (v + g.bias[col]) * fmaf(-y, y, 1.0f); }
           else if (g.epi == EPI_BACK) { float y = g.aux[(int64_t)row * g.ld_aux + col]; v = v * fmaf(-y, y, 1.0f); }
+          else if (g.epi == EPI_RBACK) {            // R{delta} = acc (1 - y^2) - 2 y t pre   (Pearlmutter R-backward through tanh)
+            const int64_t o = (int64_t)row * g.ld_aux + col;
+            float y = g.aux[o], t = g.aux2[o], pre = g.aux3[o];
+            v = v * fmaf(-y, y, 1.0f) - 2.0f * y * t * pre;
+          }
           else if (g.epi == EPI_BIAS) v = v + g.bias[col];
           else if (g.epi == EPI_BIAS_RELU) v = fmaxf(v + g.bias[col], 0.f);
           else if (g.epi == EPI_BACK_RELU) { float y = g.aux[(int64_t)row * g.ld_aux + col]; v = (y > 0.f) ? v : 0.f; }
@@ -240,6 +246,53 @@ __global__ void k_fvp_head(float* __restrict__ mudot, int64_t N, int m, const fl
   }
 }
 
+// General (theta_new != theta_old) KL Hessian head, per sample and action j  (gaussian_mlp.py:135-145):
+//   e = mu_n - mu_o, u = sigma_n^2, D = 2u + 1e-8
+//   d3  = out_scale * (2 e / D) / N                                  first-order cotangent on the pre-affine output
+//   Rd3 = out_scale * ((2/D) mudot + c_ms v_s) / N,  c_ms = -8 e u / D^2
+//   hs_j += (c_ms mudot + g2 v_s) / N,  g2 = -(1e-8 + 2A) 4u (1e-8 - 2u) / D^3,  A = e^2 + sigma_o^2
+// mudot (in: post-affine tangent of mu) is overwritten with Rd3; part: [gridDim.x][MPH] doubles.
+__global__ __launch_bounds__(256) void k_hvp_head(const float* __restrict__ mu, const float* __restrict__ mu_old,
+                                                  float* __restrict__ mudot, float* __restrict__ d3, int64_t N, int m,
+                                                  const float* __restrict__ ls_new, const float* __restrict__ ls_old,
+                                                  const float* __restrict__ vs, const float* __restrict__ osc, float inv_N,
+                                                  double* __restrict__ part) {
+  __shared__ double sh[17];
+  for (int a = 0; a < m; ++a) {
+    const float sn = expf(ls_new[a]), so = expf(ls_old[a]);
+    const float u = sn * sn, D = 2.0f * u + 1e-8f, va = vs[a], oa = osc[a];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+      const int64_t o = i * m + a;
+      const float e = mu[o] - mu_old[o], md = mudot[o];
+      const float cms = -8.0f * e * u / (D * D);
+      const float A2 = e * e + so * so;
+      const float g2 = -(1e-8f + 2.0f * A2) * 4.0f * u * (1e-8f - 2.0f * u) / (D * D * D);
+      d3[o] = oa * (2.0f * e / D) * inv_N;
+      mudot[o] = oa * ((2.0f / D) * md + cms * va) * inv_N;
+      acc += (double)((cms * md + g2 * va) * inv_N);
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * MPH + a] = acc;
+  }
+}
+__global__ void k_reduce_hs(const double* __restrict__ part, int G, int m, float* __restrict__ out) {
+  __shared__ double sh[17];
+  for (int a = 0; a < m; ++a) {
+    double t = 0.0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) t += part[(size_t)g * MPH + a];
+    t = block_sum(t, sh);
+    if (threadIdx.x == 0) out[a] = (float)t;
+  }
+}
+// p <- p * (1 - y^2)
+__global__ void k_scale_dtanh(float* __restrict__ p, const float* __restrict__ y, int64_t cnt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) {
+    float yy = y[i];
+    p[i] *= fmaf(-yy, yy, 1.0f);
+  }
+}
+
 // column sums of a (N x h) matrix, split over row ranges: part[z][h]
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ D, int64_t N, int h, int64_t ld, float* __restrict__ part) {
   __shared__ float sh[4][64];
@@ -296,6 +349,8 @@ struct LayerwiseWS {
   std::vector<float*> H;             // hidden activations of the NEW net (cached)
   std::vector<float*> T;             // tangent / delta buffers per hidden layer
   float *mu = nullptr, *mu2 = nullptr, *d3 = nullptr;   // (N x m)
+  std::vector<float*> P, RD;         // general-HVP extras: pre-activation cotangents / R-deltas (lazy)
+  float* rd3 = nullptr; int64_t gen_cap = 0;
   float* part = nullptr; int64_t part_cap = 0;          // split-K partials
   double* hpart = nullptr;           // head partials
   bool fwd_valid = false;
@@ -309,13 +364,16 @@ struct LayerwiseWS {
     for (int l = 0; l < nL(); ++l) { oW.push_back(k); k += (int64_t)sizes[l] * sizes[l + 1]; ob.push_back(k); k += sizes[l + 1]; }
     oS = k; d = k + m;
     H.assign(hid.size(), nullptr); T.assign(hid.size(), nullptr);
+    P.assign(hid.size(), nullptr); RD.assign(hid.size(), nullptr);
   }
   void invalidate() { fwd_valid = false; }
   void release() {
     hipFree(Xn); Xn = nullptr;
     for (auto& p : H) { hipFree(p); p = nullptr; }
     for (auto& p : T) { hipFree(p); p = nullptr; }
-    hipFree(mu); hipFree(mu2); hipFree(d3); hipFree(part); hipFree(hpart);
+    hipFree(mu); hipFree(mu2); hipFree(d3); hipFree(part); hipFree(hpart); hipFree(rd3); rd3 = nullptr; gen_cap = 0;
+    for (auto& p : P) { hipFree(p); p = nullptr; }
+    for (auto& p : RD) { hipFree(p); p = nullptr; }
     mu = mu2 = d3 = part = nullptr; hpart = nullptr; cap = 0; part_cap = 0;
   }
   static constexpr int HEAD_G = 512;
@@ -458,6 +516,87 @@ struct LayerwiseWS {
     hipLaunchKernelGGL(k_fvp_head, dim3(ew_grid(N * m)), dim3(256), 0, st, d3, N, m, theta + oS, tr + 2 * n + m, (float)(1.0 / (double)Ng));
     hipLaunchKernelGGL(k_fvp_logstd, dim3(1), dim3(64), 0, st, theta + oS, v + oS, m, (float)((double)N / (double)Ng), out + oS);
     return backward(theta, N, out, st);
+  }
+
+  // Exact Hessian-vector product of mean_kl(new, old) wrt theta_new for theta_new != theta_old
+  // (npg_cg.py:62-81 in general position, e.g. under input_normalization :101-107):
+  // forward + R-forward + backward + R-backward (Pearlmutter), without the damping term.
+  int hvp_general(const float* obs, int64_t N, int64_t Ng, const float* th_new, const float* th_old, const float* tr_new,
+                  const float* tr_old, const float* v, float* out, hipStream_t st) {
+    if (N > cap) return 1;
+    if (gen_cap < cap) {
+      for (size_t l = 0; l < P.size(); ++l) {
+        hipFree(P[l]); hipFree(RD[l]);
+        if (hipMalloc(&P[l], (size_t)cap * sizes[l + 1] * 4) != hipSuccess) return 2;
+        if (hipMalloc(&RD[l], (size_t)cap * sizes[l + 1] * 4) != hipSuccess) return 2;
+      }
+      hipFree(rd3);
+      if (hipMalloc(&rd3, (size_t)cap * m * 4) != hipSuccess) return 2;
+      gen_cap = cap;
+    }
+    const float inv_N = (float)(1.0 / (double)Ng);
+    forward(th_old, tr_old, obs, N, T, mu2, st);          // old means (hidden activations are scratch)
+    forward(th_new, tr_new, obs, N, H, mu, st);
+    fwd_valid = true;
+    // R-forward: T_l = (in V_l^T + T_{l-1} W_l^T + c_l)(1 - H_l^2), rd3 = out_scale (.. + c_L)
+    const float* tin = nullptr;
+    for (int l = 0; l < nL(); ++l) {
+      const bool last = (l == nL() - 1);
+      const float* in = (l == 0) ? Xn : H[l - 1];
+      GemmArgs g{};
+      g.M = (int)N; g.N = sizes[l + 1]; g.npairs = tin ? 2 : 1;
+      g.K[0] = sizes[l]; g.A[0] = in; g.a_rs[0] = sizes[l]; g.a_ks[0] = 1;
+      g.B[0] = v + oW[l]; g.b_cs[0] = sizes[l]; g.b_ks[0] = 1;
+      if (tin) { g.K[1] = sizes[l]; g.A[1] = tin; g.a_rs[1] = sizes[l]; g.a_ks[1] = 1; g.B[1] = th_new + oW[l]; g.b_cs[1] = sizes[l]; g.b_ks[1] = 1; }
+      g.bias = v + ob[l]; g.c_zs = 0;
+      if (last) { g.C = rd3; g.ldc = m; g.epi = EPI_BIAS_AFFINE; g.osc = tr_new + 2 * n + m; g.osh = nullptr; }
+      else { g.C = T[l]; g.ldc = sizes[l + 1]; g.epi = EPI_TANGENT; g.aux = H[l]; g.ld_aux = sizes[l + 1]; }
+      launch_gemm(g, 1, st);
+      tin = last ? nullptr : T[l];
+    }
+    hipLaunchKernelGGL(k_hvp_head, dim3(HEAD_G), dim3(256), 0, st, mu, mu2, rd3, d3, N, m, th_new + oS, th_old + oS, v + oS,
+                       tr_new + 2 * n + m, inv_N, hpart);
+    hipLaunchKernelGGL(k_reduce_hs, dim3(1), dim3(256), 0, st, hpart, HEAD_G, m, out + oS);
+    // backward with R: delta (first order) and Rdelta
+    const float* dl = d3; const float* rdl = rd3;
+    for (int l = nL() - 1; l >= 0; --l) {
+      const int ho = sizes[l + 1], hi_ = sizes[l];
+      const float* in = (l == 0) ? Xn : H[l - 1];
+      const float* tinl = (l == 0) ? nullptr : T[l - 1];
+      int tiles = ((ho + GBM - 1) / GBM) * ((hi_ + GBN - 1) / GBN);
+      int splits = (int)((N + 2047) / 2048);
+      int maxs = (1024 + tiles - 1) / tiles;
+      if (splits > maxs) splits = maxs;
+      if (splits < 1) splits = 1;
+      if (ensure_part((int64_t)splits * ho * hi_ + (int64_t)splits * ho)) return 2;
+      GemmArgs g{};                                         // R{gW_l} = Rdelta^T in + delta^T Tin
+      g.M = ho; g.N = hi_; g.npairs = tinl ? 2 : 1;
+      g.K[0] = (int)N; g.A[0] = rdl; g.a_rs[0] = 1; g.a_ks[0] = ho; g.B[0] = in; g.b_cs[0] = 1; g.b_ks[0] = hi_;
+      if (tinl) { g.K[1] = (int)N; g.A[1] = dl; g.a_rs[1] = 1; g.a_ks[1] = ho; g.B[1] = tinl; g.b_cs[1] = 1; g.b_ks[1] = hi_; }
+      g.C = part; g.ldc = hi_; g.c_zs = (int64_t)ho * hi_; g.epi = EPI_STORE;
+      launch_gemm(g, splits, st);
+      hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid((int64_t)ho * hi_)), dim3(256), 0, st, part, splits, (int64_t)ho * hi_, out + oW[l]);
+      float* bpart = part + (int64_t)splits * ho * hi_;
+      hipLaunchKernelGGL(k_colsum, dim3((ho + 63) / 64, splits), dim3(256), 0, st, rdl, N, ho, (int64_t)ho, bpart);
+      hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid(ho)), dim3(256), 0, st, bpart, splits, (int64_t)ho, out + ob[l]);
+      if (l > 0) {
+        GemmArgs a{};                                       // pre = delta W_l
+        a.M = (int)N; a.N = hi_; a.npairs = 1; a.K[0] = ho;
+        a.A[0] = dl; a.a_rs[0] = ho; a.a_ks[0] = 1; a.B[0] = th_new + oW[l]; a.b_cs[0] = 1; a.b_ks[0] = hi_;
+        a.C = P[l - 1]; a.ldc = hi_; a.c_zs = 0; a.epi = EPI_STORE;
+        launch_gemm(a, 1, st);
+        GemmArgs b{};                                       // Rdelta_l = (delta V_l + Rdelta W_l)(1-H^2) - 2 H T pre
+        b.M = (int)N; b.N = hi_; b.npairs = 2;
+        b.K[0] = ho; b.A[0] = dl; b.a_rs[0] = ho; b.a_ks[0] = 1; b.B[0] = v + oW[l]; b.b_cs[0] = 1; b.b_ks[0] = hi_;
+        b.K[1] = ho; b.A[1] = rdl; b.a_rs[1] = ho; b.a_ks[1] = 1; b.B[1] = th_new + oW[l]; b.b_cs[1] = 1; b.b_ks[1] = hi_;
+        b.C = RD[l - 1]; b.ldc = hi_; b.c_zs = 0;
+        b.aux = H[l - 1]; b.ld_aux = hi_; b.aux2 = T[l - 1]; b.aux3 = P[l - 1]; b.epi = EPI_RBACK;
+        launch_gemm(b, 1, st);
+        hipLaunchKernelGGL(k_scale_dtanh, dim3(ew_grid(N * hi_)), dim3(256), 0, st, P[l - 1], H[l - 1], N * hi_);
+        dl = P[l - 1]; rdl = RD[l - 1];
+      }
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
   }
 
   int eval(const float* obs, const float* act, const float* adv, int64_t N, const float* th_new, const float* th_old,

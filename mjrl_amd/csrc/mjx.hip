@@ -438,9 +438,15 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
 int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
   if (int rc = check_bound(c, false)) return rc;
   if (!v || !out) return fail(MJX_ERR_ARG, "null vector");
-  if (!c->old_is_new) return fail(MJX_ERR_UNSUPPORTED, "mjx_fvp needs theta_new == theta_old (Gauss-Newton form); general Hessian not implemented");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->device));
+  if (!c->old_is_new) {
+    // general position (e.g. input_normalization, npg_cg.py:101-107): exact Pearlmutter product on the layer-wise path
+    if (c->lw.cap < c->N_local) { if (int rc = c->lw.reserve(c->N_local)) return fail(rc, "layer-wise workspace allocation failed"); }
+    int rc = c->lw.hvp_general(c->obs, c->N_local, c->N_global, c->theta_new, c->theta_old, c->tr_new ? c->tr_new : c->ident_tr,
+                               c->tr_old ? c->tr_old : c->ident_tr, v, out, st);
+    return rc ? fail(MJX_ERR_STATE, "general Hessian-vector product failed (%d)", rc) : MJX_OK;
+  }
   const float frac = (float)((double)c->N_local / (double)c->N_global);
   const bool prof = c->prof_on && c->prof_used + 2 <= c->prof_ev.size();
   if (prof) HIPCHK(hipEventRecord(c->prof_ev[c->prof_used], st));

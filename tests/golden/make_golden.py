@@ -66,7 +66,7 @@ def cat(paths):
 
 
 def npg_case(name, n, m, hidden, n_traj, T, cg_iters, algo="npg", ragged=False, transforms=None,
-             kl_dist=None, step=0.05, demo=None):
+             kl_dist=None, step=0.05, demo=None, input_normalization=None):
     pol = make_policy(n, m, hidden, transforms=transforms)
     theta0 = pol.get_param_values()
     paths = synth.make_paths(n_traj, T, n, m, seed=0, ragged=ragged)
@@ -75,7 +75,7 @@ def npg_case(name, n, m, hidden, n_traj, T, cg_iters, algo="npg", ragged=False, 
     adv_w = (adv - np.mean(adv)) / (np.std(adv) + 1e-6)
     kw = dict(FIM_invert_args={'iters': cg_iters, 'damping': 1e-4})
     if algo == "npg":
-        agent = NPG(None, pol, None, normalized_step_size=step, **kw)
+        agent = NPG(None, pol, None, normalized_step_size=step, input_normalization=input_normalization, **kw)
     elif algo == "trpo":
         agent = TRPO(None, pol, None, kl_dist=kl_dist, **kw)
     else:
@@ -89,6 +89,7 @@ def npg_case(name, n, m, hidden, n_traj, T, cg_iters, algo="npg", ragged=False, 
     if demo is not None:
         out.update(demo_n_traj=demo[0], demo_T=demo[1], demo_seed=7, lam_0=1e-2, lam_1=0.95)
     # pieces (only meaningful for the plain NPG gradient; DAPG builds its own)
+    out["input_normalization"] = -1.0 if input_normalization is None else input_normalization
     out["surr_before"] = agent.CPI_surrogate(obs, act, adv_w).data.numpy().ravel()[0]
     g = agent.flat_vpg(obs, act, adv_w)
     out["vpg"] = g
@@ -102,6 +103,7 @@ def npg_case(name, n, m, hidden, n_traj, T, cg_iters, algo="npg", ragged=False, 
     agent.logger = DataLog()
     stats = agent.train_from_paths(paths)
     log = agent.logger.log
+    out.update(final_in_shift=pol.model.in_shift.data.numpy(), final_in_scale=pol.model.in_scale.data.numpy())
     out.update(new_params=pol.get_param_values(), alpha=log['alpha'][-1], kl=log['kl_dist'][-1],
                surr_improvement=log['surr_improvement'][-1], base_stats=np.array(stats),
                running_score=agent.running_score)
@@ -182,6 +184,7 @@ if __name__ == "__main__":
     npg_case("npg_pointmass_32x32", 6, 2, (32, 32), 40, 25, 10)
     npg_case("npg_cfg2_small", 17, 6, (64, 64), 20, 500, 10)
     npg_case("npg_cfg2_ragged_tr", 17, 6, (64, 64), 37, 300, 10, ragged=True, transforms=tr)
+    npg_case("npg_inputnorm_32x32", 11, 3, (32, 32), 30, 100, 10, input_normalization=0.7)
     npg_case("trpo_cfg3_small", 17, 6, (64, 64), 20, 500, 10, algo="trpo", kl_dist=0.01)
     npg_case("npg_cfg4_small", 376, 17, (256, 256), 80, 250, 25)
     npg_case("dapg_cfg5_small", 39, 28, (512, 512), 100, 100, 10, algo="dapg", kl_dist=0.025, demo=(5, 100))

@@ -386,3 +386,61 @@ def test_train_step_plumbing_numpy_env():
     assert 0 < lg["kl_dist"] < 0.1 and lg["surr_improvement"] > 0
     assert scores[-1] > scores[0]          # it learns
     assert agent.seed == 2 + 8 * 80
+
+
+# ----------------------------------------------------------------------------- N1: general Hessian
+def test_general_hvp_vs_reference():
+    """theta_new != theta_old and different input transforms: exact Pearlmutter product against the
+    reference's double-backward HVP (golden) and the torch-autograd port."""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    g = load("hvp_general_64x64")
+    n, m, hid = int(g["n"]), int(g["m"]), tuple(int(h) for h in g["hidden"])
+    paths = synth.make_paths(int(g["n_traj"]), int(g["T"]), n, m, seed=0)
+    obs = np.concatenate([p["observations"] for p in paths])
+    eng = UpdateEngine(n, m, hid)
+    ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    trn = np.concatenate([np.float32(g["in_shift"]), np.float32(g["in_scale"]), np.zeros(m, np.float32), np.ones(m, np.float32)])
+    eng.set_policy(g["theta_new"], g["theta_old"], trn, ident)
+    eng.set_batch(obs)
+    hv = eng.fvp(torch.from_numpy(g["v"]).to(eng.device)).cpu().numpy() + np.float32(1e-4) * g["v"]
+    assert rel(hv, g["hvp"]) < 1e-5, rel(hv, g["hvp"])
+    eng.close()
+    # a non-fused shape with out_scale != 1, against the autograd port
+    from oracle.torch_port import TorchPolicy
+    n, m, hid, N = 40, 9, (96, 48, 24), 3000
+    rng = np.random.RandomState(2)
+    th_o = synth.perturbed_params(synth.init_params(n, m, hid), scale=0.05)
+    th_n = (th_o + 0.03 * rng.randn(th_o.size)).astype(np.float32)
+    obs = rng.randn(N, n)
+    act = rng.randn(N, m)
+    trn = O.Transforms(n, m, 0.1 * rng.randn(n), 1 + 0.1 * rng.rand(n), 0.05 * rng.randn(m), 1 + 0.2 * rng.rand(m))
+    tro = O.Transforms(n, m, None, None, 0.02 * rng.randn(m), 1 + 0.1 * rng.rand(m))
+    pk = lambda t: np.concatenate([t.in_shift, t.in_scale, t.out_shift, t.out_scale]).astype(np.float32)
+    v = rng.randn(th_o.size).astype(np.float32)
+    ref = TorchPolicy(th_n, n, m, hid, theta_old=th_o, tr_new=trn, tr_old=tro).hvp(obs, act, v, 0.0)
+    eng = UpdateEngine(n, m, hid)
+    eng.set_policy(th_n, th_o, pk(trn), pk(tro))
+    eng.set_batch(obs)
+    hv = eng.fvp(torch.from_numpy(v).to(eng.device)).cpu().numpy()
+    assert rel(hv, ref) < 1e-5, rel(hv, ref)
+    eng.close()
+
+
+def test_npg_input_normalization_vs_reference():
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    c = NpgCase("npg_inputnorm_32x32")
+    spec = type("Spec", (), dict(observation_dim=c.n, action_dim=c.m, horizon=1000))
+    pol = MLP(spec, hidden_sizes=c.hidden, seed=1, init_log_std=-0.5)
+    pol.set_param_values(c.theta0)
+    agent = NPG(None, pol, None, normalized_step_size=float(c.g["step"]), input_normalization=float(c.g["input_normalization"]),
+                FIM_invert_args={'iters': c.cg_iters, 'damping': 1e-4})
+    agent.train_from_paths(c.paths)
+    np.testing.assert_allclose(pol.model.in_shift, c.g["final_in_shift"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(pol.model.in_scale, c.g["final_in_scale"], rtol=1e-6, atol=1e-7)
+    assert np.all(pol.old_model.in_scale == 1.0)                  # the reference never touches old_model here
+    step, ref = pol.get_param_values().astype(np.float64) - c.theta0, c.g["new_params"].astype(np.float64) - c.theta0
+    assert rel(step, ref) < 2e-5, rel(step, ref)
+    assert abs(agent.last_update["alpha"] - float(c.g["alpha"])) < 2e-5 * float(c.g["alpha"])
+    assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < 1e-4 * float(c.g["kl"])
