@@ -379,36 +379,32 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       }
     };
 
-    // output layer on the matrix pipe: acc[r] (r < RA) = bias[a] + sum_k W[a][k] v[k], a = unit_of(r, hi);
-    // rows >= MP of the 32-row tile are fed zeros.  v = accumulators of the previous layer (chained).
-    auto out_mfma = [&](f32x16& acc, const float* slot, const f32x16 (&v)[MT2]) {
-      const float* arow = &slot[L.oW3 + (j < MP ? j : 0) * S3 + 4 * hi];
-      constexpr int NS = MT2 * 4;
-      __builtin_amdgcn_sched_barrier(0);            // own region: [read of group g+1][4 chained MFMAs of group g]
-      f32x4 wc = *(const f32x4*)arow, wn;
+    // Output layer (M = #actions is tiny) on v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer-product
+    // blocks per instruction; lane l = (block l/4, column l%4) gets D[r][l%4] += A[4*(l/4)+r] * B[l].
+    // Here block = the lane's sample quad, B = the lane's own activation register (unit k of its half),
+    // A = W[a = 4*grp + (l&3)][k]: each lane accumulates og[grp][r] = partial out[a = 4*grp + r] of ITS
+    // sample over the 32 units its half owns.  8 cycles per instruction instead of padding M to 32.
+    constexpr int NGRP = MP / 4;
+    auto out_small = [&](f32x4 (&og)[NGRP], const float* slot, const f32x16 (&v)[MT2]) {
 #pragma unroll
-      for (int st = 0; st < NS; ++st) {
-        const int kb = st >> 2, q = st & 3;
-        if (st + 1 < NS) wn = *(const f32x4*)(arow + 32 * ((st + 1) >> 2) + 8 * ((st + 1) & 3));
-        f32x4 a4 = (j < MP) ? wc : (f32x4)(0.f);
+      for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc = MJX_MFMA(a4[t], v[kb][4 * q + t], acc);
-        wc = wn;
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int q = 0; q < 4; ++q) {
+          f32x4 w[NGRP];
 #pragma unroll
-      for (int st = 0; st < NS; ++st) {
-        if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // the four selects that zero rows >= MP
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+          for (int gp = 0; gp < NGRP; ++gp) w[gp] = *(const f32x4*)&slot[L.oW3 + (4 * gp + (lane & 3)) * S3 + 32 * mt + 8 * q + 4 * hi];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int gp = 0; gp < NGRP; ++gp) og[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[gp][t], v[mt][4 * q + t], og[gp], 0, 0, 0);
+        }
     };
-    auto bias_rows = [&](const float* slot) {
-      f32x16 acc = (f32x16)(0.f);
+    // both lane halves end up with the full sums for all MP actions
+    auto out_finish = [&](f32x4 (&og)[NGRP], float (&o)[MP]) {
 #pragma unroll
-      for (int r = 0; r < RA; ++r) acc[r] = slot[L.oB3 + unit_of(r, hi)];
-      return acc;
+      for (int gp = 0; gp < NGRP; ++gp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float p = og[gp][r]; o[4 * gp + r] = p + __shfl_xor(p, 32); }
     };
 
     f32x16 h1[MT1], h2[MT2];
@@ -418,9 +414,13 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 
     float d3r[RA];                                  // cotangent on the pre-scale output, rows a = unit_of(r, hi)
     if (MODE == MODE_FVP) {
-      f32x16 md = bias_rows(slotB);                 // c3
-      out_mfma(md, slotB, h2);                      // + V3 h2
-      out_mfma(md, slotA, t2);                      // + W3 t2
+      f32x4 og[NGRP];
+#pragma unroll
+      for (int gp = 0; gp < NGRP; ++gp) og[gp] = (f32x4)(0.f);
+      out_small(og, slotB, h2);                     // V3 h2
+      out_small(og, slotA, t2);                     // + W3 t2
+      float md[MP];
+      out_finish(og, md);
       if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0) {
         float* g = A.dbg;
 #pragma unroll
@@ -438,55 +438,60 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
             g[2048 * 3 + (32 * mt + unit_of(r, hi)) * 32 + j] = t2[mt][r];
           }
       }
+      float d3a[MP];
 #pragma unroll
-      for (int r = 0; r < RA; ++r) {
-        const int a = unit_of(r, hi);
+      for (int a = 0; a < MP; ++a) {
         float osc = cst[C_OSC * MP + a], sg = cst[C_SG * MP + a];
-        float mudot = osc * md[r];
+        float mudot = osc * (md[a] + slotB[L.oB3 + a]);             // + c3
         float Dk = 2.0f / (2.0f * sg * sg + 1e-8f);
         float dmu = valid ? Dk * mudot * A.inv_N : 0.f;
-        d3r[r] = osc * dmu;
-        if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0) A.dbg[2048 * 4 + a * 32 + j] = mudot;
+        d3a[a] = osc * dmu;
+        if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0 && hi == 0) A.dbg[2048 * 4 + a * 32 + j] = mudot;
       }
+#pragma unroll
+      for (int r = 0; r < RA; ++r) d3r[r] = hi ? d3a[unit_of(r, 1)] : d3a[unit_of(r, 0)];
     } else {
       // ---- likelihoods (mean_LL, gaussian_mlp.py:99-115); each lane owns the actions a = unit_of(r, hi)
       float sum_lsA = 0.f, sum_lsB = 0.f;
 #pragma unroll
       for (int a = 0; a < MP; ++a) { sum_lsA += cst[C_LS * MP + a]; sum_lsB += cst[C_LSB * MP + a]; }
       const float llc = 0.5f * (float)m * 1.8378770664093453f;
-      f32x16 mu = bias_rows(slotA);
-      out_mfma(mu, slotA, h2);
-      float av[RA], z[RA], muv[RA];
+      f32x4 og[NGRP];
+#pragma unroll
+      for (int gp = 0; gp < NGRP; ++gp) og[gp] = (f32x4)(0.f);
+      out_small(og, slotA, h2);
+      float oa[MP];
+      out_finish(og, oa);
+      float z[MP], muv[MP], av[MP];
       float llA = 0.f;
 #pragma unroll
-      for (int r = 0; r < RA; ++r) {
-        const int a = unit_of(r, hi);
+      for (int a = 0; a < MP; ++a) {
         const bool ok = valid && (a < m);
         float x = A.act[ok ? (s0 + j) * m + a : 0];
-        av[r] = ok ? x : 0.f;
-        muv[r] = mu[r] * cst[C_OSC * MP + a] + cst[C_OSH * MP + a];
-        z[r] = (av[r] - muv[r]) / cst[C_SG * MP + a];
-        llA = fmaf(-0.5f * z[r], z[r], llA);
+        av[a] = ok ? x : 0.f;
+        muv[a] = (oa[a] + slotA[L.oB3 + a]) * cst[C_OSC * MP + a] + cst[C_OSH * MP + a];
+        z[a] = (av[a] - muv[a]) / cst[C_SG * MP + a];
+        llA = fmaf(-0.5f * z[a], z[a], llA);
       }
-      llA += __shfl_xor(llA, 32);
       llA = llA - sum_lsA - llc;
-      float llB = llA, muB[RA];
+      float llB = llA, muB[MP];
 #pragma unroll
-      for (int r = 0; r < RA; ++r) muB[r] = muv[r];
+      for (int a = 0; a < MP; ++a) muB[a] = muv[a];
       if (MODE == MODE_EVAL || !A.old_is_new) {
         f32x16 g1[MT1], g2[MT2];
         layers12(std::false_type{}, slotB, trs + 2 * NP, trs + 3 * NP, false, g1, g2, t1, t2);
-        f32x16 mo = bias_rows(slotB);
-        out_mfma(mo, slotB, g2);
+#pragma unroll
+        for (int gp = 0; gp < NGRP; ++gp) og[gp] = (f32x4)(0.f);
+        out_small(og, slotB, g2);
+        float ob[MP];
+        out_finish(og, ob);
         llB = 0.f;
 #pragma unroll
-        for (int r = 0; r < RA; ++r) {
-          const int a = unit_of(r, hi);
-          muB[r] = mo[r] * cst[C_OSCB * MP + a] + cst[C_OSHB * MP + a];
-          float zb = (av[r] - muB[r]) / cst[C_SGB * MP + a];
+        for (int a = 0; a < MP; ++a) {
+          muB[a] = (ob[a] + slotB[L.oB3 + a]) * cst[C_OSCB * MP + a] + cst[C_OSHB * MP + a];
+          float zb = (av[a] - muB[a]) / cst[C_SGB * MP + a];
           llB = fmaf(-0.5f * zb, zb, llB);
         }
-        llB += __shfl_xor(llB, 32);
         llB = llB - sum_lsB - llc;
       }
       float advv;
@@ -500,32 +505,36 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         // mean_kl(new, old), gaussian_mlp.py:135-145
         float kl = 0.f;
 #pragma unroll
-        for (int r = 0; r < RA; ++r) {
-          const int a = unit_of(r, hi);
+        for (int a = 0; a < MP; ++a) {
           float so = cst[C_SGB * MP + a], sn = cst[C_SG * MP + a];
-          float Nr = (muB[r] - muv[r]) * (muB[r] - muv[r]) + so * so - sn * sn;
+          float Nr = (muB[a] - muv[a]) * (muB[a] - muv[a]) + so * so - sn * sn;
           float Dr = 2.0f * sn * sn + 1e-8f;
           kl += Nr / Dr + cst[C_LS * MP + a] - cst[C_LSB * MP + a];
         }
-        kl += __shfl_xor(kl, 32);
         if (valid && hi == 0) s_kl += (double)kl;
       } else {
         float w = valid ? advv * LR * A.inv_N : 0.f;
+        float d3a[MP];
+#pragma unroll
+        for (int a = 0; a < MP; ++a) {
+          float sg = cst[C_SG * MP + a];
+          d3a[a] = cst[C_OSC * MP + a] * (w * z[a] / sg);
+        }
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-          const int a = unit_of(r, hi);
-          float sg = cst[C_SG * MP + a];
-          d3r[r] = cst[C_OSC * MP + a] * (w * z[r] / sg);
-          gls[r] += w * (z[r] * z[r] - 1.0f);
+          d3r[r] = hi ? d3a[unit_of(r, 1)] : d3a[unit_of(r, 0)];
+          float zr = hi ? z[unit_of(r, 1)] : z[unit_of(r, 0)];
+          gls[r] += w * (zr * zr - 1.0f);
         }
-        if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0) {
+        if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0 && hi == 0) {
 #pragma unroll
-          for (int r = 0; r < RA; ++r) A.dbg[2048 * 4 + unit_of(r, hi) * 32 + j] = muv[r];
-          if (hi == 0) A.dbg[2048 * 4 + MP * 32 + j] = llA;
+          for (int a = 0; a < MP; ++a) A.dbg[2048 * 4 + a * 32 + j] = muv[a];
+          A.dbg[2048 * 4 + MP * 32 + j] = llA;
         }
       }
     }
 
+    __builtin_amdgcn_sched_barrier(0);
     if (MODE != MODE_EVAL) {
       // ================= backward (shared by VPG and FVP) =================
       // Park h2^T in bufA, h1^T in bufB ([unit][sample]) and d3^T in d3T ([action][sample]).  The deltas

@@ -444,3 +444,29 @@ def test_npg_input_normalization_vs_reference():
     assert rel(step, ref) < 2e-5, rel(step, ref)
     assert abs(agent.last_update["alpha"] - float(c.g["alpha"])) < 2e-5 * float(c.g["alpha"])
     assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < 1e-4 * float(c.g["kl"])
+
+
+def test_hvp_sample_frac_rng_parity():
+    """hvp_sample_frac < 0.99: one with-replacement row sample per Fisher product from NumPy's global RNG
+    (npg_cg.py:65-69); with the same seed the oracle replays the same rows."""
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    c = NpgCase("npg_pointmass_32x32")
+    spec = type("Spec", (), dict(observation_dim=c.n, action_dim=c.m, horizon=1000))
+    pol = MLP(spec, hidden_sizes=c.hidden, seed=1, init_log_std=-0.5)
+    pol.set_param_values(c.theta0)
+    agent = NPG(None, pol, None, normalized_step_size=0.05, hvp_sample_frac=0.5, FIM_invert_args={'iters': 6, 'damping': 1e-4})
+    np.random.seed(11)
+    agent.train_from_paths(c.paths)
+    th = c.theta0.astype(np.float64)
+    a = (c.n, c.m, c.hidden)
+    g = O.vpg(th, th, c.obs, c.act, c.adv_w, *a)
+    np.random.seed(11)
+    N = c.obs.shape[0]
+    def hv(p):
+        idx = np.random.choice(N, size=int(0.5 * N))
+        return O.fvp(th, c.obs[idx], p, *a, damping=1e-4)
+    x = O.cg_solve(hv, g, 6)
+    alpha = np.sqrt(abs(0.05 / (g.dot(x) + 1e-20)))
+    step = pol.get_param_values().astype(np.float64) - c.theta0
+    assert rel(step, alpha * x) < 2e-5

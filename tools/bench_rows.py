@@ -59,6 +59,24 @@ out["K3_eval_ms"] = 1e3 * timeit(lambda: eng.eval_surr_kl(), 10)
 t0 = time.perf_counter()
 out["upload_1M_fp64_to_f32_s"] = timeit(lambda: eng.set_batch(obs.astype(np.float64), act.astype(np.float64), adv), 2)
 
+# end-to-end NPG.train_from_paths on fp64 host paths (process_paths + upload + update + read-back)
+from mjrl_amd.algos.npg_cg import NPG
+from mjrl_amd.algos.trpo import TRPO
+from mjrl_amd.policies.gaussian_mlp import MLP
+for p_, a_ in zip(paths, np.split(adv, 1000)):
+    p_["advantages"] = a_
+pol = MLP(spec, hidden_sizes=(64, 64), seed=1, init_log_std=-0.5)
+agent = NPG(None, pol, None, normalized_step_size=0.05)
+agent.train_from_paths(paths)
+t0 = time.perf_counter(); agent.train_from_paths(paths); torch.cuda.synchronize()
+out["npg_train_from_paths_end_to_end_s"] = time.perf_counter() - t0
+t0 = time.perf_counter(); agent.process_paths(paths); out["process_paths_host_s"] = time.perf_counter() - t0
+tr = TRPO(None, pol, None, kl_dist=0.01)
+tr.train_from_paths(paths)
+t0 = time.perf_counter(); tr.train_from_paths(paths); torch.cuda.synchronize()
+out["trpo_train_from_paths_end_to_end_s"] = time.perf_counter() - t0
+out["trpo_trials"] = tr.last_update["trials"]
+
 # layer-wise path: cfg4 shapes, 200k samples on one GPU
 n, m, hid, N = 376, 17, (256, 256), 200000
 th4 = synth.perturbed_params(synth.init_params(n, m, hid), scale=0.02)
