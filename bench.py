@@ -56,22 +56,39 @@ def initial_params():
 
 def cpu_baseline(theta0, sample_traj):
     """The reference's CPU algorithm (torch-autograd port, oracle/torch_port.py) timed on this
-    box's host cores on a bounded slice of the same workload."""
+    box's host cores on a bounded slice of the same workload.  torch's intra-op thread count is
+    calibrated first on a small slice (many-core hosts are slower at their default of one thread per
+    core on these skinny matrices), so the baseline is the CPU's best showing."""
     import torch
     from oracle import torch_port
     obs, act, adv = synth_shard(0, N_TRAJ // sample_traj)        # first `sample_traj` trajectories
     obs, act = obs.astype(np.float64), act.astype(np.float64)    # the reference holds fp64 rollouts
     adv = (adv - adv.mean()) / (adv.std() + 1e-6)
     kw = dict(cg_iters=CG_ITERS, damping=DAMPING, delta=STEP)
-    torch_port.npg_update(theta0, obs[:20000], act[:20000], adv[:20000], N_OBS, N_ACT, HIDDEN, **kw)   # warm-up
+    default_threads = torch.get_num_threads()
+    cal = {}
+    ncal = 40000
+    for k in sorted({8, 16, 32, 64, default_threads}):
+        if k > default_threads:
+            continue
+        torch.set_num_threads(k)
+        torch_port.npg_update(theta0, obs[:10000], act[:10000], adv[:10000], N_OBS, N_ACT, HIDDEN, **kw)   # warm-up
+        t0 = time.time()
+        torch_port.npg_update(theta0, obs[:ncal], act[:ncal], adv[:ncal], N_OBS, N_ACT, HIDDEN, **kw)
+        cal[k] = time.time() - t0
+    best = min(cal, key=cal.get)
+    torch.set_num_threads(best)
     t0 = time.time()
     torch_port.npg_update(theta0, obs, act, adv, N_OBS, N_ACT, HIDDEN, **kw)
     dt = time.time() - t0
+    torch.set_num_threads(default_threads)
     n = obs.shape[0]
     ups = (n / float(N_TRAJ * T)) / dt                            # linear-in-N extrapolation to 1M
-    return dict(value=ups, unit="updates/s", cores=int(torch.get_num_threads()), kind="port",
+    return dict(value=ups, unit="updates/s", cores=int(best), kind="port",
                 sample="%d-timestep slice (%d traj) of the 1M batch, one NPG update in %.2f s on torch-CPU "
-                       "(autograd double-backward HVP, as the reference), scaled linearly to 1M" % (n, sample_traj, dt),
+                       "(autograd double-backward HVP, as the reference) with %d intra-op threads (best of %s on a "
+                       "%d-sample calibration), scaled linearly to 1M" % (n, sample_traj, dt, best,
+                                                                          {k: round(v, 2) for k, v in cal.items()}, ncal),
                 seconds=dt, nproc=os.cpu_count())
 
 

@@ -428,7 +428,7 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
                           grad_out, scal_out, st) ? fail(MJX_ERR_STATE, "layer-wise surr_vpg failed") : MJX_OK;
   FusedArgs a = make_args(c, c->theta_old);
   if (int rc = dispatch_fused(c, MODE_VPG, a, st)) return rc;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 63) / 64), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
+  hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
                      grad_out, (const float*)nullptr, (const float*)nullptr, c->oS, 0.f);
   hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, c->grid, scal_out);
   HIPCHK(hipGetLastError());
@@ -458,7 +458,7 @@ int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
   FusedArgs a = make_args(c, v);
   if (int rc = dispatch_fused(c, MODE_FVP, a, st)) return rc;
   if (prof) { HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], st)); c->prof_used += 2; }
-  hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 63) / 64), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
+  hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
                      out, c->theta_new, v, c->oS, frac);
   HIPCHK(hipGetLastError());
   return MJX_OK;
