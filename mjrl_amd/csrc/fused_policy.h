@@ -49,6 +49,11 @@ struct FusedArgs {
   int n, m;
 };
 
+#ifdef MJX_PHASE_CLOCK
+#define MJX_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (A.dbg && blockIdx.x == 0 && wave == 0 && lane == 0 && tile == tstride) ((long long*)A.dbg)[k] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MJX_STAMP(k) do {} while (0)
+#endif
 #define MJX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ void wave_sync() {
@@ -84,7 +89,7 @@ struct FusedLayout {
   int oW1, oW2, oW3, oB2, oB3, SLOT;            // weight slot (one per parameter set)
   int oXS, oXT, oD3, oBA, oBB, WAVE;            // per-wave scratch
   int oTR, oCST, oWAVES, TOTAL;
-  static constexpr int NCST = 8;                // osc, osh, sigma, log_std (new) ; osc, osh, sigma, log_std (old)
+  static constexpr int NCST = 9;                // osc, osh, sigma, log_std (new) ; the same for old ; Dk = 2/(2 sigma^2 + 1e-8)
   __host__ __device__ explicit FusedLayout(int n) {
     NP = (n + 1 + 3) & ~3;
     S1 = NP + 2;
@@ -94,8 +99,8 @@ struct FusedLayout {
     oB2 = oW3 + MP * S3;
     oB3 = oB2 + H2;
     SLOT = ((oB3 + MP + 3) / 4) * 4;
-    oXS = 0;                                    // [32][S1]
-    oXT = ((oXS + 32 * S1 + 3) / 4) * 4;        // [NP][ST]
+    oXS = 0;                                    // raw image of the tile: 32*n floats (+ float4 slack)
+    oXT = ((oXS + 32 * n + 4 * 64 + 3) / 4) * 4; // [NP][ST]
     oD3 = oXT + NP * ST;                        // [MP][ST]
     oBA = oD3 + MP * ST;                        // [HM][ST]
     oBB = oBA + HM * ST;                        // [HM][ST]
@@ -117,7 +122,7 @@ struct FlatOff {
   }
 };
 
-template <int H1, int H2, int NT1, int MP, int MODE, bool DBG = false>
+template <int H1, int H2, int NT1, int MP, int MODE, bool DBG = false, int NPC = 0>
 __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   using LT = FusedLayout<H1, H2, NT1, MP>;
   constexpr int MT1 = LT::MT1, MT2 = LT::MT2, S2 = LT::S2, S3 = LT::S3, ST = LT::ST;
@@ -126,7 +131,8 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
   const int n = A.n, m = A.m;
   const LT L(n);
-  const int NP = L.NP, S1 = L.S1;
+  const int NP = NPC ? NPC : L.NP;                // compile-time when the variant is specialised for the obs dim
+  const int S1 = NP + 2;
   const FlatOff fo(n, m, H1, H2);
 
   float* slotA = lds;
@@ -164,13 +170,12 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     trs[3 * NP + idx] = A.trB[n + idx];
   }
   // constant "ones" feature (bias column) of every wave's staging buffers
-  if (lane < 32) xs[lane * S1 + n] = 1.0f;
   if (lane < 32) xT[n * ST + lane] = 1.0f;
   __syncthreads();
 
   // ---------------- per-action constants (LDS, broadcast reads) ----------------
   float* cst = lds + L.oCST;
-  enum { C_OSC = 0, C_OSH = 1, C_SG = 2, C_LS = 3, C_OSCB = 4, C_OSHB = 5, C_SGB = 6, C_LSB = 7 };
+  enum { C_OSC = 0, C_OSH = 1, C_SG = 2, C_LS = 3, C_OSCB = 4, C_OSHB = 5, C_SGB = 6, C_LSB = 7, C_DK = 8 };
   if (tid < MP) {
     const int a = tid;
     const bool ok = a < m;
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     cst[C_OSHB * MP + a] = ok ? A.trB[2 * n + a] : 0.f;
     cst[C_SGB * MP + a] = ok ? expf(lsb) : 1.0f;
     cst[C_LSB * MP + a] = lsb;
+    { float sg = ok ? expf(lsa) : 1.0f; cst[C_DK * MP + a] = 2.0f / (2.0f * sg * sg + 1e-8f); }
   }
   __syncthreads();
 
@@ -232,21 +238,13 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   for (; tile < ntiles; tile += tstride) {
     const int64_t s0 = tile * 32;
     const bool valid = (s0 + j) < A.N;
-    // ---- 0. stage observations (raw) into xs [sample][feature]; rows past the batch end are zeroed so
-    // that their activations stay finite (their cotangents are masked to zero further down).
-    const int nvalid = (int)((A.N - s0 < 32) ? (A.N - s0) : 32);
+    MJX_STAMP(0);
+    // ---- 0. stage the tile's observations: xs is the raw memory image (sample-major, row stride n),
+    // written with the same float4 granules it was fetched in.  Rows past the batch end are masked when read.
 #pragma unroll
     for (int c = 0; c < XL4; ++c) {
       const int e4 = c * 64 + lane;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = 4 * e4 + k;
-        const int sidx = (int)(((float)e + 0.5f) * inv_n);
-        const int f = e - sidx * n;
-        const bool inb = e4 < 8 * n;
-        const float v = (sidx < nvalid) ? xr[c][k] : 0.0f;
-        xs[inb ? sidx * S1 + f : NP] = v;                     // out-of-range lanes hit an unused pad slot
-      }
+      *(f32x4*)&xs[4 * ((e4 < 8 * n) ? e4 : 8 * n + lane)] = xr[c];   // out-of-range lanes hit the slack area
     }
     if (tile + tstride < ntiles) load_x(tile + tstride);
     wave_sync();
@@ -264,27 +262,33 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       for (int mt = 0; mt < MT1; ++mt) { z1[mt] = (f32x16)(0.f); if (TAN) t1[mt] = (f32x16)(0.f); }
       // layer 1: K = features (+ ones column carrying the bias), operands by ds_read_b64
       {
-        f32x2 wc[MT1], vc[MT1], xb;
+        f32x2 wc[MT1], vc[MT1];
         const int f00 = 2 * hi;
-        xb = *(const f32x2*)&xs[j * S1 + f00];
+        // x~[j][f] = (x - shift)/(scale + 1e-8) for f < n (fc_network.py:46); the bias column f == n reads 1, the
+        // pad reads 0; rows past the batch end read 0.  Computed one group ahead, so the divide overlaps the MFMAs.
+        auto xnorm = [&](int f) {
+          const int fc = (f < n) ? f : 0;
+          float v = (xs[j * n + fc] - tsh[fc]) / (tsc[fc] + 1e-8f);
+          return (f < n) ? (valid ? v : 0.0f) : (f == n ? 1.0f : 0.0f);
+        };
+        float xb0 = xnorm(f00), xb1 = xnorm(f00 + 1);
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt) {
           wc[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f00];
           if (TAN) vc[mt] = *(const f32x2*)&slotB[L.oW1 + (32 * mt + j) * S1 + f00];
         }
-        for (int q = 0; q < NP / 4; ++q) {
+#pragma unroll(NPC ? NPC / 4 : 1)
+        for (int q = 0; q < (NPC ? NPC / 4 : NP / 4); ++q) {
           const int f0 = 4 * q + 2 * hi;
           const int f1 = (q + 1 < NP / 4) ? f0 + 4 : f0;        // next group (clamped on the last trip)
-          f32x2 wn[MT1], vn[MT1], xn;
-          xn = *(const f32x2*)&xs[j * S1 + f1];
+          f32x2 wn[MT1], vn[MT1];
+          const float xn0 = xnorm(f1), xn1 = xnorm(f1 + 1);
 #pragma unroll
           for (int mt = 0; mt < MT1; ++mt) {
             wn[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f1];
             if (TAN) vn[mt] = *(const f32x2*)&slotB[L.oW1 + (32 * mt + j) * S1 + f1];
           }
-          // x~ = (x - shift)/(scale + 1e-8); the ones column (f == n) and the zero pad pass through
-          float x0 = (f0 < n) ? (xb.x - tsh[f0]) / (tsc[f0] + 1e-8f) : xb.x;
-          float x1 = (f0 + 1 < n) ? (xb.y - tsh[f0 + 1]) / (tsc[f0 + 1] + 1e-8f) : xb.y;
+          const float x0 = xb0, x1 = xb1;
           if (writeT) { xT[f0 * ST + j] = x0; xT[(f0 + 1) * ST + j] = x1; }
 #pragma unroll
           for (int mt = 0; mt < MT1; ++mt) {
@@ -296,11 +300,12 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
             z1[mt] = MJX_MFMA(wc[mt].y, x1, z1[mt]);
             if (TAN) t1[mt] = MJX_MFMA(vc[mt].y, x1, t1[mt]);
           }
-          xb = xn;
+          xb0 = xn0; xb1 = xn1;
 #pragma unroll
           for (int mt = 0; mt < MT1; ++mt) { wc[mt] = wn[mt]; if (TAN) vc[mt] = vn[mt]; }
         }
       }
+      MJX_STAMP(2);
 #pragma unroll
       for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
@@ -308,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
           h1[mt][r] = fast_tanh(z1[mt][r]);
           if (TAN) t1[mt][r] *= fmaf(-h1[mt][r], h1[mt][r], 1.0f);
         }
+      MJX_STAMP(3);
       // layer 2: accumulators start at the bias (b2 / c2), K = h1 units chained from registers
       f32x16 z2[MT2];
 #pragma unroll
@@ -346,8 +352,10 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
           for (int mt = 0; mt < MT2; ++mt) wc[mt] = wn[mt];
         }
       }
+      MJX_STAMP(4);
       if (TAN) {
-        // pass B: t2 += V2 h1 ; independent of z2, so tanh(z2) below can issue in its shadow
+        // pass B: t2 += V2 h1.  z2 is final after pass A, so tanh(z2), and the [unit][sample] copies of h2 / h1
+        // the backward pass needs (bufA / bufB), are issued step by step in the shadow of these MFMAs.
         f32x4 vc[MT2], vn[MT2];
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) vc[mt] = *(const f32x4*)&slotB[L.oW2 + (32 * mt + j) * S2 + 4 * hi];
@@ -363,19 +371,31 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int mt = 0; mt < MT2; ++mt) t2[mt] = MJX_MFMA(vc[mt][t], h1[kb][4 * q + t], t2[mt]);
+          // this step's share of the VALU / LDS-store work: 16*MT2/NS registers of z2 and 16*MT1/NS of h1
+          constexpr int R2 = 16 * MT2 / NS, R1 = 16 * MT1 / NS;
+#pragma unroll
+          for (int e = 0; e < R2; ++e) {
+            const int idx = st * R2 + e, mt = idx >> 4, r = idx & 15;
+            h2[mt][r] = fast_tanh(z2[mt][r]);
+            bufA[(32 * mt + unit_of(r, hi)) * ST + j] = h2[mt][r];
+          }
+#pragma unroll
+          for (int e = 0; e < R1; ++e) {
+            const int idx = st * R1 + e, mt = idx >> 4, r = idx & 15;
+            bufB[(32 * mt + unit_of(r, hi)) * ST + j] = h1[mt][r];
+          }
 #pragma unroll
           for (int mt = 0; mt < MT2; ++mt) vc[mt] = vn[mt];
         }
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h2[mt][r] = fast_tanh(z2[mt][r]);
-      if (TAN) {
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) t2[mt][r] *= fmaf(-h2[mt][r], h2[mt][r], 1.0f);
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h2[mt][r] = fast_tanh(z2[mt][r]);
       }
     };
 
@@ -386,18 +406,25 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     // sample over the 32 units its half owns.  8 cycles per instruction instead of padding M to 32.
     constexpr int NGRP = MP / 4;
     auto out_small = [&](f32x4 (&og)[NGRP], const float* slot, const f32x16 (&v)[MT2]) {
+      constexpr int NS4 = MT2 * 4;
+      const float* wbase = &slot[L.oW3 + (lane & 3) * S3 + 4 * hi];
+      f32x4 wc[NGRP], wn[NGRP];
 #pragma unroll
-      for (int mt = 0; mt < MT2; ++mt)
+      for (int gp = 0; gp < NGRP; ++gp) wc[gp] = *(const f32x4*)(wbase + 4 * gp * S3);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 w[NGRP];
+      for (int st = 0; st < NS4; ++st) {
+        const int mt = st >> 2, q = st & 3;
+        if (st + 1 < NS4) {
 #pragma unroll
-          for (int gp = 0; gp < NGRP; ++gp) w[gp] = *(const f32x4*)&slot[L.oW3 + (4 * gp + (lane & 3)) * S3 + 32 * mt + 8 * q + 4 * hi];
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int gp = 0; gp < NGRP; ++gp) og[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[gp][t], v[mt][4 * q + t], og[gp], 0, 0, 0);
+          for (int gp = 0; gp < NGRP; ++gp) wn[gp] = *(const f32x4*)(wbase + 4 * gp * S3 + 32 * ((st + 1) >> 2) + 8 * ((st + 1) & 3));
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int gp = 0; gp < NGRP; ++gp) og[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[gp][t], v[mt][4 * q + t], og[gp], 0, 0, 0);
+#pragma unroll
+        for (int gp = 0; gp < NGRP; ++gp) wc[gp] = wn[gp];
+      }
     };
     // both lane halves end up with the full sums for all MP actions
     auto out_finish = [&](f32x4 (&og)[NGRP], float (&o)[MP]) {
@@ -407,11 +434,13 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         for (int r = 0; r < 4; ++r) { float p = og[gp][r]; o[4 * gp + r] = p + __shfl_xor(p, 32); }
     };
 
+    MJX_STAMP(1);
     f32x16 h1[MT1], h2[MT2];
     f32x16 t1[MT1], t2[MT2];                        // tangent activations (FVP only)
     if (MODE == MODE_FVP) layers12(std::true_type{}, slotA, trs, trs + NP, true, h1, h2, t1, t2);
     else layers12(std::false_type{}, slotA, trs, trs + NP, MODE != MODE_EVAL, h1, h2, t1, t2);
 
+    MJX_STAMP(6);
     float d3r[RA];                                  // cotangent on the pre-scale output, rows a = unit_of(r, hi)
     if (MODE == MODE_FVP) {
       f32x4 og[NGRP];
@@ -419,6 +448,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       for (int gp = 0; gp < NGRP; ++gp) og[gp] = (f32x4)(0.f);
       out_small(og, slotB, h2);                     // V3 h2
       out_small(og, slotA, t2);                     // + W3 t2
+      MJX_STAMP(7);
       float md[MP];
       out_finish(og, md);
       if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0) {
@@ -441,9 +471,9 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       float d3a[MP];
 #pragma unroll
       for (int a = 0; a < MP; ++a) {
-        float osc = cst[C_OSC * MP + a], sg = cst[C_SG * MP + a];
+        float osc = cst[C_OSC * MP + a];
         float mudot = osc * (md[a] + slotB[L.oB3 + a]);             // + c3
-        float Dk = 2.0f / (2.0f * sg * sg + 1e-8f);
+        float Dk = cst[C_DK * MP + a];
         float dmu = valid ? Dk * mudot * A.inv_N : 0.f;
         d3a[a] = osc * dmu;
         if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0 && hi == 0) A.dbg[2048 * 4 + a * 32 + j] = mudot;
@@ -552,6 +582,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) bufB[(32 * mt + unit_of(r, hi)) * ST + j] = h1[mt][r];
+      MJX_STAMP(8);
       // delta2 in both layouts: K = actions, the W3 column fragment serves as A (-> lane = sample) and as B (-> lane = unit)
       f32x16 dl2s[MT2], dl2u[MT2];
 #pragma unroll
@@ -570,6 +601,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dl2s[mt][r] *= fmaf(-h2[mt][r], h2[mt][r], 1.0f);
       wave_sync();
+      MJX_STAMP(9);
       // gW3[a][k] += sum_s d3[s][a] * h2[s][k]      (operands prefetched one group ahead)
       {
         const float* arow = &d3T[(j < MP ? j : 0) * ST + 4 * hi];
@@ -613,6 +645,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         for (int r = 0; r < 16; ++r) sacc += dl2u[nt][r];
         sb2[nt] += sacc + __shfl_xor(sacc, 32);
       }
+      MJX_STAMP(10);
       // gW2[u2][u1] += sum_s delta2[s][u2] * h1[s][u1]; delta1u = (delta2 W2)(1 - h1^2), lane = h1 unit.
       // Both walk h1^T (bufB) group by group, so the (1 - h1^2) factors ride on the gW2 operand fetches.
       f32x16 dl1u[MT1];
@@ -654,6 +687,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      MJX_STAMP(11);
       {
         f32x4 bc[MT1], bn[MT1];
 #pragma unroll
@@ -689,6 +723,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) g[2048 + (32 * nt + j) * 32 + unit_of(r, hi)] = dl1u[nt][r];
       }
+      MJX_STAMP(12);
       // gW1a[u1][f] += sum_s delta1[s][u1] * x~a[s][f]   (column n = bias gradient); A from registers
       {
         f32x4 bc[NT1], bn[NT1];
@@ -713,6 +748,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         }
       }
     }
+    MJX_STAMP(13);
     wave_sync();                                  // everything read before the next tile's staging
   }
 
