@@ -8,10 +8,11 @@ same constructor, same flat parameter order, same ``get_action`` RNG stream, sam
   affine transforms), so the object pickles / deep-copies / forks freely
   (mjrl/utils/train_agent.py:83,102,129-131; mjrl/samplers/core.py:196) and ``get_action``
   never touches HIP;
-* the batch operators (likelihoods, surrogate, gradient, Fisher-vector products) are not
-  evaluated here -- agents drive them on the GPU through ``mjrl_amd.engine``.  A torch-CPU
-  mirror (``model`` / ``trainable_params`` / ``new_dist_info`` ...) exists for the callers
-  that optimise the policy with torch optimisers (behavior_cloning.py:42, ppo_clip.py:46).
+* the batch operators (likelihoods, surrogate, gradient, Fisher-vector products) of the NPG /
+  TRPO / DAPG agents are not evaluated here -- the agents drive them on the GPU through
+  ``mjrl_amd.engine``.  A torch-CPU mirror (``model`` / ``trainable_params`` / ``new_dist_info``
+  ...) aliasing the same memory exists for callers that optimise the policy with torch
+  optimisers (behavior_cloning.py:42, ppo_clip.py:46).
 """
 import numpy as np
 
@@ -49,19 +50,27 @@ class _NetView:
     def _params(self):
         return self._p._new if self._which == "new" else self._p._old
 
-    # fc_network.py:39-52 (fp32, NumPy)
+    # fc_network.py:39-52
     def forward(self, x):
-        is_torch = hasattr(x, "detach")
-        xin = np.asarray(x.detach().cpu().numpy() if is_torch else x, np.float32)
-        out = (xin - np.asarray(self.in_shift, np.float32)) / (np.asarray(self.in_scale, np.float32) + np.float32(1e-8))
+        """NumPy in -> NumPy out (fp32; what get_action uses: no torch, fork-safe).
+        torch in -> torch out, differentiable w.r.t. ``policy.trainable_params`` for the new model
+        (what BC / PPO optimise through, behavior_cloning.py:104, ppo_clip.py:58-102)."""
+        if hasattr(x, "detach"):
+            import torch
+            ps = self._p.trainable_params if self._which == "new" else self._p.old_params
+            out = (x.float() - torch.from_numpy(self.in_shift)) / (torch.from_numpy(self.in_scale) + 1e-8)
+            nl = (len(ps) - 1) // 2
+            for i in range(nl):
+                out = torch.nn.functional.linear(out, ps[2 * i], ps[2 * i + 1])
+                if i < nl - 1:
+                    out = torch.tanh(out)
+            return out * torch.from_numpy(self.out_scale) + torch.from_numpy(self.out_shift)
+        xin = np.asarray(x, np.float32)
+        out = (xin - self.in_shift) / (self.in_scale + np.float32(1e-8))
         Ws, bs = self._p._unflatten(self._params())
         for W, b in zip(Ws[:-1], bs[:-1]):
             out = np.tanh(out @ W.T + b)
-        out = (out @ Ws[-1].T + bs[-1]) * np.asarray(self.out_scale, np.float32) + np.asarray(self.out_shift, np.float32)
-        if is_torch:
-            import torch
-            return torch.from_numpy(np.ascontiguousarray(out))
-        return out
+        return (out @ Ws[-1].T + bs[-1]) * self.out_scale + self.out_shift
 
     __call__ = forward
 
@@ -93,8 +102,9 @@ class MLP:
         _ = [torch.nn.Linear(sizes[i], sizes[i + 1]) for i in range(len(sizes) - 1)]     # old_model's draws
         _ = torch.randn(self.n)                                                          # obs_var's draw
 
-        self._new = np.concatenate(flat).astype(np.float32)
+        self._new = np.ascontiguousarray(np.concatenate(flat), dtype=np.float32)
         self._old = self._new.copy()
+        self._tp = self._op = None
         self.param_shapes = [s for i in range(len(sizes) - 1) for s in ((sizes[i + 1], sizes[i]), (sizes[i + 1],))] + [(self.m,)]
         self.param_sizes = [int(np.prod(s)) for s in self.param_shapes]
         self.d = int(np.sum(self.param_sizes))
@@ -111,13 +121,41 @@ class MLP:
             bs.append(theta[k:k + sb]); k += sb
         return Ws, bs
 
+    # ------------------------------------------------------------------ torch mirror (shared memory)
+    def _torch_views(self, flat, grad):
+        import torch
+        out, k = [], 0
+        for shape, size in zip(self.param_shapes, self.param_sizes):
+            t = torch.from_numpy(flat[k:k + size].reshape(shape))      # a view: optimiser steps land in the NumPy store
+            out.append(t.requires_grad_(grad)); k += size
+        return out
+
+    @property
+    def trainable_params(self):
+        """list of torch leaves [W1, b1, ..., log_std] aliasing the NumPy parameter store
+        (gaussian_mlp.py:38; behavior_cloning.py:42 and ppo_clip.py:46 hand it to torch.optim.Adam)."""
+        if self.__dict__.get("_tp") is None:
+            self._tp = self._torch_views(self._new, True)
+        return self._tp
+
+    @property
+    def old_params(self):
+        if self.__dict__.get("_op") is None:
+            self._op = self._torch_views(self._old, False)
+        return self._op
+
     @property
     def log_std(self):
-        return self._new[-self.m:]
+        return self.trainable_params[-1]
 
     @property
     def old_log_std(self):
-        return self._old[-self.m:]
+        return self.old_params[-1]
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_tp", None); state.pop("_op", None)       # rebuilt lazily; the NumPy store is the state
+        return state
 
     def get_param_values(self):
         return self._new.copy()
@@ -126,16 +164,17 @@ class MLP:
         return self._old.copy()
 
     def set_param_values(self, new_params, set_new=True, set_old=True):
-        """gaussian_mlp.py:65-87 (float32 cast, log_std clamped at min_log_std)."""
+        """gaussian_mlp.py:65-87 (float32 cast, log_std clamped at min_log_std); written in place so
+        the torch views handed to optimisers stay valid."""
         vals = np.asarray(new_params, dtype=np.float32).ravel()
         assert vals.size == self.d
         if set_new:
-            self._new = vals.copy()
-            self._new[-self.m:] = np.maximum(self._new[-self.m:], np.float32(self.min_log_std))
+            self._new[:] = vals
+            np.maximum(self._new[-self.m:], np.float32(self.min_log_std), out=self._new[-self.m:])
             self.log_std_val = np.float64(self._new[-self.m:].copy())
         if set_old:
-            self._old = vals.copy()
-            self._old[-self.m:] = np.maximum(self._old[-self.m:], np.float32(self.min_log_std))
+            self._old[:] = vals
+            np.maximum(self._old[-self.m:], np.float32(self.min_log_std), out=self._old[-self.m:])
 
     def old_equals_new(self):
         """True when both parameter copies and both transform sets describe the same function
@@ -145,27 +184,30 @@ class MLP:
 
     # ------------------------------------------------------------------ acting (host, fork-safe)
     def get_action(self, observation):
-        """gaussian_mlp.py:91-97: fp32 mean + exp(log_std) * np.random.randn(m)."""
+        """gaussian_mlp.py:91-97: fp32 mean + exp(log_std) * np.random.randn(m).  NumPy only."""
         o = np.float32(observation.reshape(1, -1))
         mean = self.model.forward(o).ravel()
         noise = np.exp(self.log_std_val) * np.random.randn(self.m)
         action = mean + noise
         return [action, {'mean': mean, 'log_std': self.log_std_val, 'evaluation': mean}]
 
-    # ------------------------------------------------------------------ small-batch host operators
+    # ------------------------------------------------------------------ torch-valued operators (reference API)
+    # These return torch tensors like the reference's (gaussian_mlp.py:99-145) and are differentiable
+    # w.r.t. trainable_params: they serve BC / PPO and any caller written against mjrl.  The NPG / TRPO /
+    # DAPG agents of this package never call them -- their batch math runs in libmjx on the GPU.
     def mean_LL(self, observations, actions, model=None, log_std=None):
-        """gaussian_mlp.py:99-115 on the host (NumPy fp32) -- for small batches / tests;
-        the training path evaluates these on the GPU."""
+        import torch
         model = self.model if model is None else model
         log_std = self.log_std if log_std is None else log_std
-        mean = model.forward(np.asarray(observations, np.float32))
-        ls = np.asarray(log_std, np.float32)
-        zs = (np.asarray(actions, np.float32) - mean) / np.exp(ls)
-        LL = -0.5 * np.sum(zs ** 2, axis=1) - np.sum(ls) - np.float32(0.5 * self.m * LOG_2PI)
+        obs_var = observations if isinstance(observations, torch.Tensor) else torch.from_numpy(np.asarray(observations)).float()
+        act_var = actions if isinstance(actions, torch.Tensor) else torch.from_numpy(np.asarray(actions)).float()
+        mean = model(obs_var)
+        zs = (act_var - mean) / torch.exp(log_std)
+        LL = -0.5 * torch.sum(zs ** 2, dim=1) - torch.sum(log_std) - 0.5 * self.m * LOG_2PI
         return mean, LL
 
     def log_likelihood(self, observations, actions, model=None, log_std=None):
-        return self.mean_LL(observations, actions, model, log_std)[1]
+        return self.mean_LL(observations, actions, model, log_std)[1].data.numpy()
 
     def old_dist_info(self, observations, actions):
         mean, LL = self.mean_LL(observations, actions, self.old_model, self.old_log_std)
@@ -176,14 +218,16 @@ class MLP:
         return [LL, mean, self.log_std]
 
     def likelihood_ratio(self, new_dist_info, old_dist_info):
-        return np.exp(new_dist_info[0] - old_dist_info[0])
+        import torch
+        return torch.exp(new_dist_info[0] - old_dist_info[0])
 
     def mean_kl(self, new_dist_info, old_dist_info):
         """gaussian_mlp.py:135-145"""
-        old_std, new_std = np.exp(old_dist_info[2]), np.exp(new_dist_info[2])
+        import torch
+        old_std, new_std = torch.exp(old_dist_info[2]), torch.exp(new_dist_info[2])
         Nr = (old_dist_info[1] - new_dist_info[1]) ** 2 + old_std ** 2 - new_std ** 2
         Dr = 2 * new_std ** 2 + 1e-8
-        return np.mean(np.sum(Nr / Dr + new_dist_info[2] - old_dist_info[2], axis=1))
+        return torch.mean(torch.sum(Nr / Dr + new_dist_info[2] - old_dist_info[2], dim=1))
 
 
 class LinearPolicy(MLP):

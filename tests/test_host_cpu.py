@@ -82,7 +82,7 @@ def test_policy_surface_and_lifecycle():
     ll = p.log_likelihood(obs, act)
     ll_o, _ = O.log_likelihood(p.get_param_values().astype(np.float64), obs, act, 17, 6, (64, 64))
     assert np.allclose(ll, ll_o, rtol=1e-5, atol=1e-5)
-    assert abs(p.mean_kl(p.new_dist_info(obs, act), p.old_dist_info(obs, act))) < 1e-6
+    assert abs(float(p.mean_kl(p.new_dist_info(obs, act), p.old_dist_info(obs, act)))) < 1e-6
 
 
 def test_host_cg_matches_oracle():
