@@ -1,0 +1,364 @@
+// mlp_fit.h -- persistent single-workgroup minibatch-Adam trainer for the MLP value baseline
+// (d_in -> H -> H -> 1, ReLU, H = 128, batch 64).
+//
+// Minibatch SGD is a strictly sequential chain of ~15k tiny steps per epoch per million samples
+// (mjrl/utils/optimize_model.py:7-36, mlp_baseline.py:61-95): launched as kernels it is pure launch
+// latency (14 launches / step).  Here ONE workgroup (4 waves, one per SIMD of a CU) runs the whole fit:
+// weights live in LDS for the entire run, the Adam moments stream through L2, every step is
+//   gather 64 rows -> forward -> MSE gradient -> backward -> Adam, in two 32-sample halves,
+// with the GEMMs on v_mfma_f32_32x32x2_f32 in the same chained / operand-swapped formulation as the policy
+// kernels (fused_policy.h): wave w owns units 32w..32w+31 of both hidden layers, activations are exchanged
+// between waves through [unit][sample] LDS tiles, weight-gradient accumulators stay in registers until the
+// owning thread applies Adam to "its" weights.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fused_policy.h"
+
+namespace mjx {
+
+struct MlpFitArgs {
+  const float* feat;       // (N, d_in) fp32
+  const float* y;          // (N)
+  const int32_t* perm;     // epochs * N row indices
+  int64_t N;
+  int d_in, epochs;
+  int64_t steps;           // minibatch steps per epoch = N / 64 - 1
+  float* params;           // flat [W1 (H x d_in), b1, W2 (H x H), b2, W3 (H), b3], updated in place
+  float* m;                // Adam first moment  (same layout)
+  float* v;                // Adam second moment
+  int64_t step0;           // Adam steps taken before this call
+  float lr, wd;
+  double* epoch_loss;      // [epochs] sum over steps of the minibatch MSE
+};
+
+template <int H>
+struct MlpFitLayout {
+  static constexpr int ST = 36, S2 = H + 4;
+  int K1, S1;
+  int oW1, oW2, oW3, oB2, oXS, oXT, oH1, oH2, oD2, oY, oPART, oDY, TOTAL;
+  __host__ __device__ explicit MlpFitLayout(int d_in) {
+    K1 = (d_in + 1 + 3) & ~3; S1 = K1 + 2;
+    oW1 = 0; oW2 = oW1 + H * S1; oW3 = oW2 + H * S2; oB2 = oW3 + H;
+    oXS = ((oB2 + H + 4 + 3) / 4) * 4;            // [32][S1]  (b3 sits at oB2 + H)
+    oXT = ((oXS + 32 * S1 + 3) / 4) * 4;          // [K1][ST]
+    oH1 = oXT + K1 * ST;                          // [H][ST]
+    oH2 = oH1 + H * ST;
+    oD2 = oH2 + H * ST;
+    oY = oD2 + H * ST;                            // [32]
+    oPART = oY + 32;                              // [4][32]
+    oDY = oPART + 128;                            // [32]
+    TOTAL = oDY + 32;
+  }
+  __host__ __device__ size_t bytes() const { return (size_t)TOTAL * 4; }
+};
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
+  static_assert(H == 128, "wave w owns unit tile w: 4 waves x 32 units");
+  using LT = MlpFitLayout<H>;
+  constexpr int ST = LT::ST, S2 = LT::S2, NT = H / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const LT L(A.d_in);
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+  const int d_in = A.d_in, K1 = L.K1, S1 = L.S1;
+  float* sW1 = lds + L.oW1; float* sW2 = lds + L.oW2; float* sW3 = lds + L.oW3; float* sB2 = lds + L.oB2;
+  float* sB3 = sB2 + H;
+  float* xs = lds + L.oXS; float* xT = lds + L.oXT; float* h1T = lds + L.oH1; float* h2T = lds + L.oH2; float* d2T = lds + L.oD2;
+  float* sY = lds + L.oY; float* sPart = lds + L.oPART; float* sDY = lds + L.oDY;
+  const int64_t oW1g = 0, oB1g = (int64_t)H * d_in, oW2g = oB1g + H, oB2g = oW2g + (int64_t)H * H, oW3g = oB2g + H, oB3g = oW3g + H;
+
+  // ---- load parameters into LDS (b1 rides as the "ones" column of W1)
+  for (int i = tid; i < L.TOTAL; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < H * (d_in + 1); i += 256) {
+    int u = i / (d_in + 1), f = i - u * (d_in + 1);
+    sW1[u * S1 + f] = (f < d_in) ? A.params[oW1g + (int64_t)u * d_in + f] : A.params[oB1g + u];
+  }
+  for (int i = tid; i < H * H; i += 256) sW2[(i / H) * S2 + (i % H)] = A.params[oW2g + i];
+  for (int i = tid; i < H; i += 256) { sW3[i] = A.params[oW3g + i]; sB2[i] = A.params[oB2g + i]; }
+  if (tid == 0) sB3[0] = A.params[oB3g];
+  if (tid < 32) { xs[tid * S1 + d_in] = 1.0f; xT[d_in * ST + tid] = 1.0f; }
+  __syncthreads();
+
+  const float b1c = 0.9f, b2c = 0.999f, eps = 1e-8f;
+  double pw1 = pow((double)b1c, (double)A.step0), pw2 = pow((double)b2c, (double)A.step0);
+  constexpr int GL = (32 * 32 + 255) / 256;         // gather elements per thread (d_in <= 31)
+  float gx[GL];
+  float gy = 0.f;
+
+  auto gather_load = [&](int ep, int64_t mb, int hb) {
+    const int32_t* idx = A.perm + (int64_t)ep * A.N + mb * 64 + 32 * hb;
+#pragma unroll
+    for (int c = 0; c < GL; ++c) {
+      int e = c * 256 + tid, s = e / d_in, f = e - s * d_in;
+      bool ok = e < 32 * d_in;
+      gx[c] = A.feat[ok ? (int64_t)idx[s] * d_in + f : 0];
+    }
+    gy = A.y[idx[tid & 31]];
+  };
+  auto gather_store = [&]() {
+#pragma unroll
+    for (int c = 0; c < GL; ++c) {
+      int e = c * 256 + tid, s = e / d_in, f = e - s * d_in;
+      if (e < 32 * d_in) { xs[s * S1 + f] = gx[c]; xT[f * ST + s] = gx[c]; }
+    }
+    if (tid < 32) sY[tid] = gy;
+  };
+
+  for (int ep = 0; ep < A.epochs; ++ep) {
+    double ep_loss = 0.0;
+    if (A.steps > 0) gather_load(ep, 0, 0);
+#pragma unroll 1
+    for (int64_t mb = 0; mb < A.steps; ++mb) {
+      f32x16 gW2[NT], gW1;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) gW2[nt] = (f32x16)(0.f);
+      gW1 = (f32x16)(0.f);
+      float gb2 = 0.f, gw3 = 0.f, gb3 = 0.f;
+#pragma unroll 1
+      for (int hb = 0; hb < 2; ++hb) {
+        gather_store();
+        __syncthreads();
+        // prefetch the next half's rows while this half computes
+        if (hb == 0) gather_load(ep, mb, 1);
+        else if (mb + 1 < A.steps) gather_load(ep, mb + 1, 0);
+        // ---- layer 1: z1[unit 32w+., sample] = W1a x~a ; h1 = relu
+        f32x16 z1 = (f32x16)(0.f);
+        for (int q = 0; q < K1 / 4; ++q) {
+          const int f0 = 4 * q + 2 * hi;
+          f32x2 a = *(const f32x2*)&sW1[(32 * w + j) * S1 + f0];
+          f32x2 b = *(const f32x2*)&xs[j * S1 + f0];
+          z1 = MJX_MFMA(a.x, b.x, z1);
+          z1 = MJX_MFMA(a.y, b.y, z1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1T[(32 * w + unit_of(r, hi)) * ST + j] = fmaxf(z1[r], 0.f);
+        __syncthreads();
+        // ---- layer 2: K = all 128 h1 units (B operand from the shared h1^T tile)
+        f32x16 z2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 b = *(const f32x4*)&sB2[32 * w + 8 * q + 4 * hi];
+          z2[4 * q] = b.x; z2[4 * q + 1] = b.y; z2[4 * q + 2] = b.z; z2[4 * q + 3] = b.w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          f32x4 ac = *(const f32x4*)&sW2[(32 * w + j) * S2 + 4 * hi], an;
+          float bc[4], bn[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bc[t] = h1T[(4 * hi + t) * ST + j];
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            if (g + 1 < 16) {
+              const int k1 = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3) + 4 * hi;
+              an = *(const f32x4*)&sW2[(32 * w + j) * S2 + k1];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) bn[t] = h1T[(k1 + t) * ST + j];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) z2 = MJX_MFMA(ac[t], bc[t], z2);
+            ac = an;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bc[t] = bn[t];
+          }
+          // in-order single wave: keep group g+1's five LDS fetches ahead of group g's four MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            if (g + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float hv = fmaxf(z2[r], 0.f);
+          z2[r] = hv;
+          h2T[(32 * w + unit_of(r, hi)) * ST + j] = hv;
+          part = fmaf(sW3[32 * w + unit_of(r, hi)], hv, part);
+        }
+        part += __shfl_xor(part, 32);
+        if (hi == 0) sPart[w * 32 + j] = part;
+        __syncthreads();
+        // ---- output + MSE gradient (every wave redundantly, lane j = sample)
+        const float yhat = (sPart[j] + sPart[32 + j]) + (sPart[64 + j] + sPart[96 + j]) + sB3[0];
+        const float err = yhat - sY[j];
+        const float dy = 2.0f * err / 64.0f;              // MSELoss(mean) over the 64-row minibatch
+        if (w == 0 && hi == 0) {
+          sDY[j] = dy;
+          float e2 = err * err;
+#pragma unroll
+          for (int off = 1; off < 32; off <<= 1) e2 += __shfl_xor(e2, off);
+          if (j == 0) ep_loss += (double)e2 / 64.0;
+        }
+        // delta2 (lane = sample) -> d2T [unit][sample]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int u = 32 * w + unit_of(r, hi);
+          d2T[u * ST + j] = (z2[r] > 0.f) ? sW3[u] * dy : 0.f;
+        }
+        __syncthreads();
+        // ---- grad W3 / b3 (thread = unit), grad b2, delta2 in lane = unit layout straight from d2T
+        if (tid < H) {
+          float a = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            f32x4 hv = *(const f32x4*)&h2T[tid * ST + 4 * q];
+            f32x4 dv = *(const f32x4*)&sDY[4 * q];
+            a += hv.x * dv.x + hv.y * dv.y + hv.z * dv.z + hv.w * dv.w;
+          }
+          gw3 += a;
+        }
+        if (tid == 0) { float a = 0.f; for (int s = 0; s < 32; ++s) a += sDY[s]; gb3 += a; }
+        f32x16 d2u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 t4 = *(const f32x4*)&d2T[(32 * w + j) * ST + 8 * q + 4 * hi];
+          d2u[4 * q] = t4.x; d2u[4 * q + 1] = t4.y; d2u[4 * q + 2] = t4.z; d2u[4 * q + 3] = t4.w;
+        }
+        {
+          float s2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s2 += d2u[r];
+          gb2 += s2 + __shfl_xor(s2, 32);
+        }
+        // grad W2 rows of this wave: A = delta2u (registers), B = h1^T tiles
+        {
+          f32x4 bc[NT], bn[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bc[nt] = *(const f32x4*)&h1T[(32 * nt + j) * ST + 4 * hi];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (q + 1 < 4) {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const f32x4*)&h1T[(32 * nt + j) * ST + 8 * (q + 1) + 4 * hi];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) gW2[nt] = MJX_MFMA(d2u[4 * q + t], bc[nt][t], gW2[nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bc[nt] = bn[nt];
+          }
+        }
+        // delta1 (lane = h1 unit of this wave's tile): A = delta2 [sample][k] from d2T, B = W2[k][unit]
+        f32x16 d1u = (f32x16)(0.f);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          float ac[4], an[4], bc[4], bn[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { ac[t] = d2T[(4 * hi + t) * ST + j]; bc[t] = sW2[(4 * hi + t) * S2 + 32 * w + j]; }
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            if (g + 1 < 16) {
+              const int k1 = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3) + 4 * hi;
+#pragma unroll
+              for (int t = 0; t < 4; ++t) { an[t] = d2T[(k1 + t) * ST + j]; bn[t] = sW2[(k1 + t) * S2 + 32 * w + j]; }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d1u = MJX_MFMA(ac[t], bc[t], d1u);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { ac[t] = an[t]; bc[t] = bn[t]; }
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            if (g + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                       // relu'(z1) mask from h1^T (same layout)
+          f32x4 hv = *(const f32x4*)&h1T[(32 * w + j) * ST + 8 * q + 4 * hi];
+          d1u[4 * q] = hv.x > 0.f ? d1u[4 * q] : 0.f; d1u[4 * q + 1] = hv.y > 0.f ? d1u[4 * q + 1] : 0.f;
+          d1u[4 * q + 2] = hv.z > 0.f ? d1u[4 * q + 2] : 0.f; d1u[4 * q + 3] = hv.w > 0.f ? d1u[4 * q + 3] : 0.f;
+        }
+        // grad W1a rows of this wave (column d_in = grad b1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 b4 = *(const f32x4*)&xT[(j < K1 ? j : 0) * ST + 8 * q + 4 * hi];
+          if (j >= K1) b4 = (f32x4)(0.f);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) gW1 = MJX_MFMA(d1u[4 * q + t], b4[t], gW1);
+        }
+        __syncthreads();                                    // tiles are rewritten by the next half
+      }
+      // ---- Adam (torch.optim.Adam: L2 weight decay folded into the gradient, bias-corrected)
+      pw1 *= (double)b1c; pw2 *= (double)b2c;
+      const float bc1 = (float)(1.0 - pw1), bc2s = (float)sqrt(1.0 - pw2);
+      const float step_size = A.lr / bc1;
+      auto adam_math = [&](float p, float g, float& mi, float& vi) {
+        g += A.wd * p;
+        mi = mi + (g - mi) * (1.0f - b1c);
+        vi = vi * b2c + g * g * (1.0f - b2c);
+        return p - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+      };
+      auto adam = [&](float* p_lds, int64_t gi, float g) {
+        float mi = A.m[gi], vi = A.v[gi];
+        *p_lds = adam_math(*p_lds, g, mi, vi);
+        A.m[gi] = mi; A.v[gi] = vi;
+      };
+      // the owned W2 block, 16 elements at a time: issue the 32 moment loads together, then update, then store.
+      // Element (nt, r) sits at a compile-time offset from one per-lane base (row 32w + 4hi, column j).
+      {
+        const int64_t gbase = oW2g + (int64_t)(32 * w + 4 * hi) * H + j;
+        float* __restrict__ mW = A.m + gbase;
+        float* __restrict__ vW = A.v + gbase;
+        float* pW = sW2 + (32 * w + 4 * hi) * S2 + j;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float mv[16], vv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const int o = unit_of(r, 0) * H + 32 * nt; mv[r] = mW[o]; vv[r] = vW[o]; }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = unit_of(r, 0) * H + 32 * nt, ol = unit_of(r, 0) * S2 + 32 * nt;
+            pW[ol] = adam_math(pW[ol], gW2[nt][r], mv[r], vv[r]);
+            mW[o] = mv[r]; vW[o] = vv[r];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      {
+        // W1 rows of this wave (lane j < d_in) and b1 (lane j == d_in): one base pointer + a small per-register stride
+        float mv[16], vv[16];
+        const bool isw = j < d_in, own = j <= d_in;
+        const int stg = isw ? d_in : 1;
+        const int64_t gbase = isw ? oW1g + (int64_t)(32 * w + 4 * hi) * d_in + j : oB1g + 32 * w + 4 * hi;
+        float* __restrict__ mW = A.m + (own ? gbase : 0);
+        float* __restrict__ vW = A.v + (own ? gbase : 0);
+        float* pW = sW1 + (32 * w + 4 * hi) * S1 + (isw ? j : d_in);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int o = own ? unit_of(r, 0) * stg : 0; mv[r] = mW[o]; vv[r] = vW[o]; }
+        if (own) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = unit_of(r, 0) * stg, ol = unit_of(r, 0) * S1;
+            pW[ol] = adam_math(pW[ol], gW1[r], mv[r], vv[r]);
+            mW[o] = mv[r]; vW[o] = vv[r];
+          }
+        }
+      }
+      if (hi == 0) adam(&sB2[32 * w + j], oB2g + 32 * w + j, gb2);
+      if (tid < H) adam(&sW3[tid], oW3g + tid, gw3);
+      if (tid == 0) adam(&sB3[0], oB3g, gb3);
+      __syncthreads();
+    }
+    if (tid == 0) A.epoch_loss[ep] = ep_loss;
+  }
+  // ---- write the trained parameters back
+  __syncthreads();
+  for (int i = tid; i < H * (d_in + 1); i += 256) {
+    int u = i / (d_in + 1), f = i - u * (d_in + 1);
+    if (f < d_in) A.params[oW1g + (int64_t)u * d_in + f] = sW1[u * S1 + f]; else A.params[oB1g + u] = sW1[u * S1 + d_in];
+  }
+  for (int i = tid; i < H * H; i += 256) A.params[oW2g + i] = sW2[(i / H) * S2 + (i % H)];
+  for (int i = tid; i < H; i += 256) { A.params[oW3g + i] = sW3[i]; A.params[oB2g + i] = sB2[i]; }
+  if (tid == 0) A.params[oB3g] = sB3[0];
+}
+
+}  // namespace mjx
