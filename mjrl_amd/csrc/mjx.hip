@@ -116,6 +116,9 @@ int pick_variant(int n, int m, const std::vector<int>& hid, int64_t d, size_t* b
 int dispatch_fused(mjx_ctx* c, int mode, const FusedArgs& a, hipStream_t st) {
   // shape-specialised instances (compile-time feature count => fully unrolled first layer)
   const int NPr = (c->n + 1 + 3) & ~3;
+#ifdef MJX_PHASE_CLOCK
+  if (c->fused == 1 && NPr == 20) return launch_fused<64, 64, 1, 8, false, 20>(c, mode, a, st);
+#endif
   if (c->fused == 1 && NPr == 20 && !c->dbg) return launch_fused<64, 64, 1, 8, false, 20>(c, mode, a, st);   // obs 16..19 (HalfCheetah 17)
   switch (c->fused) {
 #ifdef MJX_PHASE_CLOCK

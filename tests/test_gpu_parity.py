@@ -470,3 +470,47 @@ def test_hvp_sample_frac_rng_parity():
     alpha = np.sqrt(abs(0.05 / (g.dot(x) + 1e-20)))
     step = pol.get_param_values().astype(np.float64) - c.theta0
     assert rel(step, alpha * x) < 2e-5
+
+
+@pytest.mark.parametrize("n,m,hid,expect_fused", [
+    (17, 12, (64, 64), True),      # MP = 16 variant
+    (9, 10, (32, 32), True),       # 32x32, MP = 16
+    (40, 4, (32, 32), True),       # NT1 = 2 (obs dim > 31)
+    (22, 8, (64, 64), True),       # m == MP
+    (28, 8, (64, 64), None),       # near the 160 KB LDS limit of the 64x64 variant: either path
+    (31, 1, (32, 32), True),       # n + 1 == 32 exactly, single action
+    (12, 3, (64, 32), False),      # unequal hidden sizes -> layer-wise
+    (50, 5, (64, 64), False),      # obs too wide for the 64x64 fused LDS budget -> layer-wise
+    (8, 2, (48,), False),          # one hidden layer
+    (7, 20, (32, 32), False),      # more actions than any fused variant
+])
+def test_other_shapes_vs_oracle(n, m, hid, expect_fused):
+    """every kernel variant / dispatch branch: K1, K2, K3 against the fp64 oracle (with transforms, old != new in K3)"""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    rng = np.random.RandomState(n * 100 + m)
+    N = 3000 + n
+    th = synth.perturbed_params(synth.init_params(n, m, hid), scale=0.05)
+    th2 = (th + 0.02 * rng.randn(th.size)).astype(np.float32)
+    obs, act, adv = rng.randn(N, n), rng.randn(N, m), rng.randn(N)
+    tr = O.Transforms(n, m, 0.1 * rng.randn(n), 1 + 0.1 * rng.rand(n), 0.05 * rng.randn(m), 1 + 0.2 * rng.rand(m))
+    pk = np.concatenate([tr.in_shift, tr.in_scale, tr.out_shift, tr.out_scale]).astype(np.float32)
+    eng = UpdateEngine(n, m, hid)
+    assert expect_fused is None or eng.fused == expect_fused
+    eng.set_policy(th, th, pk, pk)
+    eng.set_batch(obs, act, adv)
+    th64 = th.astype(np.float64)
+    g, surr = eng.surr_vpg()
+    assert rel(g.cpu().numpy(), O.vpg(th64, th64, obs, act, adv, n, m, hid, tr, tr)) < TOL_VPG
+    v = rng.randn(th.size).astype(np.float32)
+    hv = eng.fvp(torch.from_numpy(v).to(eng.device)).cpu().numpy()
+    assert rel(hv, O.fvp(th64, obs, v.astype(np.float64), n, m, hid, tr)) < TOL_FVP
+    eng.set_policy(th2, th, pk, pk)
+    s, kl = eng.eval_surr_kl()
+    t2 = th2.astype(np.float64)
+    assert abs(s - O.surrogate(t2, th64, obs, act, adv, n, m, hid, tr, tr)) < 5e-6
+    klo = O.mean_kl(t2, th64, obs, n, m, hid, tr, tr)
+    assert abs(kl - klo) < 2e-5 * klo + 1e-7
+    g2, s2 = eng.surr_vpg()                                   # K1 with an explicit old network
+    assert rel(g2.cpu().numpy(), O.vpg(t2, th64, obs, act, adv, n, m, hid, tr, tr)) < 5e-6
+    eng.close()

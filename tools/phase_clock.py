@@ -21,8 +21,9 @@ for _ in range(3):
     eng.fvp(v)
 torch.cuda.synchronize()
 st = dbg.cpu().numpy().view(np.int64)[:14]
-names = ["stage x", "L1 fwd+tan MFMA", "tanh z1 + t1 scale", "bias init", "pass A", "pass B", "tanh z2 + t2 scale", "out_small x2",
-         "out_finish + d3", "transposes + delta2", "gW3 + factor + bias sums", "delta1u", "gW2 + factor", "gW1"]
+names = ["0 stage x", "1 L1 fwd+tan MFMAs (40)", "2 (tanh z1, sunk)", "3 tanh z1 + bias init + pass A (128)", "4 pass B (64) + tanh z2 + transposes", "5 -", "6 out_small (128 x 4x4)",
+         "7 out_finish + d3", "8 delta2 (16)", "9 gW3 (32) + factor", "10 delta1u (64)", "11 gW2 (64) + factor", "12 gW1 (32)"]
+st[5] = st[4]  # stamp 5 no longer exists
 d = np.diff(st)
 tot = st[13] - st[0]
 for i, x in enumerate(d):
