@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       if (TAN) {
         // pass B: t2 += V2 h1.  z2 is final after pass A, so tanh(z2), and the [unit][sample] copies of h2 / h1
         // the backward pass needs (bufA / bufB), are issued step by step in the shadow of these MFMAs.
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 vc[MT2], vn[MT2];
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) vc[mt] = *(const f32x4*)&slotB[L.oW2 + (32 * mt + j) * S2 + 4 * hi];
@@ -387,6 +388,19 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
           for (int mt = 0; mt < MT2; ++mt) vc[mt] = vn[mt];
         }
+        // one wave per SIMD issues in order: interleave, per MFMA, a slice of the tanh / LDS-store work
+        __builtin_amdgcn_sched_group_barrier(0x100, MT2, 0);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, MT2, 0);
+#pragma unroll
+          for (int i = 0; i < 4 * MT2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll

@@ -451,6 +451,11 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
   if (!grad_out || !scal_out) return fail(MJX_ERR_ARG, "null output");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->device));
+  if (c->N_local == 0) {                       // a rank without trajectories contributes zeros
+    HIPCHK(hipMemsetAsync(grad_out, 0, c->d * sizeof(float), st));
+    HIPCHK(hipMemsetAsync(scal_out, 0, 4 * sizeof(double), st));
+    return MJX_OK;
+  }
   if (!c->fused)
     return c->lw.surr_vpg(c->obs, c->act, c->adv, c->N_local, c->N_global, c->theta_new, c->theta_old,
                           c->tr_new ? c->tr_new : c->ident_tr, c->tr_old ? c->tr_old : c->ident_tr, c->old_is_new,
@@ -469,6 +474,7 @@ int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
   if (!v || !out) return fail(MJX_ERR_ARG, "null vector");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->device));
+  if (c->N_local == 0) { HIPCHK(hipMemsetAsync(out, 0, c->d * sizeof(float), st)); return MJX_OK; }
   if (!c->old_is_new) {
     // general position (e.g. input_normalization, npg_cg.py:101-107): exact Pearlmutter product on the layer-wise path
     if (c->lw.cap < c->N_local) { if (int rc = c->lw.reserve(c->N_local)) return fail(rc, "layer-wise workspace allocation failed"); }
@@ -498,6 +504,7 @@ int mjx_eval_surr_kl(mjx_ctx* c, double* scal_out, void* stream) {
   if (!scal_out) return fail(MJX_ERR_ARG, "null output");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->device));
+  if (c->N_local == 0) { HIPCHK(hipMemsetAsync(scal_out, 0, 4 * sizeof(double), st)); return MJX_OK; }
   if (!c->fused)
     return c->lw.eval(c->obs, c->act, c->adv, c->N_local, c->theta_new, c->theta_old,
                       c->tr_new ? c->tr_new : c->ident_tr, c->tr_old ? c->tr_old : c->ident_tr, scal_out, st)

@@ -514,3 +514,20 @@ def test_other_shapes_vs_oracle(n, m, hid, expect_fused):
     g2, s2 = eng.surr_vpg()                                   # K1 with an explicit old network
     assert rel(g2.cpu().numpy(), O.vpg(t2, th64, obs, act, adv, n, m, hid, tr, tr)) < 5e-6
     eng.close()
+
+
+def test_empty_shard_contributes_zero():
+    """a rank that holds no trajectories (N_local == 0, N_global > 0) must produce zeros on both paths"""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    for n, m, hid in ((17, 6, (64, 64)), (40, 9, (96, 48))):
+        th = synth.perturbed_params(synth.init_params(n, m, hid))
+        tr = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+        eng = UpdateEngine(n, m, hid)
+        eng.set_policy(th, th, tr, tr)
+        eng.set_batch(np.zeros((0, n), np.float32), np.zeros((0, m), np.float32), np.zeros(0, np.float32), N_global=1000)
+        g, s = eng.surr_vpg()
+        assert float(g.abs().max()) == 0.0 and s == 0.0
+        assert float(eng.fvp(torch.ones(th.size, device=eng.device)).abs().max()) == 0.0
+        assert eng.eval_surr_kl() == (0.0, 0.0)
+        eng.close()
