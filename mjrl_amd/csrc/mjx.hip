@@ -56,6 +56,7 @@ struct mjx_ctx {
   int64_t N_local = 0, N_global = 0;
   const float *theta_new = nullptr, *theta_old = nullptr, *tr_new = nullptr, *tr_old = nullptr;
   int old_is_new = 1;
+  bool batch_bound = false;
   // workspace (device)
   float* partials = nullptr;       // [grid][d]
   double* spartials = nullptr;     // [grid][4]
@@ -151,8 +152,8 @@ FusedArgs make_args(mjx_ctx* c, const float* thetaB) {
 
 int check_bound(mjx_ctx* c, bool need_act) {
   if (!c) return fail(MJX_ERR_ARG, "null context");
-  if (!c->obs || c->N_local < 0 || c->N_global <= 0) return fail(MJX_ERR_STATE, "mjx_bind_batch has not been called");
-  if (need_act && (!c->act || !c->adv)) return fail(MJX_ERR_STATE, "actions / advantages not bound");
+  if (!c->batch_bound || c->N_local < 0 || c->N_global <= 0) return fail(MJX_ERR_STATE, "mjx_bind_batch has not been called");
+  if (need_act && c->N_local > 0 && (!c->act || !c->adv)) return fail(MJX_ERR_STATE, "actions / advantages not bound");
   if (!c->theta_new || !c->theta_old) return fail(MJX_ERR_STATE, "mjx_bind_policy has not been called");
   return MJX_OK;
 }
@@ -230,6 +231,7 @@ int mjx_bind_batch(mjx_ctx* c, const float* obs, const float* act, const float* 
   if (!c || (!obs && N_local > 0) || N_local < 0 || N_global < N_local || N_global <= 0) return fail(MJX_ERR_ARG, "bad batch");
   if (((uintptr_t)obs & 15) != 0) return fail(MJX_ERR_ARG, "obs must be 16-byte aligned");
   c->obs = obs; c->act = act; c->adv = adv; c->N_local = N_local; c->N_global = N_global;
+  c->batch_bound = true;
   c->lw.invalidate();
   if (!c->fused) { int rc = c->lw.reserve(N_local); if (rc) return fail(rc, "layer-wise workspace allocation failed"); }
   return MJX_OK;
