@@ -349,7 +349,10 @@ int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, con
     if (!(force && force[0] == '1') && n_hidden == 2 && hidden[0] == 128 && hidden[1] == 128 && batch == 64 && d_in <= 31 &&
         steps_ > 0 && epochs > 0) {
       MlpFitLayout<128> L(d_in);
-      MlpFitArgs a{feat, y, perm, N, d_in, epochs, steps_, params, m, v, step0, lr, wd, epoch_loss_out};
+      static thread_local Scratch mvws;
+      const int64_t P = (int64_t)128 * d_in + 128 + 128 * 128 + 128 + 128 + 1;
+      if (int rc = get_scratch(mvws, (size_t)P * 2 * sizeof(float))) return rc;
+      MlpFitArgs a{feat, y, perm, N, d_in, epochs, steps_, params, m, v, (float*)mvws.p, step0, lr, wd, epoch_loss_out};
       static thread_local bool configured = false;
       if (!configured) {
         HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));

@@ -18,6 +18,12 @@
 
 namespace mjx {
 
+#ifdef MJX_PHASE_CLOCK
+#define MJX_FIT_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (tid == 0 && ep == 0 && mb == 100 && hb == 0) ((long long*)A.epoch_loss)[8 + (k)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MJX_FIT_STAMP(k) do {} while (0)
+#endif
+
 struct MlpFitArgs {
   const float* feat;       // (N, d_in) fp32
   const float* y;          // (N)
@@ -28,6 +34,7 @@ struct MlpFitArgs {
   float* params;           // flat [W1 (H x d_in), b1, W2 (H x H), b2, W3 (H), b3], updated in place
   float* m;                // Adam first moment  (same layout)
   float* v;                // Adam second moment
+  float* mv;               // workspace: interleaved (m, v) pairs, 2 * P floats
   int64_t step0;           // Adam steps taken before this call
   float lr, wd;
   double* epoch_loss;      // [epochs] sum over steps of the minibatch MSE
@@ -80,6 +87,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   for (int i = tid; i < H; i += 256) { sW3[i] = A.params[oW3g + i]; sB2[i] = A.params[oB2g + i]; }
   if (tid == 0) sB3[0] = A.params[oB3g];
   if (tid < 32) { xs[tid * S1 + d_in] = 1.0f; xT[d_in * ST + tid] = 1.0f; }
+  const int64_t Ptot = oB3g + 1;
+  for (int64_t i = tid; i < Ptot; i += 256) { A.mv[2 * i] = A.m[i]; A.mv[2 * i + 1] = A.v[i]; }
   __syncthreads();
 
   const float b1c = 0.9f, b2c = 0.999f, eps = 1e-8f;
@@ -88,15 +97,27 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   float gx[GL];
   float gy = 0.f;
 
-  auto gather_load = [&](int ep, int64_t mb, int hb) {
+  // Two-stage prefetch: the permutation entries (row indices) are fetched one half-step before the
+  // rows they address, the rows one half-step before they are staged, so neither latency is exposed.
+  int gidx[GL];
+  int gyi = 0;
+  auto index_load = [&](int ep, int64_t mb, int hb) {
     const int32_t* idx = A.perm + (int64_t)ep * A.N + mb * 64 + 32 * hb;
+#pragma unroll
+    for (int c = 0; c < GL; ++c) {
+      int e = c * 256 + tid, s = e / d_in;
+      gidx[c] = idx[(e < 32 * d_in) ? s : 0];
+    }
+    gyi = idx[tid & 31];
+  };
+  auto gather_load = [&]() {
 #pragma unroll
     for (int c = 0; c < GL; ++c) {
       int e = c * 256 + tid, s = e / d_in, f = e - s * d_in;
       bool ok = e < 32 * d_in;
-      gx[c] = A.feat[ok ? (int64_t)idx[s] * d_in + f : 0];
+      gx[c] = A.feat[ok ? (int64_t)gidx[c] * d_in + f : 0];
     }
-    gy = A.y[idx[tid & 31]];
+    gy = A.y[gyi];
   };
   auto gather_store = [&]() {
 #pragma unroll
@@ -109,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
 
   for (int ep = 0; ep < A.epochs; ++ep) {
     double ep_loss = 0.0;
-    if (A.steps > 0) gather_load(ep, 0, 0);
+    if (A.steps > 0) { index_load(ep, 0, 0); gather_load(); index_load(ep, 0, 1); }
 #pragma unroll 1
     for (int64_t mb = 0; mb < A.steps; ++mb) {
       f32x16 gW2[NT], gW1;
@@ -119,11 +140,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
       float gb2 = 0.f, gw3 = 0.f, gb3 = 0.f;
 #pragma unroll 1
       for (int hb = 0; hb < 2; ++hb) {
+        MJX_FIT_STAMP(0);
         gather_store();
         __syncthreads();
         // prefetch the next half's rows while this half computes
-        if (hb == 0) gather_load(ep, mb, 1);
-        else if (mb + 1 < A.steps) gather_load(ep, mb + 1, 0);
+        if (hb == 0) { gather_load(); if (mb + 1 < A.steps) index_load(ep, mb + 1, 0); }       // rows of half 1; indices of the next step
+        else if (mb + 1 < A.steps) { gather_load(); index_load(ep, mb + 1, 1); }
+        MJX_FIT_STAMP(1);
         // ---- layer 1: z1[unit 32w+., sample] = W1a x~a ; h1 = relu
         f32x16 z1 = (f32x16)(0.f);
         for (int q = 0; q < K1 / 4; ++q) {
@@ -136,6 +159,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) h1T[(32 * w + unit_of(r, hi)) * ST + j] = fmaxf(z1[r], 0.f);
         __syncthreads();
+        MJX_FIT_STAMP(2);
         // ---- layer 2: K = all 128 h1 units (B operand from the shared h1^T tile)
         f32x16 z2;
 #pragma unroll
@@ -183,6 +207,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         part += __shfl_xor(part, 32);
         if (hi == 0) sPart[w * 32 + j] = part;
         __syncthreads();
+        MJX_FIT_STAMP(3);
         // ---- output + MSE gradient (every wave redundantly, lane j = sample)
         const float yhat = (sPart[j] + sPart[32 + j]) + (sPart[64 + j] + sPart[96 + j]) + sB3[0];
         const float err = yhat - sY[j];
@@ -201,6 +226,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
           d2T[u * ST + j] = (z2[r] > 0.f) ? sW3[u] * dy : 0.f;
         }
         __syncthreads();
+        MJX_FIT_STAMP(4);
         // ---- grad W3 / b3 (thread = unit), grad b2, delta2 in lane = unit layout straight from d2T
         if (tid < H) {
           float a = 0.f;
@@ -225,6 +251,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
           for (int r = 0; r < 16; ++r) s2 += d2u[r];
           gb2 += s2 + __shfl_xor(s2, 32);
         }
+        MJX_FIT_STAMP(5);
         // grad W2 rows of this wave: A = delta2u (registers), B = h1^T tiles
         {
           f32x4 bc[NT], bn[NT];
@@ -244,6 +271,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
             for (int nt = 0; nt < NT; ++nt) bc[nt] = bn[nt];
           }
         }
+        MJX_FIT_STAMP(6);
         // delta1 (lane = h1 unit of this wave's tile): A = delta2 [sample][k] from d2T, B = W2[k][unit]
         f32x16 d1u = (f32x16)(0.f);
         __builtin_amdgcn_sched_barrier(0);
@@ -277,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
           d1u[4 * q] = hv.x > 0.f ? d1u[4 * q] : 0.f; d1u[4 * q + 1] = hv.y > 0.f ? d1u[4 * q + 1] : 0.f;
           d1u[4 * q + 2] = hv.z > 0.f ? d1u[4 * q + 2] : 0.f; d1u[4 * q + 3] = hv.w > 0.f ? d1u[4 * q + 3] : 0.f;
         }
+        MJX_FIT_STAMP(7);
         // grad W1a rows of this wave (column d_in = grad b1)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -286,60 +315,70 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
           for (int t = 0; t < 4; ++t) gW1 = MJX_MFMA(d1u[4 * q + t], b4[t], gW1);
         }
         __syncthreads();                                    // tiles are rewritten by the next half
+        MJX_FIT_STAMP(8);
       }
+      { const int hb = 0; MJX_FIT_STAMP(9); }
       // ---- Adam (torch.optim.Adam: L2 weight decay folded into the gradient, bias-corrected)
       pw1 *= (double)b1c; pw2 *= (double)b2c;
       const float bc1 = (float)(1.0 - pw1), bc2s = (float)sqrt(1.0 - pw2);
       const float step_size = A.lr / bc1;
-      auto adam_math = [&](float p, float g, float& mi, float& vi) {
+      // torch.optim.Adam's update; the two divides use v_rcp_f32 + one Newton step (<= 1 ulp from IEEE),
+      // which keeps the 19 457-weight update at ~18 VALU ops per weight
+      const float inv_bc2s = 1.0f / bc2s;
+      auto adam_math = [&](float p, float g, f32x2& q) {
         g += A.wd * p;
+        float mi = q.x, vi = q.y;
         mi = mi + (g - mi) * (1.0f - b1c);
         vi = vi * b2c + g * g * (1.0f - b2c);
-        return p - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+        q = f32x2{mi, vi};
+        const float denom = fmaf(__builtin_amdgcn_sqrtf(vi), inv_bc2s, eps);
+        float r = __builtin_amdgcn_rcpf(denom);
+        r = r * fmaf(-denom, r, 2.0f);
+        return fmaf(-step_size * mi, r, p);
       };
+      f32x2* __restrict__ MV = (f32x2*)A.mv;
       auto adam = [&](float* p_lds, int64_t gi, float g) {
-        float mi = A.m[gi], vi = A.v[gi];
-        *p_lds = adam_math(*p_lds, g, mi, vi);
-        A.m[gi] = mi; A.v[gi] = vi;
+        f32x2 q = MV[gi];
+        *p_lds = adam_math(*p_lds, g, q);
+        MV[gi] = q;
       };
-      // the owned W2 block, 16 elements at a time: issue the 32 moment loads together, then update, then store.
-      // Element (nt, r) sits at a compile-time offset from one per-lane base (row 32w + 4hi, column j).
+      // Every owned element sits at a compile-time offset from one per-lane base.  All moment pairs of the
+      // thread's 64 W2 weights are requested up front (the backward pass's registers are free by now), so the
+      // L2 latency is paid once; then update, write the weight to LDS and the pair back.
       {
         const int64_t gbase = oW2g + (int64_t)(32 * w + 4 * hi) * H + j;
-        float* __restrict__ mW = A.m + gbase;
-        float* __restrict__ vW = A.v + gbase;
+        f32x2* __restrict__ mvW = MV + gbase;
         float* pW = sW2 + (32 * w + 4 * hi) * S2 + j;
+        f32x2 q[NT][16];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          float mv[16], vv[16];
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { const int o = unit_of(r, 0) * H + 32 * nt; mv[r] = mW[o]; vv[r] = vW[o]; }
+          for (int r = 0; r < 16; ++r) q[nt][r] = mvW[unit_of(r, 0) * H + 32 * nt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int o = unit_of(r, 0) * H + 32 * nt, ol = unit_of(r, 0) * S2 + 32 * nt;
-            pW[ol] = adam_math(pW[ol], gW2[nt][r], mv[r], vv[r]);
-            mW[o] = mv[r]; vW[o] = vv[r];
+            pW[ol] = adam_math(pW[ol], gW2[nt][r], q[nt][r]);
+            mvW[o] = q[nt][r];
           }
-          __builtin_amdgcn_sched_barrier(0);
-        }
       }
       {
         // W1 rows of this wave (lane j < d_in) and b1 (lane j == d_in): one base pointer + a small per-register stride
-        float mv[16], vv[16];
         const bool isw = j < d_in, own = j <= d_in;
         const int stg = isw ? d_in : 1;
         const int64_t gbase = isw ? oW1g + (int64_t)(32 * w + 4 * hi) * d_in + j : oB1g + 32 * w + 4 * hi;
-        float* __restrict__ mW = A.m + (own ? gbase : 0);
-        float* __restrict__ vW = A.v + (own ? gbase : 0);
+        f32x2* __restrict__ mvW = MV + (own ? gbase : 0);
         float* pW = sW1 + (32 * w + 4 * hi) * S1 + (isw ? j : d_in);
+        f32x2 q[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const int o = own ? unit_of(r, 0) * stg : 0; mv[r] = mW[o]; vv[r] = vW[o]; }
+        for (int r = 0; r < 16; ++r) q[r] = mvW[own ? unit_of(r, 0) * stg : 0];
         if (own) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int o = unit_of(r, 0) * stg, ol = unit_of(r, 0) * S1;
-            pW[ol] = adam_math(pW[ol], gW1[r], mv[r], vv[r]);
-            mW[o] = mv[r]; vW[o] = vv[r];
+            pW[ol] = adam_math(pW[ol], gW1[r], q[r]);
+            mvW[o] = q[r];
           }
         }
       }
@@ -347,11 +386,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
       if (tid < H) adam(&sW3[tid], oW3g + tid, gw3);
       if (tid == 0) adam(&sB3[0], oB3g, gb3);
       __syncthreads();
+      { const int hb = 0; MJX_FIT_STAMP(10); }
     }
     if (tid == 0) A.epoch_loss[ep] = ep_loss;
   }
-  // ---- write the trained parameters back
+  // ---- write the trained parameters and the moments back
   __syncthreads();
+  for (int64_t i = tid; i < Ptot; i += 256) { A.m[i] = A.mv[2 * i]; A.v[i] = A.mv[2 * i + 1]; }
   for (int i = tid; i < H * (d_in + 1); i += 256) {
     int u = i / (d_in + 1), f = i - u * (d_in + 1);
     if (f < d_in) A.params[oW1g + (int64_t)u * d_in + f] = sW1[u * S1 + f]; else A.params[oB1g + u] = sW1[u * S1 + d_in];
