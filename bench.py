@@ -173,7 +173,13 @@ def main():
     if rank == 0:
         fvp_ms = prof[0] / max(prof[1], 1.0)
         P = N_OBS * 64 + 64 * 64 + 64 * N_ACT
-        flop_per_sample = 2 * (5 * P - 2 * N_OBS * 64)               # 51,328 @cfg2
+        # The CG loop runs the cached-forward FVP instance: h1 / h2 are stored once per update by K1 (theta is
+        # fixed during CG), each product then costs the tangent + backward passes, 2(4P - 2 n h1) FLOP and
+        # 4(n + h1 + h2) B per sample (SURVEY 8d "cached-activation variant").  The recompute instance
+        # (2(5P - 2 n h1) = 51 328 FLOP, 68 B per sample) is what mjx_fvp runs without a preceding K1.
+        flop_per_sample = 2 * (4 * P - 2 * N_OBS * 64)               # 40 192 @cfg2
+        bytes_per_sample = 4 * (N_OBS + 64 + 64)                     # 580 @cfg2
+        flop_recompute = 2 * (5 * P - 2 * N_OBS * 64)                # 51 328 @cfg2
         n_loc = eng.N_local
         achieved_tf = flop_per_sample * n_loc / (fvp_ms * 1e-3) / 1e12
         traffic = None
@@ -198,14 +204,15 @@ def main():
                                    "NPG 10 CG iters, 1M timesteps/batch (1000 traj x 1000), device-resident update",
                        "global_batch": N_TRAJ * T, "parallelism": "dp%d (trajectory shards, RCCL all-reduce per CG iter)" % world,
                        "cg_iters": CG_ITERS, "damping": DAMPING},
-            "roofline": {"bound": "mfma", "kernel": "k_fused<64,64,1,8,MODE_FVP>",
+            "roofline": {"bound": "mfma", "kernel": "k_fused<64,64,1,8,MODE_FVP,NP=20,CACHED>",
                          "achieved": achieved_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP32_MFMA_PEAK_TF, "traffic": traffic,
                          "avg_launch_ms": fvp_ms, "launches": int(prof[1]),
                          "flop_per_launch": flop_per_sample * n_loc,
-                         "algorithmic_bytes_per_launch": 4 * N_OBS * n_loc,
-                         "hbm_GBps_algorithmic": 4 * N_OBS * n_loc / (fvp_ms * 1e-3) / 1e9,
-                         "hbm_frac_algorithmic": 4 * N_OBS * n_loc / (fvp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "algorithmic_bytes_per_launch": bytes_per_sample * n_loc,
+                         "hbm_GBps_algorithmic": bytes_per_sample * n_loc / (fvp_ms * 1e-3) / 1e9,
+                         "hbm_frac_algorithmic": bytes_per_sample * n_loc / (fvp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "fvp_equivalent_TFLOPs_if_recomputed": flop_recompute * n_loc / (fvp_ms * 1e-3) / 1e12},
             "check": last,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -77,7 +77,7 @@ int mjx_bind_batch(mjx_ctx* ctx, const float* obs, const float* act, const float
                    int64_t N_local, int64_t N_global);
 /* theta_new / theta_old: flat parameter vectors (d floats each) of policy.model /
  * policy.old_model (+log_std); tr_new / tr_old: packed transforms (2n+2m floats)
- * or NULL for identity.  old_is_new != 0 asserts both describe the same function
+ * or NULL for identity (parameter vectors 16-byte aligned).  old_is_new != 0 asserts both describe the same function
  * (always true at entry to train_from_paths, gaussian_mlp.py:44-45, npg_cg.py:142). */
 int mjx_bind_policy(mjx_ctx* ctx, const float* theta_new, const float* theta_old,
                     const float* tr_new, const float* tr_old, int old_is_new);

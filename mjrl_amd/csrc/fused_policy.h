@@ -46,6 +46,7 @@ struct FusedArgs {
   float* partials;       // [gridDim.x][d]   VPG / FVP
   double* spartials;     // [gridDim.x][4]
   float* dbg;            // optional dump of tile 0 (block 0, wave 0)
+  float* hcache;         // forward-activation cache [tile][MT1+MT2][4][64 lanes][4]: written by MODE_VPG, read by cached FVP
   int n, m;
 };
 
@@ -53,6 +54,11 @@ struct FusedArgs {
 #define MJX_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (A.dbg && blockIdx.x == 0 && wave == 0 && lane == 0 && tile == tstride) ((long long*)A.dbg)[k] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define MJX_STAMP(k) do {} while (0)
+#endif
+#ifdef MJX_PHASE_CLOCK
+#define MJX_GSTAMP(k) do { if (A.dbg && blockIdx.x == 0 && threadIdx.x == 0) ((long long*)A.dbg)[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define MJX_GSTAMP(k) do {} while (0)
 #endif
 #define MJX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -89,7 +95,7 @@ struct FusedLayout {
   int oW1, oW2, oW3, oB2, oB3, SLOT;            // weight slot (one per parameter set)
   int oXS, oXT, oD3, oBA, oBB, WAVE;            // per-wave scratch
   int oTR, oCST, oWAVES, TOTAL;
-  static constexpr int NCST = 9;                // osc, osh, sigma, log_std (new) ; the same for old ; Dk = 2/(2 sigma^2 + 1e-8)
+  static constexpr int NCST = 11;               // osc, osh, sigma, log_std (new) ; the same for old ; Dk = 2/(2 sigma^2 + 1e-8) ; {c3, osc^2 Dk / N} pairs
   __host__ __device__ explicit FusedLayout(int n) {
     NP = (n + 1 + 3) & ~3;
     S1 = NP + 2;
@@ -122,7 +128,7 @@ struct FlatOff {
   }
 };
 
-template <int H1, int H2, int NT1, int MP, int MODE, bool DBG = false, int NPC = 0>
+template <int H1, int H2, int NT1, int MP, int MODE, bool DBG = false, int NPC = 0, bool CACHED = false>
 __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   using LT = FusedLayout<H1, H2, NT1, MP>;
   constexpr int MT1 = LT::MT1, MT2 = LT::MT2, S2 = LT::S2, S3 = LT::S3, ST = LT::ST;
@@ -145,9 +151,18 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   float* bufA = ws + L.oBA;
   float* bufB = ws + L.oBB;
 
+  MJX_GSTAMP(16);
   // ---------------- stage weights (whole workgroup) ----------------
-  for (int idx = tid; idx < L.TOTAL; idx += 256) lds[idx] = 0.0f;
+  // zero what is read before (or without) being written: the weight slots' pads, the constants, and each wave's
+  // xs slack / xT / d3T.  bufA / bufB are fully rewritten every tile before they are read.
+  {
+    f32x4* z4 = (f32x4*)lds;
+    for (int i = tid; i < L.oWAVES / 4; i += 256) z4[i] = (f32x4)(0.f);
+    f32x4* w4 = (f32x4*)ws;
+    for (int i = lane; i < L.oBA / 4; i += 64) w4[i] = (f32x4)(0.f);
+  }
   __syncthreads();
+#pragma unroll
   for (int s = 0; s < 2; ++s) {
     float* slot = s ? slotB : slotA;
     const float* th = s ? A.thetaB : A.thetaA;
@@ -155,9 +170,14 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       int u = idx / (n + 1), f = idx - u * (n + 1);
       slot[L.oW1 + u * S1 + f] = (f < n) ? th[fo.W1 + u * n + f] : th[fo.b1 + u];
     }
-    for (int idx = tid; idx < H2 * H1; idx += 256) {
-      int u = idx / H1, k = idx - u * H1;
-      slot[L.oW2 + u * S2 + k] = th[fo.W2 + idx];
+    // W2 rows are 16-byte aligned in the flat vector (h1 (n + 1) is a multiple of 4): 16-byte copies
+#pragma unroll
+    for (int c = 0; c < (H2 * H1 / 4 + 255) / 256; ++c) {
+      const int i4 = c * 256 + tid;
+      if (i4 < H2 * H1 / 4) {
+        const int u = (4 * i4) / H1, k = (4 * i4) % H1;
+        *(f32x4*)&slot[L.oW2 + u * S2 + k] = *(const f32x4*)&th[fo.W2 + 4 * i4];
+      }
     }
     for (int idx = tid; idx < m * H2; idx += 256) { int a = idx / H2, k = idx - a * H2; slot[L.oW3 + a * S3 + k] = th[fo.W3 + idx]; }
     for (int idx = tid; idx < H2; idx += 256) slot[L.oB2 + idx] = th[fo.b2 + idx];
@@ -190,9 +210,15 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     cst[C_SGB * MP + a] = ok ? expf(lsb) : 1.0f;
     cst[C_LSB * MP + a] = lsb;
     { float sg = ok ? expf(lsa) : 1.0f; cst[C_DK * MP + a] = 2.0f / (2.0f * sg * sg + 1e-8f); }
+    if (MODE == MODE_FVP) {                       // FVP epilogue: d3 = (md + c3) * osc^2 * Dk / N
+      float osc = ok ? A.trA[2 * n + m + a] : 0.f;
+      cst[9 * MP + 2 * a] = ok ? A.thetaB[fo.b3 + a] : 0.f;
+      cst[9 * MP + 2 * a + 1] = osc * (cst[C_DK * MP + a] * (osc * A.inv_N));
+    }
   }
   __syncthreads();
 
+  MJX_GSTAMP(17);
   // ---------------- persistent accumulators ----------------
   f32x16 gW1[MT1][NT1], gW2[MT2][MT1], gW3[MT2];
   float sb2[MT2], sb3 = 0.f, gls[RA];     // grad b2[32*nt + j] (every lane), grad b3[lane], grad log_std[unit_of(r,hi)]
@@ -232,8 +258,30 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     }
   };
 
+  // forward-activation cache (sample-lane accumulator layout, 16-byte granules: [tile][mt][q][lane][4])
+  constexpr int HC_TILE = (MT1 + MT2) * 4 * 64 * 4;           // floats per tile
+  f32x16 hn1[MT1], hn2[MT2];                                   // next tile's h1 / h2 (cached FVP)
+  auto load_h = [&](int64_t t) {
+    const float* base = A.hcache + t * HC_TILE + lane * 4;
+#pragma unroll
+    for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = *(const f32x4*)(base + (mt * 4 + q) * 256);
+        hn1[mt][4 * q] = v.x; hn1[mt][4 * q + 1] = v.y; hn1[mt][4 * q + 2] = v.z; hn1[mt][4 * q + 3] = v.w;
+      }
+#pragma unroll
+    for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = *(const f32x4*)(base + ((MT1 + mt) * 4 + q) * 256);
+        hn2[mt][4 * q] = v.x; hn2[mt][4 * q + 1] = v.y; hn2[mt][4 * q + 2] = v.z; hn2[mt][4 * q + 3] = v.w;
+      }
+  };
+
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   if (tile < ntiles) load_x(tile);
+  if (MODE == MODE_FVP && CACHED && tile < ntiles) load_h(tile);
 
   for (; tile < ntiles; tile += tstride) {
     const int64_t s0 = tile * 32;
@@ -257,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     auto layers12 = [&](auto tan_tag, const float* slot, const float* tsh, const float* tsc, bool writeT,
                         f32x16 (&h1)[MT1], f32x16 (&h2)[MT2], f32x16 (&t1)[MT1], f32x16 (&t2)[MT2]) {
       constexpr bool TAN = decltype(tan_tag)::value;
+      constexpr bool FWD = !(TAN && CACHED);          // cached FVP: h1 / h2 arrive from HBM, only the tangent products run
       f32x16 z1[MT1];
 #pragma unroll
       for (int mt = 0; mt < MT1; ++mt) { z1[mt] = (f32x16)(0.f); if (TAN) t1[mt] = (f32x16)(0.f); }
@@ -274,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         float xb0 = xnorm(f00), xb1 = xnorm(f00 + 1);
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt) {
-          wc[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f00];
+          if (FWD) wc[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f00];
           if (TAN) vc[mt] = *(const f32x2*)&slotB[L.oW1 + (32 * mt + j) * S1 + f00];
         }
 #pragma unroll(NPC ? NPC / 4 : 1)
@@ -285,24 +334,24 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
           const float xn0 = xnorm(f1), xn1 = xnorm(f1 + 1);
 #pragma unroll
           for (int mt = 0; mt < MT1; ++mt) {
-            wn[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f1];
+            if (FWD) wn[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f1];
             if (TAN) vn[mt] = *(const f32x2*)&slotB[L.oW1 + (32 * mt + j) * S1 + f1];
           }
           const float x0 = xb0, x1 = xb1;
           if (writeT) { xT[f0 * ST + j] = x0; xT[(f0 + 1) * ST + j] = x1; }
 #pragma unroll
           for (int mt = 0; mt < MT1; ++mt) {
-            z1[mt] = MJX_MFMA(wc[mt].x, x0, z1[mt]);
+            if (FWD) z1[mt] = MJX_MFMA(wc[mt].x, x0, z1[mt]);
             if (TAN) t1[mt] = MJX_MFMA(vc[mt].x, x0, t1[mt]);
           }
 #pragma unroll
           for (int mt = 0; mt < MT1; ++mt) {
-            z1[mt] = MJX_MFMA(wc[mt].y, x1, z1[mt]);
+            if (FWD) z1[mt] = MJX_MFMA(wc[mt].y, x1, z1[mt]);
             if (TAN) t1[mt] = MJX_MFMA(vc[mt].y, x1, t1[mt]);
           }
           xb0 = xn0; xb1 = xn1;
 #pragma unroll
-          for (int mt = 0; mt < MT1; ++mt) { wc[mt] = wn[mt]; if (TAN) vc[mt] = vn[mt]; }
+          for (int mt = 0; mt < MT1; ++mt) { if (FWD) wc[mt] = wn[mt]; if (TAN) vc[mt] = vn[mt]; }
         }
       }
       MJX_STAMP(2);
@@ -310,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          h1[mt][r] = fast_tanh(z1[mt][r]);
+          if (FWD) h1[mt][r] = fast_tanh(z1[mt][r]);
           if (TAN) t1[mt][r] *= fmaf(-h1[mt][r], h1[mt][r], 1.0f);
         }
       MJX_STAMP(3);
@@ -320,8 +369,10 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          f32x4 b = *(const f32x4*)&slot[L.oB2 + 32 * mt + 8 * q + 4 * hi];
-          z2[mt][4 * q + 0] = b.x; z2[mt][4 * q + 1] = b.y; z2[mt][4 * q + 2] = b.z; z2[mt][4 * q + 3] = b.w;
+          if (FWD) {
+            f32x4 b = *(const f32x4*)&slot[L.oB2 + 32 * mt + 8 * q + 4 * hi];
+            z2[mt][4 * q + 0] = b.x; z2[mt][4 * q + 1] = b.y; z2[mt][4 * q + 2] = b.z; z2[mt][4 * q + 3] = b.w;
+          }
           if (TAN) {
             f32x4 c = *(const f32x4*)&slotB[L.oB2 + 32 * mt + 8 * q + 4 * hi];
             t2[mt][4 * q + 0] = c.x; t2[mt][4 * q + 1] = c.y; t2[mt][4 * q + 2] = c.z; t2[mt][4 * q + 3] = c.w;
@@ -345,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int mt = 0; mt < MT2; ++mt) {
-              z2[mt] = MJX_MFMA(wc[mt][t], h1[kb][4 * q + t], z2[mt]);
+              if (FWD) z2[mt] = MJX_MFMA(wc[mt][t], h1[kb][4 * q + t], z2[mt]);
               if (TAN) t2[mt] = MJX_MFMA(wc[mt][t], t1[kb][4 * q + t], t2[mt]);
             }
 #pragma unroll
@@ -377,7 +428,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
           for (int e = 0; e < R2; ++e) {
             const int idx = st * R2 + e, mt = idx >> 4, r = idx & 15;
-            h2[mt][r] = fast_tanh(z2[mt][r]);
+            if (FWD) h2[mt][r] = fast_tanh(z2[mt][r]);
             bufA[(32 * mt + unit_of(r, hi)) * ST + j] = h2[mt][r];
           }
 #pragma unroll
@@ -451,8 +502,28 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     MJX_STAMP(1);
     f32x16 h1[MT1], h2[MT2];
     f32x16 t1[MT1], t2[MT2];                        // tangent activations (FVP only)
+    if (MODE == MODE_FVP && CACHED) {
+#pragma unroll
+      for (int mt = 0; mt < MT1; ++mt) h1[mt] = hn1[mt];
+#pragma unroll
+      for (int mt = 0; mt < MT2; ++mt) h2[mt] = hn2[mt];
+    }
     if (MODE == MODE_FVP) layers12(std::true_type{}, slotA, trs, trs + NP, true, h1, h2, t1, t2);
     else layers12(std::false_type{}, slotA, trs, trs + NP, MODE != MODE_EVAL, h1, h2, t1, t2);
+    if (MODE == MODE_VPG && A.hcache) {
+      // keep h1 / h2 for the Fisher-vector products of this update (theta is fixed during CG)
+      float* base = A.hcache + tile * HC_TILE + lane * 4;
+#pragma unroll
+      for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(f32x4*)(base + (mt * 4 + q) * 256) = f32x4{h1[mt][4 * q], h1[mt][4 * q + 1], h1[mt][4 * q + 2], h1[mt][4 * q + 3]};
+#pragma unroll
+      for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(f32x4*)(base + ((MT1 + mt) * 4 + q) * 256) = f32x4{h2[mt][4 * q], h2[mt][4 * q + 1], h2[mt][4 * q + 2], h2[mt][4 * q + 3]};
+    }
 
     MJX_STAMP(6);
     float d3r[RA];                                  // cotangent on the pre-scale output, rows a = unit_of(r, hi)
@@ -485,12 +556,9 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       float d3a[MP];
 #pragma unroll
       for (int a = 0; a < MP; ++a) {
-        float osc = cst[C_OSC * MP + a];
-        float mudot = osc * (md[a] + slotB[L.oB3 + a]);             // + c3
-        float Dk = cst[C_DK * MP + a];
-        float dmu = valid ? Dk * mudot * A.inv_N : 0.f;
-        d3a[a] = osc * dmu;
-        if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0 && hi == 0) A.dbg[2048 * 4 + a * 32 + j] = mudot;
+        const f32x2 kc = *(const f32x2*)&cst[9 * MP + 2 * a];       // {c3[a], out_scale^2 * Dk / N}
+        d3a[a] = valid ? (md[a] + kc.x) * kc.y : 0.f;
+        if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0 && hi == 0) A.dbg[2048 * 4 + a * 32 + j] = cst[C_OSC * MP + a] * (md[a] + kc.x);
       }
 #pragma unroll
       for (int r = 0; r < RA; ++r) d3r[r] = hi ? d3a[unit_of(r, 1)] : d3a[unit_of(r, 0)];
@@ -614,6 +682,8 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dl2s[mt][r] *= fmaf(-h2[mt][r], h2[mt][r], 1.0f);
+      // h1 / h2 are dead from here on: fetch the next tile's copies behind the weight-gradient products
+      if (MODE == MODE_FVP && CACHED && tile + tstride < ntiles) load_h(tile + tstride);
       wave_sync();
       MJX_STAMP(9);
       // gW3[a][k] += sum_s d3[s][a] * h2[s][k]      (operands prefetched one group ahead)
@@ -766,8 +836,10 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     wave_sync();                                  // everything read before the next tile's staging
   }
 
+  MJX_GSTAMP(18);
   // ---------------- workgroup reduction + partial write ----------------
   __syncthreads();
+  MJX_GSTAMP(19);
   if (MODE != MODE_EVAL) {
     // log_std gradient: reduce over the 32 samples (lanes j) within each half (the halves own different actions)
     if (MODE == MODE_VPG) {
@@ -823,6 +895,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     for (int idx = tid; idx < fo.d; idx += 256)
       outp[idx] = (red[idx] + red[fo.d + idx]) + (red[2 * fo.d + idx] + red[3 * fo.d + idx]);
   }
+  MJX_GSTAMP(20);
   if (MODE != MODE_FVP) {
     // scalar partials: wave reduce (fp64) -> LDS -> one thread
 #pragma unroll

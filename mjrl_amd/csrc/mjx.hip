@@ -57,6 +57,9 @@ struct mjx_ctx {
   const float *theta_new = nullptr, *theta_old = nullptr, *tr_new = nullptr, *tr_old = nullptr;
   int old_is_new = 1;
   bool batch_bound = false;
+  float* hcache = nullptr; size_t hcache_bytes = 0;   // forward-activation cache of the fused path
+  bool hcache_valid = false; const float* hcache_obs = nullptr; int64_t hcache_rows = 0;
+  int use_hcache = 1;
   // workspace (device)
   float* partials = nullptr;       // [grid][d]
   double* spartials = nullptr;     // [grid][4]
@@ -79,10 +82,12 @@ int launch_fused(mjx_ctx* c, int mode, const FusedArgs& a, hipStream_t st) {
   FusedLayout<H1, H2, NT1, MP> L(c->n);
   size_t bytes = L.bytes();
   void (*k)(FusedArgs) = nullptr;
+  const bool cached = (mode == MODE_FVP) && a.hcache != nullptr && !DBG;
   if (mode == MODE_VPG) k = k_fused<H1, H2, NT1, MP, MODE_VPG, DBG, NPC>;
-  else if (mode == MODE_FVP) k = k_fused<H1, H2, NT1, MP, MODE_FVP, DBG, NPC>;
+  else if (mode == MODE_FVP) k = cached ? k_fused<H1, H2, NT1, MP, MODE_FVP, false, NPC, true> : k_fused<H1, H2, NT1, MP, MODE_FVP, DBG, NPC>;
   else k = k_fused<H1, H2, NT1, MP, MODE_EVAL, false, NPC>;
-  static thread_local const void* configured[3] = {nullptr, nullptr, nullptr};
+  if (cached) mode = 3;
+  static thread_local const void* configured[4] = {nullptr, nullptr, nullptr, nullptr};
   if (configured[mode] != (const void*)k) {
     HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     configured[mode] = (const void*)k;
@@ -146,6 +151,7 @@ FusedArgs make_args(mjx_ctx* c, const float* thetaB) {
   a.old_is_new = c->old_is_new;
   a.partials = c->partials; a.spartials = c->spartials;
   a.dbg = c->dbg;
+  a.hcache = nullptr;
   a.n = c->n; a.m = c->m;
   return a;
 }
@@ -190,6 +196,7 @@ int mjx_create(mjx_ctx** out, int device, int n, int m, const int* hidden, int n
   c->grid = c->n_cu;
   c->fused = pick_variant(n, m, c->hidden, d, &c->lds_bytes);
   if (const char* e = getenv("MJX_FORCE_LAYERWISE")) if (e[0] == '1') c->fused = 0;
+  if (const char* e = getenv("MJX_NO_HCACHE")) if (e[0] == '1') c->use_hcache = 0;
   HIPCHK(hipMalloc(&c->partials, (size_t)c->grid * d * sizeof(float)));
   HIPCHK(hipMalloc(&c->spartials, (size_t)c->grid * 4 * sizeof(double)));
   HIPCHK(hipMalloc(&c->cg_x, d * 4)); HIPCHK(hipMalloc(&c->cg_r, d * 4)); HIPCHK(hipMalloc(&c->cg_p, d * 4));
@@ -211,6 +218,7 @@ void mjx_destroy(mjx_ctx* c) {
   (void)hipSetDevice(c->device);
   c->lw.release();
   for (auto& e : c->prof_ev) hipEventDestroy(e);
+  hipFree(c->hcache);
   hipFree(c->partials); hipFree(c->spartials); hipFree(c->ident_tr);
   hipFree(c->cg_x); hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_z); hipFree(c->cg_Ap); hipFree(c->cg_scal);
   delete c;
@@ -232,6 +240,7 @@ int mjx_bind_batch(mjx_ctx* c, const float* obs, const float* act, const float* 
   if (((uintptr_t)obs & 15) != 0) return fail(MJX_ERR_ARG, "obs must be 16-byte aligned");
   c->obs = obs; c->act = act; c->adv = adv; c->N_local = N_local; c->N_global = N_global;
   c->batch_bound = true;
+  if (!(c->hcache_valid && obs == c->hcache_obs && N_local <= c->hcache_rows)) c->hcache_valid = false;
   c->lw.invalidate();
   if (!c->fused) { int rc = c->lw.reserve(N_local); if (rc) return fail(rc, "layer-wise workspace allocation failed"); }
   return MJX_OK;
@@ -240,9 +249,11 @@ int mjx_bind_batch(mjx_ctx* c, const float* obs, const float* act, const float* 
 int mjx_bind_policy(mjx_ctx* c, const float* theta_new, const float* theta_old, const float* tr_new,
                     const float* tr_old, int old_is_new) {
   if (!c || !theta_new || !theta_old) return fail(MJX_ERR_ARG, "bad policy");
+  if ((((uintptr_t)theta_new) | ((uintptr_t)theta_old)) & 15) return fail(MJX_ERR_ARG, "parameter vectors must be 16-byte aligned");
   c->theta_new = theta_new; c->theta_old = theta_old; c->tr_new = tr_new; c->tr_old = tr_old;
   c->old_is_new = old_is_new ? 1 : 0;
   c->lw.invalidate();
+  c->hcache_valid = false;
   return MJX_OK;
 }
 
@@ -466,6 +477,17 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
                           c->tr_new ? c->tr_new : c->ident_tr, c->tr_old ? c->tr_old : c->ident_tr, c->old_is_new,
                           grad_out, scal_out, st) ? fail(MJX_ERR_STATE, "layer-wise surr_vpg failed") : MJX_OK;
   FusedArgs a = make_args(c, c->theta_old);
+  c->hcache_valid = false;
+  if (c->use_hcache && c->old_is_new && c->hidden.size() == 2) {
+    // keep h1 / h2 of every sample for the Fisher-vector products of this update (theta is fixed during CG)
+    const size_t need = (size_t)((c->N_local + 31) / 32) * (size_t)(c->hidden[0] / 32 + c->hidden[1] / 32) * 4 * 64 * 4 * sizeof(float);
+    if (need > c->hcache_bytes) {
+      if (c->hcache) hipFree(c->hcache);
+      c->hcache = nullptr; c->hcache_bytes = 0;
+      if (hipMalloc(&c->hcache, need) == hipSuccess) c->hcache_bytes = need; else (void)hipGetLastError();
+    }
+    if (c->hcache) { a.hcache = c->hcache; c->hcache_valid = true; c->hcache_obs = c->obs; c->hcache_rows = c->N_local; }
+  }
   if (int rc = dispatch_fused(c, MODE_VPG, a, st)) return rc;
   hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
                      grad_out, (const float*)nullptr, (const float*)nullptr, c->oS, 0.f);
@@ -477,6 +499,7 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
 int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
   if (int rc = check_bound(c, false)) return rc;
   if (!v || !out) return fail(MJX_ERR_ARG, "null vector");
+  if (((uintptr_t)v) & 15) return fail(MJX_ERR_ARG, "v must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->device));
   if (c->N_local == 0) { HIPCHK(hipMemsetAsync(out, 0, c->d * sizeof(float), st)); return MJX_OK; }
@@ -496,6 +519,7 @@ int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
     return rc ? fail(MJX_ERR_STATE, "layer-wise fvp failed") : MJX_OK;
   }
   FusedArgs a = make_args(c, v);
+  if (c->hcache_valid) a.hcache = c->hcache;
   if (int rc = dispatch_fused(c, MODE_FVP, a, st)) return rc;
   if (prof) { HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], st)); c->prof_used += 2; }
   hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,

@@ -14,7 +14,9 @@ th = synth.perturbed_params(synth.init_params(n, m, hid))
 ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
 eng = UpdateEngine(n, m, hid)
 eng.set_policy(th, th, ident, ident)
-eng.set_batch(rng.randn(N, n).astype(np.float32))
+eng.set_batch(rng.randn(N, n).astype(np.float32), rng.randn(N, m).astype(np.float32), rng.randn(N).astype(np.float32))
+if os.environ.get('CACHED', '1') == '1':
+    eng.surr_vpg()          # fills the forward-activation cache -> the cached FVP instance runs
 dbg = eng.enable_debug()
 v = torch.from_numpy(rng.randn(th.size).astype(np.float32)).to(eng.device)
 for _ in range(3):
@@ -29,3 +31,7 @@ tot = st[13] - st[0]
 for i, x in enumerate(d):
     print("%-28s %7d cycles  %5.1f%%" % (names[i] if i < len(names) else i, x, 100.0 * x / tot))
 print("tile total", tot)
+
+g = dbg.cpu().numpy().view(np.int64)[16:21]
+print("kernel phases (block 0, thread 0): prologue %d, tile loop %d (wave 0), wait for other waves %d, reduce+write %d, total %d cycles"
+      % (g[1] - g[0], g[2] - g[1], g[3] - g[2], g[4] - g[3], g[4] - g[0]))
