@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-traj", type=int, default=200)
+    ap.add_argument("--rehearse-world", type=int, default=0,
+                    help="diagnostic, 1 GPU: run rank 0's share of an R-rank job (1/R of the batch, global N, "
+                         "RCCL collectives on a 1-rank group); the line is tagged 'rehearsal' and is not the metric")
     args = ap.parse_args()
 
     import torch
@@ -111,12 +114,20 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    shards = world
+    if args.rehearse_world > 1:
+        assert world == 1
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["MJX_COLLECTIVES_AT_WORLD1"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        shards = args.rehearse_world
 
     from mjrl_amd._lib import check
     from mjrl_amd.engine import UpdateEngine
 
     theta0 = initial_params()
-    obs, act, adv = synth_shard(rank, world)
+    obs, act, adv = synth_shard(rank, shards)
     # advantage whitening over the global batch (batch_reinforce.py:185); identical on all ranks
     s = torch.tensor([adv.sum(), float(adv.size)], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -131,7 +142,7 @@ def main():
     eng = UpdateEngine(N_OBS, N_ACT, HIDDEN)
     ident = np.concatenate([np.zeros(N_OBS), np.ones(N_OBS), np.zeros(N_ACT), np.ones(N_ACT)]).astype(np.float32)
     eng.set_policy(theta0, theta0, ident, ident)
-    eng.set_batch(obs, act, adv)                    # resident in HBM from here on
+    eng.set_batch(obs, act, adv, N_global=N_TRAJ * T if args.rehearse_world > 1 else None)   # resident in HBM from here on
     assert eng.N_global == N_TRAJ * T, eng.N_global
     theta0_dev = torch.from_numpy(theta0).to(eng.device)
     last = {}
@@ -215,11 +226,14 @@ def main():
                          "fvp_equivalent_TFLOPs_if_recomputed": flop_recompute * n_loc / (fvp_ms * 1e-3) / 1e12},
             "check": last,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.rehearse_world > 1:
+            out["rehearsal"] = "rank 0 of %d on one GPU, 1-rank RCCL group: NOT the metric" % args.rehearse_world
+            out["roofline"]["traffic"] = None
+        if world == 1 and not args.no_cpu_baseline and args.rehearse_world <= 1:
             out["cpu_baseline"] = cpu_baseline(theta0, args.cpu_sample_traj)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -80,6 +80,13 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return copysignf((1.0f - t) * r, x);
 }
 
+// x[lane] + x[lane ^ 32] in every lane: v_permlane32_swap exchanges the upper half of one copy with the
+// lower half of the other (one VALU op, no LDS round trip like ds_bpermute)
+__device__ __forceinline__ float half_sum(float p) {
+  auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+  return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+
 // unit index (within a 32-block) held by accumulator register r of lane-half hi
 __device__ __forceinline__ constexpr int unit_of(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -496,7 +503,36 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
       for (int gp = 0; gp < NGRP; ++gp)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { float p = og[gp][r]; o[4 * gp + r] = p + __shfl_xor(p, 32); }
+        for (int r = 0; r < 4; ++r) o[4 * gp + r] = half_sum(og[gp][r]);
+    };
+    // the same with two independent accumulator sets (out = Wa va + Wb vb): twice the distance between
+    // dependent 4x4x1 MFMAs, which otherwise stall on their own 8-cycle predecessors
+    auto out_small2 = [&](f32x4 (&oa)[NGRP], f32x4 (&ob)[NGRP], const float* sa, const f32x16 (&va)[MT2],
+                          const float* sb, const f32x16 (&vb)[MT2]) {
+      constexpr int NS4 = MT2 * 4;
+      const float* wa = &sa[L.oW3 + (lane & 3) * S3 + 4 * hi];
+      const float* wb = &sb[L.oW3 + (lane & 3) * S3 + 4 * hi];
+      f32x4 ac[NGRP], an[NGRP], bc[NGRP], bn[NGRP];
+#pragma unroll
+      for (int gp = 0; gp < NGRP; ++gp) { ac[gp] = *(const f32x4*)(wa + 4 * gp * S3); bc[gp] = *(const f32x4*)(wb + 4 * gp * S3); }
+#pragma unroll
+      for (int st = 0; st < NS4; ++st) {
+        const int mt = st >> 2, q = st & 3;
+        if (st + 1 < NS4) {
+          const int o1 = 32 * ((st + 1) >> 2) + 8 * ((st + 1) & 3);
+#pragma unroll
+          for (int gp = 0; gp < NGRP; ++gp) { an[gp] = *(const f32x4*)(wa + 4 * gp * S3 + o1); bn[gp] = *(const f32x4*)(wb + 4 * gp * S3 + o1); }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int gp = 0; gp < NGRP; ++gp) {
+            oa[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(ac[gp][t], va[mt][4 * q + t], oa[gp], 0, 0, 0);
+            ob[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(bc[gp][t], vb[mt][4 * q + t], ob[gp], 0, 0, 0);
+          }
+#pragma unroll
+        for (int gp = 0; gp < NGRP; ++gp) { ac[gp] = an[gp]; bc[gp] = bn[gp]; }
+      }
     };
 
     MJX_STAMP(1);
@@ -531,8 +567,14 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       f32x4 og[NGRP];
 #pragma unroll
       for (int gp = 0; gp < NGRP; ++gp) og[gp] = (f32x4)(0.f);
-      out_small(og, slotB, h2);                     // V3 h2
-      out_small(og, slotA, t2);                     // + W3 t2
+      {
+        f32x4 og2[NGRP];
+#pragma unroll
+        for (int gp = 0; gp < NGRP; ++gp) og2[gp] = (f32x4)(0.f);
+        out_small2(og, og2, slotB, h2, slotA, t2);  // V3 h2 + W3 t2
+#pragma unroll
+        for (int gp = 0; gp < NGRP; ++gp) og[gp] += og2[gp];
+      }
       MJX_STAMP(7);
       float md[MP];
       out_finish(og, md);
@@ -656,14 +698,16 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       //   delta2u, delta1u (lane = unit) feed the weight-gradient products as A operands.
 #pragma unroll
       for (int r = 0; r < RA; ++r) d3T[unit_of(r, hi) * ST + j] = d3r[r];
+      if (MODE != MODE_FVP) {                        // (the FVP's pass B already parked them)
 #pragma unroll
-      for (int mt = 0; mt < MT2; ++mt)
+        for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bufA[(32 * mt + unit_of(r, hi)) * ST + j] = h2[mt][r];
+          for (int r = 0; r < 16; ++r) bufA[(32 * mt + unit_of(r, hi)) * ST + j] = h2[mt][r];
 #pragma unroll
-      for (int mt = 0; mt < MT1; ++mt)
+        for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bufB[(32 * mt + unit_of(r, hi)) * ST + j] = h1[mt][r];
+          for (int r = 0; r < 16; ++r) bufB[(32 * mt + unit_of(r, hi)) * ST + j] = h1[mt][r];
+      }
       MJX_STAMP(8);
       // delta2 in both layouts: K = actions, the W3 column fragment serves as A (-> lane = sample) and as B (-> lane = unit)
       f32x16 dl2s[MT2], dl2u[MT2];
@@ -727,7 +771,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         float sacc = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc += dl2u[nt][r];
-        sb2[nt] += sacc + __shfl_xor(sacc, 32);
+        sb2[nt] += sacc;                            // the two lane halves are summed once, after the tile loop
       }
       MJX_STAMP(10);
       // gW2[u2][u1] += sum_s delta2[s][u2] * h1[s][u1]; delta1u = (delta2 W2)(1 - h1^2), lane = h1 unit.
@@ -878,9 +922,12 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         int a = unit_of(r, hi);
         if (a < m) mine[fo.W3 + a * H2 + 32 * nt + j] = gW3[nt][r];
       }
+    float sb2f[MT2];
+#pragma unroll
+    for (int nt = 0; nt < MT2; ++nt) sb2f[nt] = half_sum(sb2[nt]);
     if (hi == 0) {
 #pragma unroll
-      for (int nt = 0; nt < MT2; ++nt) mine[fo.b2 + 32 * nt + j] = sb2[nt];
+      for (int nt = 0; nt < MT2; ++nt) mine[fo.b2 + 32 * nt + j] = sb2f[nt];
     }
     if (lane < m) mine[fo.b3 + lane] = sb3;
     if (j == 0) {

@@ -11,6 +11,7 @@ sums) are all-reduced; CG scalars are recomputed redundantly on every rank from 
 vectors, so ranks stay in lock-step without further communication.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -19,8 +20,11 @@ from ._lib import check, ptr
 
 
 def _dist():
+    """torch.distributed when this process is one rank of several, else None.  MJX_COLLECTIVES_AT_WORLD1=1
+    keeps the collectives in the path for a 1-rank group (the RCCL rehearsal of bench.py --rehearse-world)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size() > 1 or os.environ.get("MJX_COLLECTIVES_AT_WORLD1") == "1"):
         return dist
     return None
 
