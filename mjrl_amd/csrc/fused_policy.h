@@ -266,10 +266,19 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   };
 
   // forward-activation cache (sample-lane accumulator layout, 16-byte granules: [tile][mt][q][lane][4])
-  constexpr int HC_TILE = (MT1 + MT2) * 4 * 64 * 4;           // floats per tile
+  // followed by the normalised observations as the layer-1 B-operand image [q][lane][2] = x~[sample j][4q + 2hi + {0,1}]
+  // (ones column and zero pad included), so the cached FVP neither stages nor normalises the tile again.
+  constexpr int HC_H = (MT1 + MT2) * 4 * 64 * 4;              // floats per tile: activations ...
+  const int HC_TILE = HC_H + (NP / 4) * 128;                  // ... + observation image
+  constexpr int NQC = NPC ? NPC / 4 : 1;
   f32x16 hn1[MT1], hn2[MT2];                                   // next tile's h1 / h2 (cached FVP)
+  f32x2 xcn[NQC];                                              // next tile's observation image (shape-specialised instance)
   auto load_h = [&](int64_t t) {
     const float* base = A.hcache + t * HC_TILE + lane * 4;
+    if (NPC) {
+#pragma unroll
+      for (int q = 0; q < NQC; ++q) xcn[q] = *(const f32x2*)(A.hcache + t * HC_TILE + HC_H + (q * 64 + lane) * 2);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
@@ -287,8 +296,9 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   };
 
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  if (tile < ntiles) load_x(tile);
-  if (MODE == MODE_FVP && CACHED && tile < ntiles) load_h(tile);
+  constexpr bool XCACHED = (MODE == MODE_FVP) && CACHED;      // observations come from the cache image
+  if (!XCACHED && tile < ntiles) load_x(tile);
+  if (XCACHED && tile < ntiles) load_h(tile);
 
   for (; tile < ntiles; tile += tstride) {
     const int64_t s0 = tile * 32;
@@ -296,14 +306,21 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     MJX_STAMP(0);
     // ---- 0. stage the tile's observations: xs is the raw memory image (sample-major, row stride n),
     // written with the same float4 granules it was fetched in.  Rows past the batch end are masked when read.
+    if (!XCACHED) {
 #pragma unroll
-    for (int c = 0; c < XL4; ++c) {
-      const int e4 = c * 64 + lane;
-      *(f32x4*)&xs[4 * ((e4 < 8 * n) ? e4 : 8 * n + lane)] = xr[c];   // out-of-range lanes hit the slack area
+      for (int c = 0; c < XL4; ++c) {
+        const int e4 = c * 64 + lane;
+        *(f32x4*)&xs[4 * ((e4 < 8 * n) ? e4 : 8 * n + lane)] = xr[c];   // out-of-range lanes hit the slack area
+      }
+      if (tile + tstride < ntiles) load_x(tile + tstride);
+      wave_sync();
     }
-    if (tile + tstride < ntiles) load_x(tile + tstride);
-    wave_sync();
 
+    f32x2 xc[NQC];                                  // this tile's observation image (cached FVP)
+    if (XCACHED) {
+#pragma unroll
+      for (int q = 0; q < NQC; ++q) xc[q] = xcn[q];
+    }
     // ---- layers 1 and 2 of one parameter set (and, for the FVP, the tangent pass riding on the
     // same operand fetches).  Every MFMA loop prefetches the next LDS operand group before issuing
     // the current group's MFMAs, so ds_read latency hides under the matrix pipe.
@@ -327,7 +344,18 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
           float v = (xs[j * n + fc] - tsh[fc]) / (tsc[fc] + 1e-8f);
           return (f < n) ? (valid ? v : 0.0f) : (f == n ? 1.0f : 0.0f);
         };
-        float xb0 = xnorm(f00), xb1 = xnorm(f00 + 1);
+        const float* ximg = A.hcache + tile * HC_TILE + HC_H + lane * 2;
+        // group q's pair of features for this lane: computed, or (cached FVP) read back as K1 stored it
+        auto xpair = [&](int q) {
+          if constexpr (TAN && CACHED) {
+            if constexpr (NPC != 0) return xc[q]; else return *(const f32x2*)(ximg + q * 128);
+          } else {
+            const int f = 4 * q + 2 * hi;
+            return f32x2{xnorm(f), xnorm(f + 1)};
+          }
+        };
+        f32x2 xb = xpair(0);
+        float xb0 = xb.x, xb1 = xb.y;
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt) {
           if (FWD) wc[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f00];
@@ -338,7 +366,9 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
           const int f0 = 4 * q + 2 * hi;
           const int f1 = (q + 1 < NP / 4) ? f0 + 4 : f0;        // next group (clamped on the last trip)
           f32x2 wn[MT1], vn[MT1];
-          const float xn0 = xnorm(f1), xn1 = xnorm(f1 + 1);
+          const f32x2 xnx = xpair((q + 1 < NP / 4) ? q + 1 : q);
+          const float xn0 = xnx.x, xn1 = xnx.y;
+          if (MODE == MODE_VPG && writeT && A.hcache) *(f32x2*)(A.hcache + tile * HC_TILE + HC_H + (q * 64 + lane) * 2) = f32x2{xb0, xb1};
 #pragma unroll
           for (int mt = 0; mt < MT1; ++mt) {
             if (FWD) wn[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f1];

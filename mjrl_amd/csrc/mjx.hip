@@ -480,7 +480,9 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
   c->hcache_valid = false;
   if (c->use_hcache && c->old_is_new && c->hidden.size() == 2) {
     // keep h1 / h2 of every sample for the Fisher-vector products of this update (theta is fixed during CG)
-    const size_t need = (size_t)((c->N_local + 31) / 32) * (size_t)(c->hidden[0] / 32 + c->hidden[1] / 32) * 4 * 64 * 4 * sizeof(float);
+    // per 32-sample tile: h1, h2 (sample-lane accumulator image) + the normalised observations (layer-1 operand image)
+    const size_t need = (size_t)((c->N_local + 31) / 32) *
+                        ((size_t)(c->hidden[0] / 32 + c->hidden[1] / 32) * 1024 + (size_t)(((c->n + 1 + 3) & ~3) / 4) * 128) * sizeof(float);
     if (need > c->hcache_bytes) {
       if (c->hcache) hipFree(c->hcache);
       c->hcache = nullptr; c->hcache_bytes = 0;
