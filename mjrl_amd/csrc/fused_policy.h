@@ -227,18 +227,20 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 
   MJX_GSTAMP(17);
   // ---------------- persistent accumulators ----------------
-  f32x16 gW1[MT1][NT1], gW2[MT2][MT1], gW3[MT2];
+  constexpr int NT3 = H2 / 16;                    // gW3 lives in 16x16 tiles: [action 4(l>>4)+r][unit 16nt + (l&15)]
+  f32x16 gW1[MT1][NT1], gW2[MT2][MT1];
+  f32x4 gW3[NT3];
   float sb2[MT2], sb3 = 0.f, gls[RA];     // grad b2[32*nt + j] (every lane), grad b3[lane], grad log_std[unit_of(r,hi)]
 #pragma unroll
   for (int a = 0; a < MT1; ++a)
 #pragma unroll
     for (int b = 0; b < NT1; ++b) gW1[a][b] = (f32x16)(0.f);
 #pragma unroll
-  for (int a = 0; a < MT2; ++a) {
-    gW3[a] = (f32x16)(0.f);
+  for (int a = 0; a < MT2; ++a)
 #pragma unroll
     for (int b = 0; b < MT1; ++b) gW2[a][b] = (f32x16)(0.f);
-  }
+#pragma unroll
+  for (int a = 0; a < NT3; ++a) gW3[a] = (f32x4)(0.f);
 #pragma unroll
   for (int a = 0; a < RA; ++a) gls[a] = 0.f;
 #pragma unroll
@@ -760,33 +762,39 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       if (MODE == MODE_FVP && CACHED && tile + tstride < ntiles) load_h(tile + tstride);
       wave_sync();
       MJX_STAMP(9);
-      // gW3[a][k] += sum_s d3[s][a] * h2[s][k]      (operands prefetched one group ahead)
+      // gW3[a][k] += sum_s d3[s][a] * h2[s][k] on v_mfma_f32_16x16x4_f32 (M = actions padded to 16, N = 16 units,
+      // K = 4 samples; 32 cycles each): half the matrix-pipe time of padding the actions to a 32-row tile.
+      // k-slot (l>>4) of step (half, t) carries sample 16 half + 4 (l>>4) + t, so one ds_read_b128 feeds 4 steps.
       {
-        const float* arow = &d3T[(j < MP ? j : 0) * ST + 4 * hi];
-        f32x4 ac = *(const f32x4*)arow, an, bc[MT2], bn[MT2];
+        const int u16 = lane & 15, kq = lane >> 4;
+        const float* arow = &d3T[(u16 < MP ? u16 : 0) * ST + 4 * kq];
+        f32x4 a4[2], b4[NT3][2];
 #pragma unroll
-        for (int nt = 0; nt < MT2; ++nt) bc[nt] = *(const f32x4*)&bufA[(32 * nt + j) * ST + 4 * hi];
+        for (int hf = 0; hf < 2; ++hf) {
+          a4[hf] = *(const f32x4*)(arow + 16 * hf);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (q + 1 < 4) {
-            an = *(const f32x4*)(arow + 8 * (q + 1));
+          for (int nt = 0; nt < NT3; ++nt) b4[nt][hf] = *(const f32x4*)&bufA[(16 * nt + u16) * ST + 16 * hf + 4 * kq];
+        }
+        // delta2u *= (1 - h2^2): h2[sample unit_of(4q+t, hi)][unit 32nt + j] from the [unit][sample] copy
+        f32x4 fc[MT2][4];
 #pragma unroll
-            for (int nt = 0; nt < MT2; ++nt) bn[nt] = *(const f32x4*)&bufA[(32 * nt + j) * ST + 8 * (q + 1) + 4 * hi];
-          }
-          f32x4 a4 = (j < MP) ? ac : (f32x4)(0.f);
+        for (int nt = 0; nt < MT2; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fc[nt][q] = *(const f32x4*)&bufA[(32 * nt + j) * ST + 8 * q + 4 * hi];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          if (u16 >= MP) a4[hf] = (f32x4)(0.f);
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int nt = 0; nt < MT2; ++nt) gW3[nt] = MJX_MFMA(a4[t], bc[nt][t], gW3[nt]);
-          // delta2u *= (1 - h2^2): bc[nt][t] is h2[sample unit_of(4q+t, hi)][unit 32nt + j], the matching element
-#pragma unroll
-          for (int nt = 0; nt < MT2; ++nt)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dl2u[nt][4 * q + t] *= fmaf(-bc[nt][t], bc[nt][t], 1.0f);
-          ac = an;
-#pragma unroll
-          for (int nt = 0; nt < MT2; ++nt) bc[nt] = bn[nt];
+            for (int nt = 0; nt < NT3; ++nt) gW3[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[hf][t], b4[nt][hf][t], gW3[nt], 0, 0, 0);
         }
+#pragma unroll
+        for (int nt = 0; nt < MT2; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dl2u[nt][4 * q + t] *= fmaf(-fc[nt][q][t], fc[nt][q][t], 1.0f);
       }
       if (lane < MP) {                              // grad b3[a] = sum_s d3[s][a]
 #pragma unroll
@@ -946,11 +954,11 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         for (int r = 0; r < 16; ++r)
           mine[fo.W2 + (32 * mt + unit_of(r, hi)) * H1 + 32 * nt + j] = gW2[mt][nt][r];
 #pragma unroll
-    for (int nt = 0; nt < MT2; ++nt)
+    for (int nt = 0; nt < NT3; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int a = unit_of(r, hi);
-        if (a < m) mine[fo.W3 + a * H2 + 32 * nt + j] = gW3[nt][r];
+      for (int r = 0; r < 4; ++r) {
+        int a = 4 * (lane >> 4) + r;
+        if (a < m) mine[fo.W3 + a * H2 + 16 * nt + (lane & 15)] = gW3[nt][r];
       }
     float sb2f[MT2];
 #pragma unroll
