@@ -75,6 +75,14 @@ int mjx_stream_sync(void* stream);
  * act / adv may be NULL when only mjx_fvp is used. */
 int mjx_bind_batch(mjx_ctx* ctx, const float* obs, const float* act, const float* adv,
                    int64_t N_local, int64_t N_global);
+
+/* Re-bind the leading N_local rows of the batch given to the last mjx_bind_batch (same storage, same
+ * contents), optionally with another advantage vector (NULL keeps the current one): DAPG evaluates the
+ * gradient on [on-policy ; demonstrations] and the Fisher / surrogate / KL on the on-policy prefix
+ * (mjrl/algos/dapg.py:92-106).  Unlike mjx_bind_batch this keeps what mjx_surr_vpg cached for the batch
+ * (forward activations for mjx_fvp, old-policy outputs for mjx_eval_surr_kl).  Changing the CONTENTS of
+ * the bound buffers requires a new mjx_bind_batch. */
+int mjx_bind_rows(mjx_ctx* ctx, int64_t N_local, int64_t N_global, const float* adv);
 /* theta_new / theta_old: flat parameter vectors (d floats each) of policy.model /
  * policy.old_model (+log_std); tr_new / tr_old: packed transforms (2n+2m floats)
  * or NULL for identity (parameter vectors 16-byte aligned).  old_is_new != 0 asserts both describe the same function

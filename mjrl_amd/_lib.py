@@ -29,6 +29,7 @@ PROTOTYPES = {
     "mjx_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mjx_stream_sync": (c_int, [c_void_p]),
     "mjx_bind_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
+    "mjx_bind_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
     "mjx_bind_policy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "mjx_surr_vpg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mjx_fvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

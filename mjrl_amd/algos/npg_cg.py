@@ -90,7 +90,7 @@ class NPG(BatchREINFORCE):
                 d.all_reduce(eng.Ap)
             be.cg_step(eng.Ap, damping, 1e-10)
         be.cg_finish(b, eng.x, eng.bdotx)
-        eng.bind_rows(Nl)
+        be.bind_batch(full[0], full[1], full[2], Nl, Ng)       # back to the whole shard
         return eng.x, float(eng.bdotx.item())
 
     # ------------------------------------------------------------------ update

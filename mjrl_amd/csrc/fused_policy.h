@@ -47,6 +47,9 @@ struct FusedArgs {
   double* spartials;     // [gridDim.x][4]
   float* dbg;            // optional dump of tile 0 (block 0, wave 0)
   float* hcache;         // forward-activation cache [tile][MT1+MT2][4][64 lanes][4]: written by MODE_VPG, read by cached FVP
+  float* ocache;         // old-policy outputs [tile][MP + 1][32]: mean per action + log-likelihood; written by MODE_VPG
+                         // (old == new), read by MODE_EVAL when thetaB / trB still equal `snap`
+  const float* snap;     // [d + 2n + 2m] parameters and transforms the ocache was computed with
   int n, m;
 };
 
@@ -56,7 +59,7 @@ struct FusedArgs {
 #define MJX_STAMP(k) do {} while (0)
 #endif
 #ifdef MJX_PHASE_CLOCK
-#define MJX_GSTAMP(k) do { if (A.dbg && blockIdx.x == 0 && threadIdx.x == 0) ((long long*)A.dbg)[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#define MJX_GSTAMP(k) do { if (A.dbg && blockIdx.x == 0 && threadIdx.x == 0) { ((long long*)A.dbg)[k] = (long long)__builtin_readcyclecounter(); ((long long*)A.dbg)[(k) + 8] = (long long)__builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define MJX_GSTAMP(k) do {} while (0)
 #endif
@@ -225,6 +228,27 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   }
   __syncthreads();
 
+  // MODE_EVAL: the old policy's per-sample outputs of this batch may still be around from MODE_VPG (same update);
+  // they are used only if the old parameters and transforms are bit-identical to the ones they were computed with.
+  bool use_oc = false;
+  if (MODE == MODE_EVAL && A.ocache) {
+    int mism = 0;
+    for (int idx = tid; idx < fo.d; idx += 256) mism |= (A.thetaB[idx] != A.snap[idx]);
+    for (int idx = tid; idx < 2 * (n + m); idx += 256) mism |= (A.trB[idx] != A.snap[fo.d + idx]);
+    // (flag word in wave 0's staging area, zero since the fill above and rewritten by the first tile's staging;
+    //  no __syncthreads_or: its static LDS word would not fit next to a 160 KB dynamic allocation)
+    if (mism) lds[L.oWAVES] = 1.0f;
+    __syncthreads();
+    use_oc = (lds[L.oWAVES] == 0.0f);
+    __syncthreads();
+  }
+  constexpr int OC_TILE = (MP + 1) * 32;
+  float ocn[MP + 1];                              // next tile's old-policy outputs (MODE_EVAL)
+  auto load_oc = [&](int64_t t) {
+#pragma unroll
+    for (int a = 0; a <= MP; ++a) ocn[a] = A.ocache[t * OC_TILE + a * 32 + j];
+  };
+
   MJX_GSTAMP(17);
   // ---------------- persistent accumulators ----------------
   constexpr int NT3 = H2 / 16;                    // gW3 lives in 16x16 tiles: [action 4(l>>4)+r][unit 16nt + (l&15)]
@@ -301,6 +325,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   constexpr bool XCACHED = (MODE == MODE_FVP) && CACHED;      // observations come from the cache image
   if (!XCACHED && tile < ntiles) load_x(tile);
   if (XCACHED && tile < ntiles) load_h(tile);
+  if (MODE == MODE_EVAL && use_oc && tile < ntiles) load_oc(tile);
 
   for (; tile < ntiles; tile += tstride) {
     const int64_t s0 = tile * 32;
@@ -663,7 +688,18 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       float llB = llA, muB[MP];
 #pragma unroll
       for (int a = 0; a < MP; ++a) muB[a] = muv[a];
-      if (MODE == MODE_EVAL || !A.old_is_new) {
+      if (MODE == MODE_VPG && A.ocache && A.old_is_new && hi == 0) {
+        float* oc = A.ocache + tile * OC_TILE + j;
+#pragma unroll
+        for (int a = 0; a < MP; ++a) oc[a * 32] = muv[a];
+        oc[MP * 32] = llA;
+      }
+      if (MODE == MODE_EVAL && use_oc) {
+#pragma unroll
+        for (int a = 0; a < MP; ++a) muB[a] = ocn[a];
+        llB = ocn[MP];
+        if (tile + tstride < ntiles) load_oc(tile + tstride);
+      } else if (MODE == MODE_EVAL || !A.old_is_new) {
         f32x16 g1[MT1], g2[MT2];
         layers12(std::false_type{}, slotB, trs + 2 * NP, trs + 3 * NP, false, g1, g2, t1, t2);
 #pragma unroll

@@ -60,6 +60,10 @@ struct mjx_ctx {
   float* hcache = nullptr; size_t hcache_bytes = 0;   // forward-activation cache of the fused path
   bool hcache_valid = false; const float* hcache_obs = nullptr; int64_t hcache_rows = 0;
   int use_hcache = 1;
+  float* ocache = nullptr; size_t ocache_bytes = 0;   // old-policy outputs of the batch (K1 -> K3)
+  float* snap = nullptr;                              // parameters + transforms they were computed with
+  bool ocache_valid = false; int64_t ocache_rows = 0;
+  int64_t rows_bound = 0;                             // rows handed to the last mjx_bind_batch
   // workspace (device)
   float* partials = nullptr;       // [grid][d]
   double* spartials = nullptr;     // [grid][4]
@@ -151,7 +155,7 @@ FusedArgs make_args(mjx_ctx* c, const float* thetaB) {
   a.old_is_new = c->old_is_new;
   a.partials = c->partials; a.spartials = c->spartials;
   a.dbg = c->dbg;
-  a.hcache = nullptr;
+  a.hcache = nullptr; a.ocache = nullptr; a.snap = nullptr;
   a.n = c->n; a.m = c->m;
   return a;
 }
@@ -219,6 +223,8 @@ void mjx_destroy(mjx_ctx* c) {
   c->lw.release();
   for (auto& e : c->prof_ev) hipEventDestroy(e);
   hipFree(c->hcache);
+  hipFree(c->ocache);
+  hipFree(c->snap);
   hipFree(c->partials); hipFree(c->spartials); hipFree(c->ident_tr);
   hipFree(c->cg_x); hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_z); hipFree(c->cg_Ap); hipFree(c->cg_scal);
   delete c;
@@ -240,9 +246,20 @@ int mjx_bind_batch(mjx_ctx* c, const float* obs, const float* act, const float* 
   if (((uintptr_t)obs & 15) != 0) return fail(MJX_ERR_ARG, "obs must be 16-byte aligned");
   c->obs = obs; c->act = act; c->adv = adv; c->N_local = N_local; c->N_global = N_global;
   c->batch_bound = true;
-  if (!(c->hcache_valid && obs == c->hcache_obs && N_local <= c->hcache_rows)) c->hcache_valid = false;
+  c->rows_bound = N_local;
+  c->hcache_valid = false;                      // a new batch: nothing cached from earlier calls applies
+  c->ocache_valid = false;
   c->lw.invalidate();
   if (!c->fused) { int rc = c->lw.reserve(N_local); if (rc) return fail(rc, "layer-wise workspace allocation failed"); }
+  return MJX_OK;
+}
+
+int mjx_bind_rows(mjx_ctx* c, int64_t N_local, int64_t N_global, const float* adv) {
+  if (!c || !c->batch_bound) return fail(MJX_ERR_STATE, "mjx_bind_batch has not been called");
+  if (N_local < 0 || N_local > c->rows_bound || N_global < N_local || N_global <= 0) return fail(MJX_ERR_ARG, "bad row count");
+  c->N_local = N_local; c->N_global = N_global;
+  if (adv) c->adv = adv;
+  c->lw.invalidate();
   return MJX_OK;
 }
 
@@ -489,6 +506,21 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
       if (hipMalloc(&c->hcache, need) == hipSuccess) c->hcache_bytes = need; else (void)hipGetLastError();
     }
     if (c->hcache) { a.hcache = c->hcache; c->hcache_valid = true; c->hcache_obs = c->obs; c->hcache_rows = c->N_local; }
+    // ... and the old policy's means / log-likelihoods for mjx_eval_surr_kl (old == new here), with a snapshot of
+    // the parameters they belong to (the EVAL kernel compares before trusting them)
+    const size_t oneed = (size_t)((c->N_local + 31) / 32) * 17 * 32 * sizeof(float);
+    if (oneed > c->ocache_bytes) {
+      if (c->ocache) hipFree(c->ocache);
+      c->ocache = nullptr; c->ocache_bytes = 0;
+      if (hipMalloc(&c->ocache, oneed) == hipSuccess) c->ocache_bytes = oneed; else (void)hipGetLastError();
+    }
+    if (!c->snap && hipMalloc(&c->snap, (size_t)(c->d + 2 * (c->n + c->m)) * sizeof(float)) != hipSuccess) { c->snap = nullptr; (void)hipGetLastError(); }
+    c->ocache_valid = false;
+    if (c->ocache && c->snap) {
+      HIPCHK(hipMemcpyAsync(c->snap, c->theta_old, c->d * sizeof(float), hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(c->snap + c->d, a.trB, 2 * (c->n + c->m) * sizeof(float), hipMemcpyDeviceToDevice, st));
+      a.ocache = c->ocache; c->ocache_valid = true; c->ocache_rows = c->N_local;
+    }
   }
   if (int rc = dispatch_fused(c, MODE_VPG, a, st)) return rc;
   hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
@@ -521,7 +553,7 @@ int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
     return rc ? fail(MJX_ERR_STATE, "layer-wise fvp failed") : MJX_OK;
   }
   FusedArgs a = make_args(c, v);
-  if (c->hcache_valid) a.hcache = c->hcache;
+  if (c->hcache_valid && c->N_local <= c->hcache_rows) a.hcache = c->hcache;
   if (int rc = dispatch_fused(c, MODE_FVP, a, st)) return rc;
   if (prof) { HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], st)); c->prof_used += 2; }
   hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
@@ -541,6 +573,7 @@ int mjx_eval_surr_kl(mjx_ctx* c, double* scal_out, void* stream) {
                       c->tr_new ? c->tr_new : c->ident_tr, c->tr_old ? c->tr_old : c->ident_tr, scal_out, st)
                ? fail(MJX_ERR_STATE, "layer-wise eval failed") : MJX_OK;
   FusedArgs a = make_args(c, c->theta_old);
+  if (c->ocache_valid && c->N_local <= c->ocache_rows) { a.ocache = c->ocache; a.snap = c->snap; }
   if (int rc = dispatch_fused(c, MODE_EVAL, a, st)) return rc;
   hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, c->grid, scal_out);
   HIPCHK(hipGetLastError());
@@ -556,8 +589,12 @@ int mjx_cg_init(mjx_ctx* c, const float* b, void* stream) {
 const float* mjx_cg_p(mjx_ctx* c) { return c ? c->cg_p : nullptr; }
 int mjx_cg_step(mjx_ctx* c, const float* Ap, float damping, double tol, void* stream) {
   if (!c || !Ap) return fail(MJX_ERR_ARG, "bad arguments");
-  hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(1024), 0, (hipStream_t)stream, Ap, damping, tol, c->cg_x, c->cg_r, c->cg_p,
-                     c->cg_z, c->cg_scal, (int)c->d);
+  if (c->d <= 8 * 1024)
+    hipLaunchKernelGGL(k_cg_step_reg<8>, dim3(1), dim3(1024), 0, (hipStream_t)stream, Ap, damping, tol, c->cg_x, c->cg_r, c->cg_p,
+                       c->cg_scal, (int)c->d);
+  else
+    hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(1024), 0, (hipStream_t)stream, Ap, damping, tol, c->cg_x, c->cg_r, c->cg_p,
+                       c->cg_z, c->cg_scal, (int)c->d);
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }

@@ -20,13 +20,9 @@ __device__ __forceinline__ double block_sum(double v, double* sh /* >= 17 double
   __syncthreads();
   if (lane == 0) sh[w] = v;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0;
-    for (int i = 0; i < nw; ++i) t += sh[i];
-    sh[16] = t;
-  }
-  __syncthreads();
-  return sh[16];
+  double t = 0;                                   // every thread sums the wave totals in the same fixed order
+  for (int i = 0; i < nw; ++i) t += sh[i];
+  return t;
 }
 
 // out[c] = sum_g partials[g][c]  (fp64 accumulate, fixed order).  16 columns x 16 row-groups per
@@ -107,6 +103,50 @@ __global__ __launch_bounds__(1024) void k_cg_step(const float* __restrict__ Ap, 
   nrr = block_sum(nrr, sh);
   const float mu = (float)(nrr / rr);
   for (int i = threadIdx.x; i < d; i += blockDim.x) p[i] = fmaf(mu, p[i], r[i]);
+  if (threadIdx.x == 0) {
+    scal[0] = nrr; scal[2] = pz; scal[3] += 1.0;
+    if (nrr < tol) scal[1] = 1.0;
+  }
+}
+
+// the same step for d <= 1024 * EPT with every vector element held in registers: one round of loads, two block
+// reductions, one round of stores (the looped version above pays a global round trip per phase).  Same arithmetic.
+template <int EPT>
+__global__ __launch_bounds__(1024) void k_cg_step_reg(const float* __restrict__ Ap, float damping, double tol,
+                                                       float* x, float* r, float* p, double* scal, int d) {
+  __shared__ double sh[17];
+  const double done = scal[1], rr = scal[0];
+  float ap[EPT], pv[EPT], xv[EPT], rv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = threadIdx.x + e * 1024;
+    const int ic = i < d ? i : 0;
+    ap[e] = Ap[ic]; pv[e] = p[ic]; xv[e] = x[ic]; rv[e] = r[ic];
+  }
+  if (done != 0.0) return;                          // converged earlier: cg_solve.py:19-20 `break`
+  double pz = 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const float zi = ap[e] + damping * pv[e];       // npg_cg.py:81  hvp_flat + regu_coef*vector
+    ap[e] = zi;
+    if (threadIdx.x + e * 1024 < d) pz += (double)pv[e] * (double)zi;
+  }
+  pz = block_sum(pz, sh);
+  const float alpha = (float)(rr / pz);
+  double nrr = 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    xv[e] = fmaf(alpha, pv[e], xv[e]);
+    rv[e] = fmaf(-alpha, ap[e], rv[e]);
+    if (threadIdx.x + e * 1024 < d) nrr += (double)rv[e] * (double)rv[e];
+  }
+  nrr = block_sum(nrr, sh);
+  const float mu = (float)(nrr / rr);
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = threadIdx.x + e * 1024;
+    if (i < d) { x[i] = xv[e]; r[i] = rv[e]; p[i] = fmaf(mu, pv[e], rv[e]); }
+  }
   if (threadIdx.x == 0) {
     scal[0] = nrr; scal[2] = pz; scal[3] += 1.0;
     if (nrr < tol) scal[1] = 1.0;

@@ -77,6 +77,9 @@ class HipBackend:
     def bind_batch(self, obs, act, adv, rows, N_global):
         check(self.lib.mjx_bind_batch(self.ctx, ptr(obs), ptr(act), ptr(adv), int(rows), int(N_global)))
 
+    def bind_rows(self, rows, N_global, adv=None):
+        check(self.lib.mjx_bind_rows(self.ctx, int(rows), int(N_global), ptr(adv)))
+
     def surr_vpg(self, grad_out, scal_out):
         check(self.lib.mjx_surr_vpg(self.ctx, ptr(grad_out), ptr(scal_out), self.stream()))
 
@@ -190,7 +193,7 @@ class UpdateEngine:
         self.adv = None if adv is None else self.to_device_f32(adv)
         self.N_local = int(self.obs.shape[0])
         self.N_global = self.global_count(self.N_local) if N_global is None else int(N_global)
-        self.bind_rows(self.N_local)
+        self.backend.bind_batch(self.obs, self.act, self.adv, self.N_local, int(self.N_global))
 
     def bind_rows(self, rows, adv=None, N_global=None):
         """(re)bind the first `rows` samples of the uploaded block (DAPG runs the Fisher on the
@@ -199,7 +202,7 @@ class UpdateEngine:
             self.adv = self.to_device_f32(adv)
         if N_global is not None:
             self.N_global = int(N_global)
-        self.backend.bind_batch(self.obs, self.act, self.adv, int(rows), int(self.N_global))
+        self.backend.bind_rows(int(rows), int(self.N_global), self.adv)
 
     # ------------------------------------------------------------------ kernels + collectives
     def surr_vpg(self):

@@ -37,7 +37,13 @@ class OracleBackend:
     def bind_policy(self, theta_new, theta_old, tr_new, tr_old, old_is_new):
         self.tn, self.to, self.trn, self.tro, self.same = theta_new, theta_old, tr_new, tr_old, old_is_new
 
-    def bind_batch(self, obs, act, adv, rows, N_global):
+    def bind_rows(self, rows, N_global, adv=None):
+        obs, act, adv0 = self._full
+        self.bind_batch(obs, act, adv0 if adv is None else adv, rows, N_global, keep=True)
+
+    def bind_batch(self, obs, act, adv, rows, N_global, keep=False):
+        if not keep:
+            self._full = (obs, act, adv)
         self.obs = obs[:rows].numpy().astype(np.float64)
         self.act = None if act is None else act[:rows].numpy().astype(np.float64)
         self.adv = None if adv is None else adv[:rows].numpy().astype(np.float64)

@@ -531,3 +531,62 @@ def test_empty_shard_contributes_zero():
         assert float(eng.fvp(torch.ones(th.size, device=eng.device)).abs().max()) == 0.0
         assert eng.eval_surr_kl() == (0.0, 0.0)
         eng.close()
+
+
+def test_eval_reuses_old_policy_outputs_only_when_unchanged():
+    """K3 after K1 takes the old policy's means / log-likelihoods from what K1 stored -- but only while the
+    old parameters still equal the snapshot taken then; an in-place change of theta_old must be noticed by
+    the kernel itself (it compares before trusting), and mjx_bind_batch drops the stored outputs."""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    n, m, hid, N = 17, 6, (64, 64), 4000 + 13
+    rng = np.random.RandomState(11)
+    obs, act, adv = rng.randn(N, n), rng.randn(N, m), rng.randn(N)
+    th = synth.perturbed_params(synth.init_params(n, m, hid))
+    step = (0.02 * rng.randn(th.size)).astype(np.float32)
+    ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    tr64 = O.Transforms(n, m)
+
+    def truth(t_new, t_old):
+        s = O.surrogate(t_new.astype(np.float64), t_old.astype(np.float64), obs, act, adv, n, m, hid, tr64, tr64)
+        k = O.mean_kl(t_new.astype(np.float64), t_old.astype(np.float64), obs, n, m, hid, tr64, tr64)
+        return s, k
+
+    eng = UpdateEngine(n, m, hid)
+    eng.set_policy(th, th, ident, ident)
+    eng.set_batch(obs, act, adv)
+    eng.surr_vpg()                                        # K1: stores the old-policy outputs + parameter snapshot
+    eng.theta_new.copy_(torch.from_numpy(th + step).to(eng.device))
+    eng.old_is_new = False
+    eng._bind_policy()
+    s1, k1 = eng.eval_surr_kl()                           # uses the stored outputs
+    st, kt = truth(th + step, th)
+    assert abs(s1 - st) < 2e-6 and abs(k1 - kt) < 1e-5 * kt
+    # now move theta_old in place: the stored outputs are stale, the kernel has to recompute the old forward
+    th_old2 = (th - step).astype(np.float32)
+    eng.theta_old.copy_(torch.from_numpy(th_old2).to(eng.device))
+    s2, k2 = eng.eval_surr_kl()
+    st2, kt2 = truth(th + step, th_old2)
+    assert abs(s2 - st2) < 2e-6 and abs(k2 - kt2) < 1e-5 * kt2
+    assert abs(k2 - k1) > 1e-3 * kt                        # (the two situations really differ)
+    # prefix re-binding keeps the stored outputs valid for the leading rows
+    eng.theta_old.copy_(torch.from_numpy(th).to(eng.device))
+    Np = 2500
+    eng.bind_rows(Np, N_global=Np)
+    s3, k3 = eng.eval_surr_kl()
+    s3t = O.surrogate((th + step).astype(np.float64), th.astype(np.float64), obs[:Np], act[:Np], adv[:Np], n, m, hid, tr64, tr64)
+    k3t = O.mean_kl((th + step).astype(np.float64), th.astype(np.float64), obs[:Np], n, m, hid, tr64, tr64)
+    assert abs(s3 - s3t) < 2e-6 and abs(k3 - k3t) < 1e-5 * k3t
+    # a new batch in the same engine: nothing stored applies any more
+    obs2 = rng.randn(N, n)
+    eng.set_batch(obs2, act, adv)
+    s4, k4 = eng.eval_surr_kl()
+    s4t = O.surrogate((th + step).astype(np.float64), th.astype(np.float64), obs2, act, adv, n, m, hid, tr64, tr64)
+    assert abs(s4 - s4t) < 2e-6
+    # ... and the Fisher-vector product after a new batch must not read the previous batch's activations
+    eng.theta_new.copy_(torch.from_numpy(th).to(eng.device)); eng.old_is_new = True; eng._bind_policy()
+    v = rng.randn(th.size).astype(np.float32)
+    hv = eng.fvp(torch.from_numpy(v).to(eng.device)).cpu().numpy()
+    hvt = O.fvp(th.astype(np.float64), obs2, v.astype(np.float64), n, m, hid, tr64)
+    assert rel(hv, hvt) < TOL_FVP
+    eng.close()

@@ -35,3 +35,7 @@ print("tile total", tot)
 g = dbg.cpu().numpy().view(np.int64)[16:21]
 print("kernel phases (block 0, thread 0): prologue %d, tile loop %d (wave 0), wait for other waves %d, reduce+write %d, total %d cycles"
       % (g[1] - g[0], g[2] - g[1], g[3] - g[2], g[4] - g[3], g[4] - g[0]))
+
+rt = dbg.cpu().numpy().view(np.int64)[24:29]
+us = (rt[4] - rt[0]) / 100.0          # s_memrealtime ticks at 100 MHz
+print("block 0 wall time %.1f us -> shader clock %.3f GHz" % (us, (g[4] - g[0]) / us / 1e3))
