@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmjx.so")
+LIB_PATH = os.environ.get("MJX_LIB") or os.path.join(_HERE, "csrc", "libmjx.so")   # MJX_LIB: A/B builds (tools/)
 
 c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 

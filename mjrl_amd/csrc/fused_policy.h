@@ -90,6 +90,12 @@ __device__ __forceinline__ float half_sum(float p) {
   return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<N, I + 1>(f); }
+}
+
 // unit index (within a 32-block) held by accumulator register r of lane-half hi
 __device__ __forceinline__ constexpr int unit_of(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -297,13 +303,15 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   constexpr int HC_H = (MT1 + MT2) * 4 * 64 * 4;              // floats per tile: activations ...
   const int HC_TILE = HC_H + (NP / 4) * 128;                  // ... + observation image
   constexpr int NQC = NPC ? NPC / 4 : 1;
-  f32x16 hn1[MT1], hn2[MT2];                                   // next tile's h1 / h2 (cached FVP)
-  f32x2 xcn[NQC];                                              // next tile's observation image (shape-specialised instance)
+  // cached FVP: h1 / h2 / observation image of the tile being processed.  The next tile's copies are fetched into the
+  // same registers as soon as the current ones are dead (behind the weight-gradient products), so nothing is copied.
+  f32x16 hn1[MT1], hn2[MT2];
+  f32x2 xc[NQC];
   auto load_h = [&](int64_t t) {
     const float* base = A.hcache + t * HC_TILE + lane * 4;
     if (NPC) {
 #pragma unroll
-      for (int q = 0; q < NQC; ++q) xcn[q] = *(const f32x2*)(A.hcache + t * HC_TILE + HC_H + (q * 64 + lane) * 2);
+      for (int q = 0; q < NQC; ++q) xc[q] = *(const f32x2*)(A.hcache + t * HC_TILE + HC_H + (q * 64 + lane) * 2);
     }
 #pragma unroll
     for (int mt = 0; mt < MT1; ++mt)
@@ -343,11 +351,6 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       wave_sync();
     }
 
-    f32x2 xc[NQC];                                  // this tile's observation image (cached FVP)
-    if (XCACHED) {
-#pragma unroll
-      for (int q = 0; q < NQC; ++q) xc[q] = xcn[q];
-    }
     // ---- layers 1 and 2 of one parameter set (and, for the FVP, the tangent pass riding on the
     // same operand fetches).  Every MFMA loop prefetches the next LDS operand group before issuing
     // the current group's MFMAs, so ds_read latency hides under the matrix pipe.
@@ -531,29 +534,48 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     // Output layer (M = #actions is tiny) on v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer-product
     // blocks per instruction; lane l = (block l/4, column l%4) gets D[r][l%4] += A[4*(l/4)+r] * B[l].
     // Here block = the lane's sample quad, B = the lane's own activation register (unit k of its half),
-    // A = W[a = 4*grp + (l&3)][k]: each lane accumulates og[grp][r] = partial out[a = 4*grp + r] of ITS
+    // A = W[a = 4*grp + r][k]: each lane accumulates og[grp][r] = partial out[a = 4*grp + r] of ITS
     // sample over the 32 units its half owns.  8 cycles per instruction instead of padding M to 32.
+    // The A values are the same for all 8 blocks of a lane half, so they are fetched ONCE per tile: block b
+    // of a half keeps the fragment of k-step group (mt, q) = (b >> 2, b & 3) and the instruction's A-broadcast
+    // control (cbsz = 3, abid = b) hands it to the other 7 blocks -- 1 ds_read_b128 per (matrix, grp) and
+    // tile instead of one per 4 MFMAs.
     constexpr int NGRP = MP / 4;
+    auto out_frag = [&](f32x4 (&w)[NGRP], const float* slot) {
+      const int b = (lane >> 2) & 7;
+      const float* wbase = &slot[L.oW3 + (lane & 3) * S3 + 32 * ((b >> 2) % MT2) + 8 * (b & 3) + 4 * hi];
+#pragma unroll
+      for (int gp = 0; gp < NGRP; ++gp) w[gp] = *(const f32x4*)(wbase + 4 * gp * S3);
+    };
     auto out_small = [&](f32x4 (&og)[NGRP], const float* slot, const f32x16 (&v)[MT2]) {
-      constexpr int NS4 = MT2 * 4;
-      const float* wbase = &slot[L.oW3 + (lane & 3) * S3 + 4 * hi];
-      f32x4 wc[NGRP], wn[NGRP];
-#pragma unroll
-      for (int gp = 0; gp < NGRP; ++gp) wc[gp] = *(const f32x4*)(wbase + 4 * gp * S3);
-#pragma unroll
-      for (int st = 0; st < NS4; ++st) {
-        const int mt = st >> 2, q = st & 3;
-        if (st + 1 < NS4) {
-#pragma unroll
-          for (int gp = 0; gp < NGRP; ++gp) wn[gp] = *(const f32x4*)(wbase + 4 * gp * S3 + 32 * ((st + 1) >> 2) + 8 * ((st + 1) & 3));
-        }
+      f32x4 w[NGRP];
+      out_frag(w, slot);
+      static_for<MT2 * 4>([&](auto st) {
+        constexpr int mt = decltype(st)::value >> 2, q = decltype(st)::value & 3;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int gp = 0; gp < NGRP; ++gp) og[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[gp][t], v[mt][4 * q + t], og[gp], 0, 0, 0);
+          for (int gp = 0; gp < NGRP; ++gp)
+            og[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[gp][t], v[mt][4 * q + t], og[gp], 3, mt * 4 + q, 0);
+      });
+    };
+    // the same with two independent accumulator sets (out = Wa va + Wb vb): twice the distance between
+    // dependent 4x4x1 MFMAs, which otherwise stall on their own 8-cycle predecessors
+    auto out_small2 = [&](f32x4 (&oa)[NGRP], f32x4 (&ob)[NGRP], const float* sa, const f32x16 (&va)[MT2],
+                          const float* sb, const f32x16 (&vb)[MT2]) {
+      f32x4 wa[NGRP], wb[NGRP];
+      out_frag(wa, sa);
+      out_frag(wb, sb);
+      static_for<MT2 * 4>([&](auto st) {
+        constexpr int mt = decltype(st)::value >> 2, q = decltype(st)::value & 3;
 #pragma unroll
-        for (int gp = 0; gp < NGRP; ++gp) wc[gp] = wn[gp];
-      }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int gp = 0; gp < NGRP; ++gp) {
+            oa[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[gp][t], va[mt][4 * q + t], oa[gp], 3, mt * 4 + q, 0);
+            ob[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[gp][t], vb[mt][4 * q + t], ob[gp], 3, mt * 4 + q, 0);
+          }
+      });
     };
     // both lane halves end up with the full sums for all MP actions
     auto out_finish = [&](f32x4 (&og)[NGRP], float (&o)[MP]) {
@@ -562,45 +584,12 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[4 * gp + r] = half_sum(og[gp][r]);
     };
-    // the same with two independent accumulator sets (out = Wa va + Wb vb): twice the distance between
-    // dependent 4x4x1 MFMAs, which otherwise stall on their own 8-cycle predecessors
-    auto out_small2 = [&](f32x4 (&oa)[NGRP], f32x4 (&ob)[NGRP], const float* sa, const f32x16 (&va)[MT2],
-                          const float* sb, const f32x16 (&vb)[MT2]) {
-      constexpr int NS4 = MT2 * 4;
-      const float* wa = &sa[L.oW3 + (lane & 3) * S3 + 4 * hi];
-      const float* wb = &sb[L.oW3 + (lane & 3) * S3 + 4 * hi];
-      f32x4 ac[NGRP], an[NGRP], bc[NGRP], bn[NGRP];
-#pragma unroll
-      for (int gp = 0; gp < NGRP; ++gp) { ac[gp] = *(const f32x4*)(wa + 4 * gp * S3); bc[gp] = *(const f32x4*)(wb + 4 * gp * S3); }
-#pragma unroll
-      for (int st = 0; st < NS4; ++st) {
-        const int mt = st >> 2, q = st & 3;
-        if (st + 1 < NS4) {
-          const int o1 = 32 * ((st + 1) >> 2) + 8 * ((st + 1) & 3);
-#pragma unroll
-          for (int gp = 0; gp < NGRP; ++gp) { an[gp] = *(const f32x4*)(wa + 4 * gp * S3 + o1); bn[gp] = *(const f32x4*)(wb + 4 * gp * S3 + o1); }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int gp = 0; gp < NGRP; ++gp) {
-            oa[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(ac[gp][t], va[mt][4 * q + t], oa[gp], 0, 0, 0);
-            ob[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(bc[gp][t], vb[mt][4 * q + t], ob[gp], 0, 0, 0);
-          }
-#pragma unroll
-        for (int gp = 0; gp < NGRP; ++gp) { ac[gp] = an[gp]; bc[gp] = bn[gp]; }
-      }
-    };
 
     MJX_STAMP(1);
-    f32x16 h1[MT1], h2[MT2];
+    f32x16 h1l[MT1], h2l[MT2];
+    f32x16 (&h1)[MT1] = XCACHED ? hn1 : h1l;
+    f32x16 (&h2)[MT2] = XCACHED ? hn2 : h2l;
     f32x16 t1[MT1], t2[MT2];                        // tangent activations (FVP only)
-    if (MODE == MODE_FVP && CACHED) {
-#pragma unroll
-      for (int mt = 0; mt < MT1; ++mt) h1[mt] = hn1[mt];
-#pragma unroll
-      for (int mt = 0; mt < MT2; ++mt) h2[mt] = hn2[mt];
-    }
     if (MODE == MODE_FVP) layers12(std::true_type{}, slotA, trs, trs + NP, true, h1, h2, t1, t2);
     else layers12(std::false_type{}, slotA, trs, trs + NP, MODE != MODE_EVAL, h1, h2, t1, t2);
     if (MODE == MODE_VPG && A.hcache) {
