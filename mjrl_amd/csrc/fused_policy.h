@@ -169,6 +169,50 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 
   MJX_GSTAMP(16);
   // ---------------- stage weights (whole workgroup) ----------------
+  // Every global value is requested first (one batch of independent loads per thread), the LDS zero-fill runs
+  // while they are in flight, then the values are scattered to their padded LDS rows: one memory round trip for
+  // the whole prologue instead of one per staging loop.
+  constexpr bool XCACHED = (MODE == MODE_FVP) && CACHED;      // observations / activations come from the K1 cache
+  constexpr int C1 = NPC ? NPC / 4 : 8 * NT1;                 // W1a: 4 threads per row, features p, p + 4, ...
+  constexpr int C2 = (H2 * H1 / 4 + 255) / 256;               // W2: 16-byte granules (rows are 16-byte aligned in theta)
+  constexpr int C3 = (MP * H2 + 255) / 256;
+  const int u1 = tid >> 2, p1 = tid & 3;
+  float w1r[2][C1], w3r[2][C3], b2r[2], b3r[2], trr[4], csr[7];
+  f32x4 w2r[2][C2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float* th = s ? A.thetaB : A.thetaA;
+    if (!(XCACHED && s == 0)) {                               // (the cached FVP never reads W1a of the parameter slot)
+#pragma unroll
+      for (int c = 0; c < C1; ++c) {
+        const int f = p1 + 4 * c;
+        const bool ok = (u1 < H1) && (f <= n);
+        w1r[s][c] = th[ok ? ((f < n) ? fo.W1 + u1 * n + f : fo.b1 + u1) : 0];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C2; ++c) { const int i4 = c * 256 + tid; w2r[s][c] = *(const f32x4*)&th[fo.W2 + 4 * (i4 < H2 * H1 / 4 ? i4 : 0)]; }
+#pragma unroll
+    for (int c = 0; c < C3; ++c) { const int idx = c * 256 + tid; w3r[s][c] = th[fo.W3 + (idx < m * H2 ? idx : 0)]; }
+    b2r[s] = th[fo.b2 + (tid < H2 ? tid : 0)];
+    b3r[s] = th[fo.b3 + (tid < m ? tid : 0)];
+  }
+  {
+    const int i = tid < n ? tid : 0;
+    trr[0] = A.trA[i]; trr[1] = A.trA[n + i]; trr[2] = A.trB[i]; trr[3] = A.trB[n + i];
+    const int a = tid < m ? tid : 0;
+    csr[0] = A.thetaA[fo.S + a]; csr[1] = A.thetaB[fo.S + a];
+    csr[2] = A.trA[2 * n + m + a]; csr[3] = A.trA[2 * n + a];
+    csr[4] = A.trB[2 * n + m + a]; csr[5] = A.trB[2 * n + a];
+    csr[6] = A.thetaB[fo.b3 + a];
+  }
+  // MODE_EVAL: the old policy's per-sample outputs of this batch may still be around from MODE_VPG (same update);
+  // they are used only if the old parameters and transforms are bit-identical to the ones they were computed with.
+  int mism = 0;
+  if (MODE == MODE_EVAL && A.ocache) {
+    for (int idx = tid; idx < fo.d; idx += 256) mism |= (A.thetaB[idx] != A.snap[idx]);
+    for (int idx = tid; idx < 2 * (n + m); idx += 256) mism |= (A.trB[idx] != A.snap[fo.d + idx]);
+  }
   // zero what is read before (or without) being written: the weight slots' pads, the constants, and each wave's
   // xs slack / xT / d3T.  bufA / bufB are fully rewritten every tile before they are read.
   {
@@ -181,33 +225,29 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     float* slot = s ? slotB : slotA;
-    const float* th = s ? A.thetaB : A.thetaA;
-    for (int idx = tid; idx < H1 * (n + 1); idx += 256) {
-      int u = idx / (n + 1), f = idx - u * (n + 1);
-      slot[L.oW1 + u * S1 + f] = (f < n) ? th[fo.W1 + u * n + f] : th[fo.b1 + u];
-    }
-    // W2 rows are 16-byte aligned in the flat vector (h1 (n + 1) is a multiple of 4): 16-byte copies
+    if (!(XCACHED && s == 0)) {
 #pragma unroll
-    for (int c = 0; c < (H2 * H1 / 4 + 255) / 256; ++c) {
-      const int i4 = c * 256 + tid;
-      if (i4 < H2 * H1 / 4) {
-        const int u = (4 * i4) / H1, k = (4 * i4) % H1;
-        *(f32x4*)&slot[L.oW2 + u * S2 + k] = *(const f32x4*)&th[fo.W2 + 4 * i4];
+      for (int c = 0; c < C1; ++c) {
+        const int f = p1 + 4 * c;
+        if ((u1 < H1) && (f <= n)) slot[L.oW1 + u1 * S1 + f] = w1r[s][c];
       }
     }
-    for (int idx = tid; idx < m * H2; idx += 256) { int a = idx / H2, k = idx - a * H2; slot[L.oW3 + a * S3 + k] = th[fo.W3 + idx]; }
-    for (int idx = tid; idx < H2; idx += 256) slot[L.oB2 + idx] = th[fo.b2 + idx];
-    for (int idx = tid; idx < m; idx += 256) slot[L.oB3 + idx] = th[fo.b3 + idx];
+#pragma unroll
+    for (int c = 0; c < C2; ++c) {
+      const int i4 = c * 256 + tid;
+      if (i4 < H2 * H1 / 4) *(f32x4*)&slot[L.oW2 + ((4 * i4) / H1) * S2 + (4 * i4) % H1] = w2r[s][c];
+    }
+#pragma unroll
+    for (int c = 0; c < C3; ++c) {
+      const int idx = c * 256 + tid;
+      if (idx < m * H2) slot[L.oW3 + (idx / H2) * S3 + idx % H2] = w3r[s][c];
+    }
+    if (tid < H2) slot[L.oB2 + tid] = b2r[s];
+    if (tid < m) slot[L.oB3 + tid] = b3r[s];
   }
-  for (int idx = tid; idx < n; idx += 256) {
-    trs[idx] = A.trA[idx];
-    trs[NP + idx] = A.trA[n + idx];
-    trs[2 * NP + idx] = A.trB[idx];
-    trs[3 * NP + idx] = A.trB[n + idx];
-  }
+  if (tid < n) { trs[tid] = trr[0]; trs[NP + tid] = trr[1]; trs[2 * NP + tid] = trr[2]; trs[3 * NP + tid] = trr[3]; }
   // constant "ones" feature (bias column) of every wave's staging buffers
   if (lane < 32) xT[n * ST + lane] = 1.0f;
-  __syncthreads();
 
   // ---------------- per-action constants (LDS, broadcast reads) ----------------
   float* cst = lds + L.oCST;
@@ -215,36 +255,31 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   if (tid < MP) {
     const int a = tid;
     const bool ok = a < m;
-    float lsa = ok ? A.thetaA[fo.S + a] : 0.f;
-    float lsb = (ok && MODE != MODE_FVP) ? A.thetaB[fo.S + a] : lsa;
-    cst[C_OSC * MP + a] = ok ? A.trA[2 * n + m + a] : 0.f;
-    cst[C_OSH * MP + a] = ok ? A.trA[2 * n + a] : 0.f;
-    cst[C_SG * MP + a] = ok ? expf(lsa) : 1.0f;
+    const float lsa = ok ? csr[0] : 0.f;
+    const float lsb = (ok && MODE != MODE_FVP) ? csr[1] : lsa;
+    const float sga = ok ? expf(lsa) : 1.0f;
+    const float dk = 2.0f / (2.0f * sga * sga + 1e-8f);
+    cst[C_OSC * MP + a] = ok ? csr[2] : 0.f;
+    cst[C_OSH * MP + a] = ok ? csr[3] : 0.f;
+    cst[C_SG * MP + a] = sga;
     cst[C_LS * MP + a] = lsa;
-    cst[C_OSCB * MP + a] = ok ? A.trB[2 * n + m + a] : 0.f;
-    cst[C_OSHB * MP + a] = ok ? A.trB[2 * n + a] : 0.f;
+    cst[C_OSCB * MP + a] = ok ? csr[4] : 0.f;
+    cst[C_OSHB * MP + a] = ok ? csr[5] : 0.f;
     cst[C_SGB * MP + a] = ok ? expf(lsb) : 1.0f;
     cst[C_LSB * MP + a] = lsb;
-    { float sg = ok ? expf(lsa) : 1.0f; cst[C_DK * MP + a] = 2.0f / (2.0f * sg * sg + 1e-8f); }
+    cst[C_DK * MP + a] = dk;
     if (MODE == MODE_FVP) {                       // FVP epilogue: d3 = (md + c3) * osc^2 * Dk / N
-      float osc = ok ? A.trA[2 * n + m + a] : 0.f;
-      cst[9 * MP + 2 * a] = ok ? A.thetaB[fo.b3 + a] : 0.f;
-      cst[9 * MP + 2 * a + 1] = osc * (cst[C_DK * MP + a] * (osc * A.inv_N));
+      const float osc = ok ? csr[2] : 0.f;
+      cst[9 * MP + 2 * a] = ok ? csr[6] : 0.f;
+      cst[9 * MP + 2 * a + 1] = osc * (dk * (osc * A.inv_N));
     }
   }
+  // (flag word in wave 0's staging area, zero since the fill above and rewritten by the first tile's staging;
+  //  no __syncthreads_or: its static LDS word would not fit next to a 160 KB dynamic allocation)
+  if (MODE == MODE_EVAL && mism) lds[L.oWAVES] = 1.0f;
   __syncthreads();
-
-  // MODE_EVAL: the old policy's per-sample outputs of this batch may still be around from MODE_VPG (same update);
-  // they are used only if the old parameters and transforms are bit-identical to the ones they were computed with.
   bool use_oc = false;
   if (MODE == MODE_EVAL && A.ocache) {
-    int mism = 0;
-    for (int idx = tid; idx < fo.d; idx += 256) mism |= (A.thetaB[idx] != A.snap[idx]);
-    for (int idx = tid; idx < 2 * (n + m); idx += 256) mism |= (A.trB[idx] != A.snap[fo.d + idx]);
-    // (flag word in wave 0's staging area, zero since the fill above and rewritten by the first tile's staging;
-    //  no __syncthreads_or: its static LDS word would not fit next to a 160 KB dynamic allocation)
-    if (mism) lds[L.oWAVES] = 1.0f;
-    __syncthreads();
     use_oc = (lds[L.oWAVES] == 0.0f);
     __syncthreads();
   }
@@ -330,7 +365,6 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   };
 
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  constexpr bool XCACHED = (MODE == MODE_FVP) && CACHED;      // observations come from the cache image
   if (!XCACHED && tile < ntiles) load_x(tile);
   if (XCACHED && tile < ntiles) load_h(tile);
   if (MODE == MODE_EVAL && use_oc && tile < ntiles) load_oc(tile);
