@@ -283,6 +283,15 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     use_oc = (lds[L.oWAVES] == 0.0f);
     __syncthreads();
   }
+  // FVP epilogue constants as wave-uniform scalars (no LDS round trip on the d3 critical path)
+  float kc3[MP], kcs[MP];
+  if (MODE == MODE_FVP) {
+#pragma unroll
+    for (int a = 0; a < MP; ++a) {
+      kc3[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cst[9 * MP + 2 * a])));
+      kcs[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cst[9 * MP + 2 * a + 1])));
+    }
+  }
   constexpr int OC_TILE = (MP + 1) * 32;
   float ocn[MP + 1];                              // next tile's old-policy outputs (MODE_EVAL)
   auto load_oc = [&](int64_t t) {
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       float d3a[MP];
 #pragma unroll
       for (int a = 0; a < MP; ++a) {
-        const f32x2 kc = *(const f32x2*)&cst[9 * MP + 2 * a];       // {c3[a], out_scale^2 * Dk / N}
+        const f32x2 kc = f32x2{kc3[a], kcs[a]};                      // {c3[a], out_scale^2 * Dk / N} (wave-uniform, SGPRs)
         d3a[a] = valid ? (md[a] + kc.x) * kc.y : 0.f;
         if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0 && hi == 0) A.dbg[2048 * 4 + a * 32 + j] = cst[C_OSC * MP + a] * (md[a] + kc.x);
       }
