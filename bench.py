@@ -184,12 +184,13 @@ def main():
     if rank == 0:
         fvp_ms = prof[0] / max(prof[1], 1.0)
         P = N_OBS * 64 + 64 * 64 + 64 * N_ACT
-        # The CG loop runs the cached-forward FVP instance: h1 / h2 are stored once per update by K1 (theta is
-        # fixed during CG), each product then costs the tangent + backward passes, 2(4P - 2 n h1) FLOP and
-        # 4(n + h1 + h2) B per sample (SURVEY 8d "cached-activation variant").  The recompute instance
-        # (2(5P - 2 n h1) = 51 328 FLOP, 68 B per sample) is what mjx_fvp runs without a preceding K1.
+        # The CG loop runs the cached-forward FVP instance: K1 stores h1 / h2 and the normalised observation image once
+        # per update (theta is fixed during CG), each product then costs the tangent + backward passes:
+        # 2(4P - 2 n h1) FLOP and 4(h1 + h2 + NP) B per sample, NP = n + 1 padded to 4 (SURVEY 8d "cached-activation
+        # variant").  The recompute instance (2(5P - 2 n h1) = 51 328 FLOP, 68 B per sample) is what mjx_fvp runs
+        # without a preceding K1.
         flop_per_sample = 2 * (4 * P - 2 * N_OBS * 64)               # 40 192 @cfg2
-        bytes_per_sample = 4 * (N_OBS + 64 + 64)                     # 580 @cfg2
+        bytes_per_sample = 4 * (64 + 64 + ((N_OBS + 1 + 3) & ~3))    # 592 @cfg2
         flop_recompute = 2 * (5 * P - 2 * N_OBS * 64)                # 51 328 @cfg2
         n_loc = eng.N_local
         achieved_tf = flop_per_sample * n_loc / (fvp_ms * 1e-3) / 1e12

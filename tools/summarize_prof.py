@@ -46,7 +46,7 @@ def main():
     json.dump(out, open(os.path.join(dst, "pmc_per_launch_avg.json"), "w"), indent=1)
     fvp = next(k for k in out if "MODE_FVP" in k)
     cached = "CACHED" in fvp
-    algo = 4 * (N_OBS + H1 + H2) * N_SAMPLES if cached else 4 * N_OBS * N_SAMPLES
+    algo = 4 * (((N_OBS + 4) & ~3) + H1 + H2) * N_SAMPLES if cached else 4 * N_OBS * N_SAMPLES
     fetch, write = out[fvp]["FETCH_SIZE"], out[fvp]["WRITE_SIZE"]
     json.dump({
         "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
