@@ -153,6 +153,14 @@ int mjx_whiten_cast(const double* adv, int64_t N, double mean, double std, doubl
                     float* out32, void* stream);
 int mjx_cast_f64_f32(const double* x, int64_t count, float* out32, void* stream);
 
+/* Host-side gather for rollout ingestion: copies blocks [first, first + count) of a list of
+ * per-trajectory arrays -- src[i] is rows(i) x row_bytes, C-contiguous -- to their place in one staging block,
+ * dst + offsets[i] * row_bytes (offsets = cumulative row counts, n_blocks + 1 entries), with n_threads worker
+ * threads.  Replaces np.concatenate over the path list (mjrl/algos/batch_reinforce.py:180-181); dst is
+ * normally page-locked memory that is then sent with one asynchronous copy per group.  No device work. */
+int mjx_host_gather(void* dst, const void* const* src, const int64_t* offsets, int64_t first, int64_t count,
+                    int64_t row_bytes, int n_threads);
+
 /* ---- K6: value baselines --------------------------------------------------- */
 /* Feature maps of the reference baselines over the concatenated fp64 observation block
  * (N x n) with tpos[s] = time index of sample s inside its trajectory:

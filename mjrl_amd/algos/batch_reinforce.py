@@ -107,11 +107,10 @@ class BatchREINFORCE:
     # ------------------------------------------------------------------ vanilla PG update
     def train_from_paths(self, paths):
         """batch_reinforce.py:117-175 (optional halving line search on the KL)."""
-        observations, actions, advantages, base_stats, self.running_score = self.process_paths(paths)
+        base_stats = self._process_and_bind(paths)
         if self.save_logs:
             self.log_rollout_statistics(paths)
         eng = self.engine
-        self._bind(observations, actions, advantages)
         t0 = timer.time()
         g, surr_before = eng.surr_vpg()
         eng.x.copy_(g)
@@ -143,6 +142,10 @@ class BatchREINFORCE:
         rank's trajectory shard and mean / std / return statistics are taken over all ranks."""
         observations = np.concatenate([path["observations"] for path in paths])
         actions = np.concatenate([path["actions"] for path in paths])
+        advantages, base_stats, running_score = self._advantages_and_statistics(paths)
+        return observations, actions, advantages, base_stats, running_score
+
+    def _advantages_and_statistics(self, paths):
         advantages = np.concatenate([path["advantages"] for path in paths])
         path_returns = np.array([float(np.sum(p["rewards"])) for p in paths])
         d = _dist()
@@ -155,7 +158,18 @@ class BatchREINFORCE:
         mean_return = np.mean(path_returns)
         base_stats = [mean_return, np.std(path_returns), np.amin(path_returns), np.amax(path_returns)]
         running_score = mean_return if self.running_score is None else 0.9 * self.running_score + 0.1 * mean_return
-        return observations, actions, advantages, base_stats, running_score
+        return advantages, base_stats, running_score
+
+    def _process_and_bind(self, paths):
+        """process_paths + upload + binding for train_from_paths: the (whitened, fp64) advantages are assembled on the
+        host like the reference does, observations / actions go path by path through the engine's page-locked
+        stager (utils/ingest.py) -- no concatenated host copy, transfers overlapped with staging.
+        -> base_stats; sets self.running_score."""
+        advantages, base_stats, self.running_score = self._advantages_and_statistics(paths)
+        staged = self.engine.stage_paths(paths, ("observations", "actions"))
+        self._push_policy()
+        self.engine.set_batch(staged["observations"], staged["actions"], advantages)
+        return base_stats
 
     def _global_mean_std(self, x):
         """population mean / std of a sample vector that is sharded over the ranks"""

@@ -113,13 +113,16 @@ class NPG(BatchREINFORCE):
 
     def train_from_paths(self, paths):
         """npg_cg.py:91-163"""
-        observations, actions, advantages, base_stats, self.running_score = self.process_paths(paths)
+        if self.input_normalization:
+            # the running input normalisation needs the column statistics of the host observations (npg_cg.py:101-107)
+            observations, actions, advantages, base_stats, self.running_score = self.process_paths(paths)
+            self._normalize_inputs(observations)
+            self._bind(observations, actions, advantages)
+        else:
+            base_stats = self._process_and_bind(paths)
         if self.save_logs:
             self.log_rollout_statistics(paths)
-        if self.input_normalization:
-            self._normalize_inputs(observations)
         eng = self.engine
-        self._bind(observations, actions, advantages)
 
         t0 = timer.time()
         g, surr_before = eng.surr_vpg()                       # npg_cg.py:111-115

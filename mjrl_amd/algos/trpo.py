@@ -32,11 +32,10 @@ class TRPO(NPG):
 
     def train_from_paths(self, paths):
         """trpo.py:56-146"""
-        observations, actions, advantages, base_stats, self.running_score = self.process_paths(paths)
+        base_stats = self._process_and_bind(paths)
         if self.save_logs:
             self.log_rollout_statistics(paths)
         eng = self.engine
-        self._bind(observations, actions, advantages)
 
         t0 = timer.time()
         g, surr_before = eng.surr_vpg()

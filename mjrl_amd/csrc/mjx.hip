@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "baseline.h"
@@ -665,6 +666,33 @@ int mjx_whiten_cast(const double* adv, int64_t N, double mean, double std, doubl
   int grid = (int)((N + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_whiten_cast, dim3(grid), dim3(256), 0, (hipStream_t)stream, adv, N, mean, std + eps, out32);
   HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_host_gather(void* dst, const void* const* src, const int64_t* offsets, int64_t first, int64_t count,
+                    int64_t row_bytes, int n_threads) {
+  if (!dst || !src || !offsets || first < 0 || count < 0 || row_bytes <= 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (count == 0) return MJX_OK;
+  const int64_t total = (offsets[first + count] - offsets[first]) * row_bytes;
+  int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+  if (total < (int64_t)(1 << 20)) nt = 1;
+  // every thread takes a contiguous byte range of the destination (blocks are split where the range ends)
+  auto work = [&](int t) {
+    const int64_t lo = total * t / nt, hi = total * (t + 1) / nt;
+    const int64_t base = offsets[first] * row_bytes;
+    for (int64_t i = first; i < first + count; ++i) {
+      const int64_t b0 = offsets[i] * row_bytes - base, b1 = offsets[i + 1] * row_bytes - base;
+      const int64_t c0 = b0 > lo ? b0 : lo, c1 = b1 < hi ? b1 : hi;
+      if (c1 > c0) memcpy((char*)dst + base + c0, (const char*)src[i] + (c0 - b0), (size_t)(c1 - c0));
+      if (b0 >= hi) break;
+    }
+  };
+  if (nt == 1) { work(0); return MJX_OK; }
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
   return MJX_OK;
 }
 

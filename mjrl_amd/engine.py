@@ -150,6 +150,9 @@ class UpdateEngine:
         return self.backend.stream()
 
     def close(self):
+        if getattr(self, "_stager", None) is not None:
+            self._stager.close()
+            self._stager = None
         if getattr(self, "backend", None) is not None:
             self.backend.close()
 
@@ -194,6 +197,15 @@ class UpdateEngine:
         self.N_local = int(self.obs.shape[0])
         self.N_global = self.global_count(self.N_local) if N_global is None else int(N_global)
         self.backend.bind_batch(self.obs, self.act, self.adv, self.N_local, int(self.N_global))
+
+    def stage_paths(self, paths, keys=("observations", "actions")):
+        """per-path host arrays -> fp32 device blocks through the page-locked stager (utils/ingest.py): no
+        concatenated host copy, chunked transfers overlapped with the staging copies.  The tensors stay valid
+        until the next call."""
+        if getattr(self, "_stager", None) is None:
+            from .utils.ingest import PathStager
+            self._stager = PathStager(self.backend)
+        return self._stager.stage(paths, keys)
 
     def bind_rows(self, rows, adv=None, N_global=None):
         """(re)bind the first `rows` samples of the uploaded block (DAPG runs the Fisher on the

@@ -590,3 +590,21 @@ def test_eval_reuses_old_policy_outputs_only_when_unchanged():
     hvt = O.fvp(th.astype(np.float64), obs2, v.astype(np.float64), n, m, hid, tr64)
     assert rel(hv, hvt) < TOL_FVP
     eng.close()
+
+
+def test_path_stager_gpu_exact_and_update_unchanged():
+    """Page-locked staging + chunked side-stream upload + device cast delivers exactly astype(float32) of the
+    concatenated paths, and NPG.train_from_paths (which ingests through it) matches the reference fixture
+    (covered by test_npg_agent_update_vs_reference); here: ragged paths, reuse of the stager across batches."""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    rng = np.random.RandomState(4)
+    eng = UpdateEngine(17, 6, (64, 64))
+    for rep, nt in enumerate((37, 120, 11)):
+        lens = rng.randint(1, 1000, size=nt)
+        paths = [dict(observations=rng.randn(T, 17), actions=rng.randn(T, 6)) for T in lens]
+        out = eng.stage_paths(paths)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out["observations"].cpu().numpy(), np.concatenate([p["observations"] for p in paths]).astype(np.float32))
+        np.testing.assert_array_equal(out["actions"].cpu().numpy(), np.concatenate([p["actions"] for p in paths]).astype(np.float32))
+    eng.close()

@@ -108,3 +108,40 @@ def test_agent_pickles_without_engine():
         assert b.seed == 5 and b._engine_obj is None
     assert NPG(None, pol, None, kl_dist=0.02).n_step_size == 0.04          # kl_dist overrides (npg_cg.py:49)
     assert NPG(None, pol, None, input_normalization=1.5).input_normalization is None
+
+
+def test_path_stager_matches_concatenate_cpu():
+    """utils/ingest.PathStager (CPU fallback: plain memory, synchronous sends) == np.concatenate + astype(float32),
+    for ragged fp64 paths, fp32 paths, the incremental interface and more than one group per call."""
+    import torch
+    from mjrl_amd.utils.ingest import PathStager
+
+    class Backend:
+        device = torch.device("cpu")
+    Backend.torch = torch
+    rng = np.random.RandomState(3)
+    lens = [1, 7, 300, 64, 1000, 33]
+    paths = [dict(observations=rng.randn(T, 5), actions=rng.randn(T, 2)) for T in lens]
+    from mjrl_amd import _lib
+    for threads, native in ((1, False), (4, False), (3, True)):
+        be = Backend()
+        be.lib = _lib.load() if native else None            # native: the gather runs in libmjx (mjx_host_gather)
+        st = PathStager(be, threads=threads, group_rows=256)
+        assert st.native == native
+        out = st.stage(paths)
+        assert out["observations"].dtype == torch.float32 and out["observations"].shape == (sum(lens), 5)
+        np.testing.assert_array_equal(out["observations"].numpy(), np.concatenate([p["observations"] for p in paths]).astype(np.float32))
+        np.testing.assert_array_equal(out["actions"].numpy(), np.concatenate([p["actions"] for p in paths]).astype(np.float32))
+        # incremental: two add_paths calls, fp32 sources
+        p32 = [dict(observations=p["observations"].astype(np.float32), actions=p["actions"].astype(np.float32)) for p in paths]
+        st.begin(("observations", "actions"), (5, 2), (np.float32, np.float32), sum(lens))
+        st.add_paths(p32[:2])
+        st.add_paths(p32[2:])
+        out = st.finish()
+        np.testing.assert_array_equal(out["observations"].numpy(), np.concatenate([p["observations"] for p in p32]))
+        # capacity is enforced
+        st.begin(("observations", "actions"), (5, 2), (np.float64, np.float64), 10)
+        with pytest.raises(ValueError):
+            st.add_paths(paths)
+            st.finish()
+        st.close()

@@ -1,0 +1,35 @@
+"""End-to-end NPG.train_from_paths on fp64 host paths (1M timesteps, HalfCheetah shapes): host path statistics +
+ingestion (page-locked staging, chunked upload, device cast) + the update + parameter read-back.
+python tools/bench_e2e.py [threads] [group_rows]"""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from mjrl_amd.algos.npg_cg import NPG
+from mjrl_amd.policies.gaussian_mlp import MLP
+
+spec = type("Spec", (), dict(observation_dim=17, action_dim=6, horizon=1000))
+rng = np.random.RandomState(0)
+paths = [dict(observations=rng.randn(1000, 17), actions=rng.randn(1000, 6), rewards=rng.randn(1000), advantages=rng.randn(1000),
+              terminated=False) for _ in range(1000)]
+pol = MLP(spec, hidden_sizes=(64, 64), seed=1, init_log_std=-0.5)
+agent = NPG(None, pol, None, normalized_step_size=0.05)
+out = {}
+if len(sys.argv) > 1:
+    from mjrl_amd.utils.ingest import PathStager
+    agent.engine._stager = PathStager(agent.engine.backend, threads=int(sys.argv[1]), group_rows=int(sys.argv[2]) if len(sys.argv) > 2 else 32768)
+for _ in range(2):
+    agent.train_from_paths(paths)
+torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter(); agent.train_from_paths(paths); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+out["npg_train_from_paths_end_to_end_ms"] = 1e3 * min(ts)
+t0 = time.perf_counter(); agent._advantages_and_statistics(paths); out["advantages_and_statistics_host_ms"] = 1e3 * (time.perf_counter() - t0)
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter(); agent.engine.stage_paths(paths); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+out["stage_paths_ms"] = 1e3 * min(ts)
+t0 = time.perf_counter(); o, a, adv, _, _ = agent.process_paths(paths); out["process_paths_concat_host_ms"] = 1e3 * (time.perf_counter() - t0)
+t0 = time.perf_counter(); agent.engine.set_batch(o, a, adv); torch.cuda.synchronize(); out["legacy_upload_ms"] = 1e3 * (time.perf_counter() - t0)
+print(json.dumps(out))
