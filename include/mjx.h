@@ -153,6 +153,14 @@ int mjx_whiten_cast(const double* adv, int64_t N, double mean, double std, doubl
                     float* out32, void* stream);
 int mjx_cast_f64_f32(const double* x, int64_t count, float* out32, void* stream);
 
+/* Batched policy inference: mean_out[i] = out_scale * MLP_theta((obs[i] - in_shift) / (in_scale + 1e-8))
+ * + out_shift for N observations resident in HBM -- FCNetwork.forward (mjrl/utils/fc_network.py:39-52) on a
+ * (N, n) block, as the model-based rollouts and evaluation sweeps call it (mjrl/algos/model_accel/sampling.py:66-89).
+ * theta: flat parameters, tr: packed transforms (NULL = identity); neither has to be the bound policy.
+ * Runs on the MFMA GEMM chain of the layer-wise path (fused bias + tanh / output-affine epilogues). */
+int mjx_policy_forward(mjx_ctx* ctx, const float* obs, int64_t N, const float* theta, const float* tr,
+                       float* mean_out, void* stream);
+
 /* Host-side gather for rollout ingestion: copies blocks [first, first + count) of a list of
  * per-trajectory arrays -- src[i] is rows(i) x row_bytes, C-contiguous -- to their place in one staging block,
  * dst + offsets[i] * row_bytes (offsets = cumulative row counts, n_blocks + 1 entries), with n_threads worker

@@ -669,6 +669,17 @@ int mjx_whiten_cast(const double* adv, int64_t N, double mean, double std, doubl
   return MJX_OK;
 }
 
+int mjx_policy_forward(mjx_ctx* c, const float* obs, int64_t N, const float* theta, const float* tr, float* mean_out, void* stream) {
+  if (!c || N < 0 || (N > 0 && (!obs || !theta || !mean_out))) return fail(MJX_ERR_ARG, "bad arguments");
+  if (N == 0) return MJX_OK;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->lw.cap < N) { if (int rc = c->lw.reserve(N)) return fail(rc, "layer-wise workspace allocation failed"); }
+  c->lw.invalidate();                           // the hidden activations of the bound policy are overwritten (scratch)
+  c->lw.forward(theta, tr ? tr : c->ident_tr, obs, N, c->lw.T, mean_out, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
 int mjx_host_gather(void* dst, const void* const* src, const int64_t* offsets, int64_t first, int64_t count,
                     int64_t row_bytes, int n_threads) {
   if (!dst || !src || !offsets || first < 0 || count < 0 || row_bytes <= 0) return fail(MJX_ERR_ARG, "bad arguments");

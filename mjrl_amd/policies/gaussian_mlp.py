@@ -55,6 +55,8 @@ class _NetView:
         """NumPy in -> NumPy out (fp32; what get_action uses: no torch, fork-safe).
         torch in -> torch out, differentiable w.r.t. ``policy.trainable_params`` for the new model
         (what BC / PPO optimise through, behavior_cloning.py:104, ppo_clip.py:58-102)."""
+        if hasattr(x, "detach") and x.is_cuda:
+            return self._p._device_forward(x, self)           # batched inference on the GPU (SURVEY 8f N4), no autograd
         if hasattr(x, "detach"):
             import torch
             ps = self._p.trainable_params if self._which == "new" else self._p.old_params
@@ -155,6 +157,7 @@ class MLP:
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_tp", None); state.pop("_op", None)       # rebuilt lazily; the NumPy store is the state
+        state.pop("_dev", None)                                # device context: training process only
         return state
 
     def get_param_values(self):
@@ -183,6 +186,27 @@ class MLP:
                     np.array_equal(self.model.packed_transforms(), self.old_model.packed_transforms()))
 
     # ------------------------------------------------------------------ acting (host, fork-safe)
+    def _device_forward(self, x, net):
+        """(N, n) CUDA tensor -> (N, m) CUDA tensor of action means through libmjx (mjx_policy_forward): what
+        learned-model rollouts / evaluation sweeps call as policy.model.forward on a batch
+        (model_accel/sampling.py:66-89).  The parameters are read from the NumPy store at call time."""
+        import torch
+        from .._lib import check, ptr
+        dev = getattr(self, "_dev", None)
+        if dev is None or dev["device"] != x.device:
+            from ..engine import HipBackend
+            be = HipBackend(self.n, self.m, self.hidden_sizes, device=x.device)
+            dev = self._dev = dict(device=x.device, backend=be,
+                                   theta=torch.empty(be.d, dtype=torch.float32, device=x.device),
+                                   tr=torch.empty(2 * (self.n + self.m), dtype=torch.float32, device=x.device))
+        be = dev["backend"]
+        dev["theta"].copy_(torch.from_numpy(net._params()))
+        dev["tr"].copy_(torch.from_numpy(net.packed_transforms()))
+        xin = x.to(torch.float32).contiguous().reshape(-1, self.n)
+        out = torch.empty((xin.shape[0], self.m), dtype=torch.float32, device=x.device)
+        check(be.lib.mjx_policy_forward(be.ctx, ptr(xin), xin.shape[0], ptr(dev["theta"]), ptr(dev["tr"]), ptr(out), be.stream()))
+        return out
+
     def get_action(self, observation):
         """gaussian_mlp.py:91-97: fp32 mean + exp(log_std) * np.random.randn(m).  NumPy only."""
         o = np.float32(observation.reshape(1, -1))

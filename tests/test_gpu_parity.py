@@ -608,3 +608,35 @@ def test_path_stager_gpu_exact_and_update_unchanged():
         np.testing.assert_array_equal(out["observations"].cpu().numpy(), np.concatenate([p["observations"] for p in paths]).astype(np.float32))
         np.testing.assert_array_equal(out["actions"].cpu().numpy(), np.concatenate([p["actions"] for p in paths]).astype(np.float32))
     eng.close()
+
+
+@pytest.mark.parametrize("hid", [(64, 64), (32, 32), (128, 64, 32), ()])
+def test_batched_policy_forward_device(hid):
+    """policy.model.forward on a CUDA batch (learned-model rollouts / evaluation,
+    model_accel/sampling.py:66-89) goes through mjx_policy_forward; == the NumPy network / fp64 oracle."""
+    import torch
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    from mjrl_amd.policies.gaussian_linear import LinearPolicy
+    n, m, N = 11, 3, 5003
+
+    class Spec:
+        observation_dim, action_dim, horizon = n, m, 100
+    pol = MLP(Spec, hidden_sizes=hid, seed=3, init_log_std=-0.5) if hid else LinearPolicy(Spec, seed=3)
+    rng = np.random.RandomState(8)
+    pol.set_param_values((pol.get_param_values() + 0.1 * rng.randn(pol.get_param_values().size)).astype(np.float32))
+    ish, isc = rng.randn(n).astype(np.float32), (0.5 + rng.rand(n)).astype(np.float32)
+    osh, osc = rng.randn(m).astype(np.float32), (0.5 + rng.rand(m)).astype(np.float32)
+    pol.model.set_transformations(ish, isc, osh, osc)
+    obs = rng.randn(N, n).astype(np.float32)
+    dev = pol.model.forward(torch.from_numpy(obs).cuda())
+    assert dev.is_cuda and dev.shape == (N, m)
+    host = pol.model.forward(obs)                                   # NumPy fp32 network (get_action's path)
+    truth = O.forward(pol.get_param_values().astype(np.float64), obs.astype(np.float64), n, m, tuple(hid),
+                      O.Transforms(n, m, ish, isc, osh, osc))
+    assert np.abs(dev.cpu().numpy() - truth).max() < 2e-5 * max(1.0, np.abs(truth).max())
+    assert np.abs(dev.cpu().numpy() - host).max() < 2e-5 * max(1.0, np.abs(truth).max())
+    # the old network follows its own parameters / transforms
+    old = pol.old_model.forward(torch.from_numpy(obs[:100]).cuda()).cpu().numpy()
+    assert np.abs(old - pol.old_model.forward(obs[:100])).max() < 2e-5 * max(1.0, np.abs(truth).max())
+    import pickle
+    pickle.loads(pickle.dumps(pol))                                 # the device context never travels
