@@ -39,26 +39,36 @@ struct GemmArgs {
   int epi;
 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;
+constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = GBK + 4, GLT = GBM + 4;
 
-// C = sum_p A_p * B_p with v_mfma_f32_32x32x2_f32; 4 waves in a 2x2 grid of 64x64 sub-tiles.
-// blockIdx.z splits the K range of pair 0 (wgrad: K = samples).
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
-  __shared__ float As[GBK * GLD];
-  __shared__ float Bs[GBK * GLD];
+// C = sum_p A_p * B_p with v_mfma_f32_32x32x2_f32; 4 waves in a 2x2 grid of 64x64 sub-tiles, K tiles of 32.
+// Operand tiles go global -> registers -> LDS in the 16-byte granules they are contiguous in:
+//   * a K-contiguous operand (activations, W as "NT") is kept as [row][k] (row stride 36) and its MFMA fragments
+//     are read with ONE ds_read_b128 per 32-row block and 4 k-steps;
+//   * a row-contiguous operand (W as "NN", the sample-major operands of the weight gradient) is kept as [k][row]
+//     (stride 132) and read with ds_read_b32;
+//   k-slot `hi` of step (q, t) carries k = 8q + 4hi + t for A and B alike (the permutation trick of the fused kernels).
+// The next tile's global loads are issued before the MFMAs of the current one (register-staged prefetch).  blockIdx.z splits the K range of pair 0 (wgrad: K = samples).
+// BN = 128: 2x2 waves of 64x64; BN = 32 (narrow outputs: action heads, value heads): 4x1 waves of 32x32, so a
+// 17-column product is padded to 32 instead of 128 columns.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+  constexpr int WN = BN / 64 > 0 ? BN / 64 : 1;   // waves along N
+  constexpr int WMc = 4 / WN;                     // waves along M
+  constexpr int TM = GBM / WMc, TN = BN / WN;     // per-wave tile
+  constexpr int MT = TM / 32, NT = TN / 32;
+  __shared__ __attribute__((aligned(16))) float As[GBM * GLD];
+  __shared__ __attribute__((aligned(16))) float Bs[(BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-  f32x16 acc[2][2];
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * BN;
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x16)(0.f);
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x16)(0.f);
 
   for (int p = 0; p < g.npairs; ++p) {
-    const float* __restrict__ Ap = g.A[p];
-    const float* __restrict__ Bp = g.B[p];
-    const int64_t ars = g.a_rs[p], aks = g.a_ks[p], bcs = g.b_cs[p], bks = g.b_ks[p];
     int kbeg = 0, kend = g.K[p];
     if (gridDim.z > 1) {
       int chunk = (g.K[p] + gridDim.z - 1) / gridDim.z;
@@ -66,101 +76,163 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
       kbeg = blockIdx.z * chunk;
       kend = min(g.K[p], kbeg + chunk);
     }
-    float ra[8], rb[8];
-    auto gload = [&](int k0) {
-      if (aks == 1) {
-        const int kk = tid & 15, r = tid >> 4;
+    if (kbeg >= kend) continue;
+    // one operand tile = 128 rows x 32 k = 1024 float4; 4 per thread.  mode 0: K-contiguous, mode 1: row-contiguous,
+    // mode 2: anything else (scalar gather)
+    auto mode_of = [](const float* ptr, int64_t rs, int64_t ks) {
+      if (ks == 1 && (rs & 3) == 0 && (((uintptr_t)ptr) & 15) == 0) return 0;
+      if (rs == 1 && (ks & 3) == 0 && (((uintptr_t)ptr) & 15) == 0) return 1;
+      return 2;
+    };
+    const float* __restrict__ Ap = g.A[p];
+    const float* __restrict__ Bp = g.B[p];
+    const int64_t ars = g.a_rs[p], aks = g.a_ks[p], bcs = g.b_cs[p], bks = g.b_ks[p];
+    const int amode = mode_of(Ap, ars, aks), bmode = mode_of(Bp, bcs, bks);
+    constexpr int CA = GBM / 32, CB = BN / 32;        // float4 per thread and operand tile
+    f32x4 ra[CA], rb[CB];
+    // RT = rows of the tile (128 or 32): 8 float4 per row in the [row][k] image, RT/4 per k-row in the [k][row] image
+    auto gload1 = [&](auto rt, auto& r, const float* __restrict__ P, int mode, int64_t rs, int64_t ks, int r0, int R, int k0) {
+      constexpr int RT = decltype(rt)::value, NC = RT / 32, Q = RT / 4;
+      // interior tiles (block-uniform test): unconditional 16-byte loads, nothing else in the way
+      if (mode != 2 && r0 + RT <= R && k0 + GBK <= kend) {
+        if (mode == 0) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          int row = m0 + r + 16 * c, k = k0 + kk;
-          ra[c] = (row < g.M && k < kend) ? Ap[(int64_t)row * ars + k] : 0.f;
-        }
-      } else {
-        const int r = tid & 127, kq = tid >> 7;
+          for (int c = 0; c < NC; ++c) { const int idx = tid + 256 * c; r[c] = *(const f32x4*)(P + (int64_t)(r0 + (idx >> 3)) * rs + k0 + 4 * (idx & 7)); }
+        } else {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          int row = m0 + r, k = k0 + kq + 2 * c;
-          ra[c] = (row < g.M && k < kend) ? Ap[(int64_t)row * ars + (int64_t)k * aks] : 0.f;
+          for (int c = 0; c < NC; ++c) { const int idx = tid + 256 * c; r[c] = *(const f32x4*)(P + (int64_t)(k0 + idx / Q) * ks + r0 + 4 * (idx % Q)); }
         }
+        return;
       }
-      if (bks == 1) {
-        const int kk = tid & 15, r = tid >> 4;
+      // edge tiles / unaligned operands: element-wise, clamped address + select (no branches)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          int col = n0 + r + 16 * c, k = k0 + kk;
-          rb[c] = (col < g.N && k < kend) ? Bp[(int64_t)col * bcs + k] : 0.f;
-        }
-      } else {
-        const int r = tid & 127, kq = tid >> 7;
+      for (int c = 0; c < NC; ++c) {
+        const int idx = tid + 256 * c;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          int col = n0 + r, k = k0 + kq + 2 * c;
-          rb[c] = (col < g.N && k < kend) ? Bp[(int64_t)col * bcs + (int64_t)k * bks] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          const int row = (mode == 1) ? r0 + 4 * (idx % Q) + e : r0 + (idx >> 3);
+          const int k = (mode == 1) ? k0 + idx / Q : k0 + 4 * (idx & 7) + e;
+          const bool ok = (row < R) && (k < kend);
+          const float v = P[ok ? (int64_t)row * rs + (int64_t)k * ks : 0];
+          r[c][e] = ok ? v : 0.f;
         }
       }
     };
-    auto lstore = [&]() {
-      if (aks == 1) {
-        const int kk = tid & 15, r = tid >> 4;
+    // LDS image: K-contiguous operands as [row][k] (stride GLD), row-contiguous ones as [k][row] (stride RT + 4) --
+    // either way the 16-byte granule that was loaded is stored with one conflict-free ds_write_b128
+    auto lstore1 = [&](auto rt, float* S, const auto& r, int mode) {
+      constexpr int RT = decltype(rt)::value, NC = RT / 32, Q = RT / 4;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) As[kk * GLD + r + 16 * c] = ra[c];
-      } else {
-        const int r = tid & 127, kq = tid >> 7;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) As[(kq + 2 * c) * GLD + r] = ra[c];
-      }
-      if (bks == 1) {
-        const int kk = tid & 15, r = tid >> 4;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) Bs[kk * GLD + r + 16 * c] = rb[c];
-      } else {
-        const int r = tid & 127, kq = tid >> 7;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) Bs[(kq + 2 * c) * GLD + r] = rb[c];
+      for (int c = 0; c < NC; ++c) {
+        const int idx = tid + 256 * c;
+        if (mode == 1) *(f32x4*)&S[(idx / Q) * (RT + 4) + 4 * (idx % Q)] = r[c];
+        else *(f32x4*)&S[(idx >> 3) * GLD + 4 * (idx & 7)] = r[c];
       }
     };
-    if (kbeg < kend) gload(kbeg);
+    // operand fragment of the 32-row block at row0 for the 4 k-steps of group q: k-slot `hi` of step t carries
+    // k = 8q + 4hi + t (one ds_read_b128 from the [row][k] image, four ds_read_b32 from the [k][row] image)
+    auto frag = [&](auto rt, const float* S, int mode, int row0, int q) {
+      constexpr int RT = decltype(rt)::value;
+      if (mode == 1) {
+        const float* p = &S[(8 * q + 4 * hi) * (RT + 4) + row0 + j];
+        return f32x4{p[0], p[RT + 4], p[2 * (RT + 4)], p[3 * (RT + 4)]};
+      }
+      return *(const f32x4*)&S[(row0 + j) * GLD + 8 * q + 4 * hi];
+    };
+    constexpr std::integral_constant<int, GBM> RA{};
+    constexpr std::integral_constant<int, BN> RB{};
+    gload1(RA, ra, Ap, amode, ars, aks, m0, g.M, kbeg);
+    gload1(RB, rb, Bp, bmode, bcs, bks, n0, g.N, kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-      lstore();
+      __syncthreads();                               // the previous tile is fully consumed
+      lstore1(RA, As, ra, amode);
+      lstore1(RB, Bs, rb, bmode);
       __syncthreads();
-      if (k0 + GBK < kend) gload(k0 + GBK);
-#pragma unroll
-      for (int s = 0; s < GBK / 2; ++s) {
-        float a0 = As[(2 * s + hi) * GLD + wm * 64 + j], a1 = As[(2 * s + hi) * GLD + wm * 64 + 32 + j];
-        float b0 = Bs[(2 * s + hi) * GLD + wn * 64 + j], b1 = Bs[(2 * s + hi) * GLD + wn * 64 + 32 + j];
-        acc[0][0] = MJX_MFMA(a0, b0, acc[0][0]);
-        acc[0][1] = MJX_MFMA(a0, b1, acc[0][1]);
-        acc[1][0] = MJX_MFMA(a1, b0, acc[1][0]);
-        acc[1][1] = MJX_MFMA(a1, b1, acc[1][1]);
+      if (k0 + GBK < kend) {                         // next tile's global loads fly under this tile's MFMAs
+        gload1(RA, ra, Ap, amode, ars, aks, m0, g.M, k0 + GBK);
+        gload1(RB, rb, Bp, bmode, bcs, bks, n0, g.N, k0 + GBK);
       }
-      __syncthreads();
+      f32x4 a4[MT], b4[NT], an[MT], bn[NT];
+#pragma unroll
+      for (int a = 0; a < MT; ++a) a4[a] = frag(RA, As, amode, wm * TM + 32 * a, 0);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) b4[b] = frag(RB, Bs, bmode, wn * TN + 32 * b, 0);
+#pragma unroll
+      for (int q = 0; q < GBK / 8; ++q) {
+        if (q + 1 < GBK / 8) {
+#pragma unroll
+          for (int a = 0; a < MT; ++a) an[a] = frag(RA, As, amode, wm * TM + 32 * a, q + 1);
+#pragma unroll
+          for (int b = 0; b < NT; ++b) bn[b] = frag(RB, Bs, bmode, wn * TN + 32 * b, q + 1);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] = MJX_MFMA(a4[a][t], b4[b][t], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) a4[a] = an[a];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) b4[b] = bn[b];
+      }
     }
   }
+  // Epilogue, specialised once per launch (not per element): per-column constants are fetched once per 32-column
+  // block, the activation operands of a 32x32 block as one batch of independent loads.
   float* Cz = g.C + (int64_t)blockIdx.z * g.c_zs;
+  auto epilogue = [&](auto tag) {
+    constexpr int EPI = decltype(tag)::value;
+    constexpr bool USE_BIAS = EPI == EPI_BIAS_TANH || EPI == EPI_BIAS_AFFINE || EPI == EPI_TANGENT || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU;
+    constexpr bool USE_AUX = EPI == EPI_TANGENT || EPI == EPI_BACK || EPI == EPI_RBACK || EPI == EPI_BACK_RELU;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + wn * TN + nt * 32 + j;
+        const bool cok = col < g.N;
+        const int colc = cok ? col : 0;
+        const float bias = USE_BIAS ? g.bias[colc] : 0.f;
+        const float osc = (EPI == EPI_BIAS_AFFINE) ? g.osc[colc] : 1.f;
+        const float osh = (EPI == EPI_BIAS_AFFINE && g.osh) ? g.osh[colc] : 0.f;
+        const int rbase = m0 + wm * TM + mt * 32;
+        float y[16], t2[16], pre[16];
+        if (USE_AUX) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mt * 32 + unit_of(r, hi), col = n0 + wn * 64 + nt * 32 + j;
-        if (row < g.M && col < g.N) {
-          float v = acc[mt][nt][r];
-          if (g.epi == EPI_BIAS_TANH) v = tanhf(v + g.bias[col]);
-          else if (g.epi == EPI_BIAS_AFFINE) v = (v + g.bias[col]) * g.osc[col] + (g.osh ? g.osh[col] : 0.f);
-          else if (g.epi == EPI_TANGENT) { float y = g.aux[(int64_t)row * g.ld_aux + col]; v = (v + g.bias[col]) * fmaf(-y, y, 1.0f); }
-          else if (g.epi == EPI_BACK) { float y = g.aux[(int64_t)row * g.ld_aux + col]; v = v * fmaf(-y, y, 1.0f); }
-          else if (g.epi == EPI_RBACK) {            // R{delta} = acc (1 - y^2) - 2 y t pre   (Pearlmutter R-backward through tanh)
-            const int64_t o = (int64_t)row * g.ld_aux + col;
-            float y = g.aux[o], t = g.aux2[o], pre = g.aux3[o];
-            v = v * fmaf(-y, y, 1.0f) - 2.0f * y * t * pre;
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + unit_of(r, hi);
+            const int64_t o = (row < g.M) ? (int64_t)row * g.ld_aux + colc : 0;
+            y[r] = g.aux[o];
+            if (EPI == EPI_RBACK) { t2[r] = g.aux2[o]; pre[r] = g.aux3[o]; }
           }
-          else if (g.epi == EPI_BIAS) v = v + g.bias[col];
-          else if (g.epi == EPI_BIAS_RELU) v = fmaxf(v + g.bias[col], 0.f);
-          else if (g.epi == EPI_BACK_RELU) { float y = g.aux[(int64_t)row * g.ld_aux + col]; v = (y > 0.f) ? v : 0.f; }
-          Cz[(int64_t)row * g.ldc + col] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + unit_of(r, hi);
+          float v = acc[mt][nt][r];
+          if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
+          else if (EPI == EPI_BIAS_AFFINE) v = (v + bias) * osc + osh;
+          else if (EPI == EPI_TANGENT) v = (v + bias) * fmaf(-y[r], y[r], 1.0f);
+          else if (EPI == EPI_BACK) v = v * fmaf(-y[r], y[r], 1.0f);
+          else if (EPI == EPI_RBACK) v = v * fmaf(-y[r], y[r], 1.0f) - 2.0f * y[r] * t2[r] * pre[r];   // Pearlmutter R-backward through tanh
+          else if (EPI == EPI_BIAS) v = v + bias;
+          else if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+          else if (EPI == EPI_BACK_RELU) v = (y[r] > 0.f) ? v : 0.f;
+          if (cok && row < g.M) Cz[(int64_t)row * g.ldc + col] = v;
         }
       }
+  };
+  switch (g.epi) {
+    case EPI_BIAS_TANH: epilogue(std::integral_constant<int, EPI_BIAS_TANH>{}); break;
+    case EPI_BIAS_AFFINE: epilogue(std::integral_constant<int, EPI_BIAS_AFFINE>{}); break;
+    case EPI_TANGENT: epilogue(std::integral_constant<int, EPI_TANGENT>{}); break;
+    case EPI_BACK: epilogue(std::integral_constant<int, EPI_BACK>{}); break;
+    case EPI_RBACK: epilogue(std::integral_constant<int, EPI_RBACK>{}); break;
+    case EPI_BIAS: epilogue(std::integral_constant<int, EPI_BIAS>{}); break;
+    case EPI_BIAS_RELU: epilogue(std::integral_constant<int, EPI_BIAS_RELU>{}); break;
+    case EPI_BACK_RELU: epilogue(std::integral_constant<int, EPI_BACK_RELU>{}); break;
+    default: epilogue(std::integral_constant<int, EPI_STORE>{}); break;
+  }
 }
 
 // x~ = (x - in_shift) / (in_scale + 1e-8)    fc_network.py:46
@@ -398,8 +470,13 @@ struct LayerwiseWS {
   }
 
   static void launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
-    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, splits);
-    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, g);
+    if (g.N <= 32) {
+      dim3 grid(1, (g.M + GBM - 1) / GBM, splits);
+      hipLaunchKernelGGL(k_gemm<32>, grid, dim3(256), 0, st, g);
+    } else {
+      dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, splits);
+      hipLaunchKernelGGL(k_gemm<GBN>, grid, dim3(256), 0, st, g);
+    }
   }
   static int ew_grid(int64_t cnt) { int64_t g = (cnt + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 
