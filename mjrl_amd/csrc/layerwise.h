@@ -30,8 +30,9 @@ struct GemmArgs {
   int K[2];
   const float* A[2]; int64_t a_rs[2], a_ks[2];   // A(i,k) = A[i*a_rs + k*a_ks]
   const float* B[2]; int64_t b_cs[2], b_ks[2];   // B(k,j) = B[j*b_cs + k*b_ks]
-  float* C; int64_t ldc;                          // C(i,j) = C[i*ldc + j] (+ z*c_zs for split-K)
-  int64_t c_zs;
+  float* C; int64_t ldc;                          // C(i,j) = C[i*ldc + j*c_cs] (+ z*c_zs for split-K); c_cs == 0 means 1
+  int64_t c_zs, c_cs;
+  float* colsum;                                  // optional [gridDim.y][N]: per-block column sums of the stored values (bias gradients)
   const float* bias;                              // per column
   const float* aux; int64_t ld_aux;               // activation for the (1 - y^2) factor
   const float* aux2; const float* aux3;           // EPI_RBACK: tangent activation t and the pre-activation cotangent
@@ -185,6 +186,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     constexpr int EPI = decltype(tag)::value;
     constexpr bool USE_BIAS = EPI == EPI_BIAS_TANH || EPI == EPI_BIAS_AFFINE || EPI == EPI_TANGENT || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU;
     constexpr bool USE_AUX = EPI == EPI_TANGENT || EPI == EPI_BACK || EPI == EPI_RBACK || EPI == EPI_BACK_RELU;
+    constexpr bool CSUM = EPI == EPI_BACK || EPI == EPI_BACK_RELU;      // launches that may carry g.colsum
+    const int64_t ccs = g.c_cs ? g.c_cs : 1;
+    float csum[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) csum[nt] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -218,9 +224,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
           else if (EPI == EPI_BIAS) v = v + bias;
           else if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
           else if (EPI == EPI_BACK_RELU) v = (y[r] > 0.f) ? v : 0.f;
-          if (cok && row < g.M) Cz[(int64_t)row * g.ldc + col] = v;
+          const bool ok = cok && row < g.M;
+          if (ok) Cz[(int64_t)row * g.ldc + (int64_t)col * ccs] = v;
+          if (CSUM) csum[nt] += ok ? v : 0.f;
         }
       }
+    if (CSUM && g.colsum) {
+      // column sums of this block's 128 rows: lane halves (permlane swap), then the waves along M through LDS
+      __syncthreads();                              // operand tiles are dead
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float t = half_sum(csum[nt]);
+        if (hi == 0) As[wm * BN + wn * TN + nt * 32 + j] = t;
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < g.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WMc; ++w) t += As[w * BN + tid];
+        g.colsum[(int64_t)blockIdx.y * g.N + n0 + tid] = t;
+      }
+    }
   };
   switch (g.epi) {
     case EPI_BIAS_TANH: epilogue(std::integral_constant<int, EPI_BIAS_TANH>{}); break;
@@ -379,6 +403,31 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ D, int
   if (rg == 0 && c < h) part[(size_t)blockIdx.y * h + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
+// column sums of a narrow (N x h, h <= 32) matrix: every thread owns whole rows (contiguous h floats), so a wave
+// reads one contiguous block of memory per step; part[blockIdx.x][h], fixed order
+template <int HMAX>
+__global__ __launch_bounds__(256) void k_colsum_narrow(const float* __restrict__ D, int64_t N, int h, float* __restrict__ part) {
+  __shared__ float sh[4][HMAX];
+  float acc[HMAX];
+#pragma unroll
+  for (int c = 0; c < HMAX; ++c) acc[c] = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (int64_t)gridDim.x * 256) {
+    const float* row = D + r * h;
+#pragma unroll
+    for (int c = 0; c < HMAX; ++c) if (c < h) acc[c] += row[c];
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < HMAX; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) sh[w][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < h) part[(size_t)blockIdx.x * h + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
 // out[i] = sum_z part[z][i]   (fp64 accumulate, fixed order)
 __global__ void k_reduce_split(const float* __restrict__ part, int Z, int64_t cnt, float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) {
@@ -508,33 +557,52 @@ struct LayerwiseWS {
     return 0;
   }
 
-  // backward from d3 (N x m cotangent on the pre-affine output) into grad (flat, W and b blocks)
+  // backward from d3 (N x m cotangent on the pre-affine output) into grad (flat, W and b blocks).
+  // Bias gradients (column sums of delta_l) come out of the GEMM that produces delta_l (per-block column sums in its
+  // epilogue, reduced in a fixed order); only the top delta (d3, written by the head kernel) needs its own pass.
   int backward(const float* theta, int64_t N, float* grad, hipStream_t st) {
     const float* delta = d3;
+    const int rowblocks = (int)((N + GBM - 1) / GBM);
+    bool bias_done = false;
     for (int l = nL() - 1; l >= 0; --l) {
       const int ho = sizes[l + 1], hi_ = sizes[l];
       const float* in = (l == 0) ? Xn : H[l - 1];
       // weight gradient: gW[ho x hi] = delta^T (ho x N) * in (N x hi), split over samples
-      int tiles = ((ho + GBM - 1) / GBM) * ((hi_ + GBN - 1) / GBN);
+      const bool narrow = ho <= 32;                 // action head: compute gW^T (hi x ho) so the padding goes to 32 columns, not 128 rows
+      int tiles = narrow ? (hi_ + GBM - 1) / GBM : ((ho + GBM - 1) / GBM) * ((hi_ + GBN - 1) / GBN);
       int splits = (int)((N + 2047) / 2048);
       int maxs = (1024 + tiles - 1) / tiles;
       if (splits > maxs) splits = maxs;
       if (splits < 1) splits = 1;
-      int csplits = splits;
-      if (ensure_part((int64_t)splits * ho * hi_ + (int64_t)csplits * ho)) return 2;
+      const int csplits = 256;
+      if (ensure_part((int64_t)splits * ho * hi_ + (int64_t)csplits * ho + (int64_t)rowblocks * hi_)) return 2;
       GemmArgs g{};
-      g.M = ho; g.N = hi_; g.npairs = 1; g.K[0] = (int)N;
-      g.A[0] = delta; g.a_rs[0] = 1; g.a_ks[0] = ho;
-      g.B[0] = in; g.b_cs[0] = 1; g.b_ks[0] = hi_;
-      g.C = part; g.ldc = hi_; g.c_zs = (int64_t)ho * hi_;
+      g.npairs = 1; g.K[0] = (int)N;
+      if (narrow) {
+        g.M = hi_; g.N = ho;
+        g.A[0] = in; g.a_rs[0] = 1; g.a_ks[0] = hi_;
+        g.B[0] = delta; g.b_cs[0] = 1; g.b_ks[0] = ho;
+        g.ldc = 1; g.c_cs = hi_;                     // C^T(i = input unit, j = output unit) -> gW[j][i]
+      } else {
+        g.M = ho; g.N = hi_;
+        g.A[0] = delta; g.a_rs[0] = 1; g.a_ks[0] = ho;
+        g.B[0] = in; g.b_cs[0] = 1; g.b_ks[0] = hi_;
+        g.ldc = hi_;
+      }
+      g.C = part; g.c_zs = (int64_t)ho * hi_;
       g.epi = EPI_STORE;
       launch_gemm(g, splits, st);
       hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid((int64_t)ho * hi_)), dim3(256), 0, st, part, splits, (int64_t)ho * hi_, grad + oW[l]);
       float* bpart = part + (int64_t)splits * ho * hi_;
-      hipLaunchKernelGGL(k_colsum, dim3((ho + 63) / 64, csplits), dim3(256), 0, st, delta, N, ho, (int64_t)ho, bpart);
-      hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid(ho)), dim3(256), 0, st, bpart, csplits, (int64_t)ho, grad + ob[l]);
+      float* cpart = bpart + (int64_t)csplits * ho;
+      if (!bias_done) {
+        if (ho <= 32) hipLaunchKernelGGL(k_colsum_narrow<32>, dim3(csplits), dim3(256), 0, st, delta, N, ho, bpart);
+        else hipLaunchKernelGGL(k_colsum, dim3((ho + 63) / 64, csplits), dim3(256), 0, st, delta, N, ho, (int64_t)ho, bpart);
+        hipLaunchKernelGGL(k_reduce_partials, dim3((ho + 15) / 16), dim3(256), 0, st, bpart, csplits, ho, grad + ob[l],
+                           (const float*)nullptr, (const float*)nullptr, 0, 0.f);
+      }
       if (l > 0) {
-        // delta_{l} = (delta_{l+1} W_l) (1 - H_{l-1}^2)   -> T[l-1]
+        // delta_{l} = (delta_{l+1} W_l) (1 - H_{l-1}^2)   -> T[l-1]   (+ its column sums = grad b_{l-1})
         GemmArgs b{};
         b.M = (int)N; b.N = hi_; b.npairs = 1; b.K[0] = ho;
         b.A[0] = delta; b.a_rs[0] = ho; b.a_ks[0] = 1;
@@ -542,7 +610,11 @@ struct LayerwiseWS {
         b.C = T[l - 1]; b.ldc = hi_; b.c_zs = 0;
         b.aux = H[l - 1]; b.ld_aux = hi_;
         b.epi = EPI_BACK;
+        b.colsum = cpart;
         launch_gemm(b, 1, st);
+        hipLaunchKernelGGL(k_reduce_partials, dim3((hi_ + 15) / 16), dim3(256), 0, st, cpart, rowblocks, hi_, grad + ob[l - 1],
+                           (const float*)nullptr, (const float*)nullptr, 0, 0.f);
+        bias_done = true;
         delta = T[l - 1];
       }
     }
