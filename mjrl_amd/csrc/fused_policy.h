@@ -1002,8 +1002,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     // workgroup sums the four copies.  (weights in LDS are dead by now)
     float* red = lds;                             // 4 * d floats <= TOTAL (checked on host)
     float* mine = red + wave * fo.d;
-    for (int idx = lane; idx < fo.d; idx += 64) mine[idx] = 0.f;
-    wave_sync();
+    // (every entry of the wave's copy is written below: W1a/b1, W2, W3, b2, b3 and the log_std block)
 #pragma unroll
     for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
@@ -1045,8 +1044,15 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     }
     __syncthreads();
     float* outp = A.partials + (size_t)blockIdx.x * fo.d;
-    for (int idx = tid; idx < fo.d; idx += 256)
-      outp[idx] = (red[idx] + red[fo.d + idx]) + (red[2 * fo.d + idx] + red[3 * fo.d + idx]);
+    if ((fo.d & 3) == 0) {
+      const f32x4* r4 = (const f32x4*)red;
+      const int d4 = fo.d >> 2;
+      for (int idx = tid; idx < d4; idx += 256)
+        ((f32x4*)outp)[idx] = (r4[idx] + r4[d4 + idx]) + (r4[2 * d4 + idx] + r4[3 * d4 + idx]);
+    } else {
+      for (int idx = tid; idx < fo.d; idx += 256)
+        outp[idx] = (red[idx] + red[fo.d + idx]) + (red[2 * fo.d + idx] + red[3 * fo.d + idx]);
+    }
   }
   MJX_GSTAMP(20);
   if (MODE != MODE_FVP) {
