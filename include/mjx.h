@@ -161,6 +161,23 @@ int mjx_cast_f64_f32(const double* x, int64_t count, float* out32, void* stream)
 int mjx_policy_forward(mjx_ctx* ctx, const float* obs, int64_t N, const float* theta, const float* tr,
                        float* mean_out, void* stream);
 
+/* Minibatch Adam on the policy parameters: the torch-optimizer loops of behaviour cloning
+ * (mjrl/algos/behavior_cloning.py:107-136, loss 0 = MSE, 1 = MLE) and PPO (mjrl/algos/ppo_clip.py:85-95, loss 2 =
+ * clipped surrogate against theta_old / tr_old) with the whole batch resident in HBM.  idx holds steps x B row
+ * indices (int32) -- the caller draws them (np.random.choice) so the random stream matches the reference.  theta is
+ * updated in place; adam_m / adam_v (d floats each) and step0 (steps already taken) are the torch.optim.Adam
+ * state (betas 0.9 / 0.999, eps 1e-8, no weight decay).  MSE leaves the log_std block and its Adam state alone
+ * (it has no gradient there).  loss_trace (optional, steps doubles) receives every minibatch loss.
+ * adv, theta_old, tr_old are only read for loss 2; tr / tr_old NULL = identity.
+ * old_tracks_new (loss 2): 0 = the old policy stays fixed during the epochs (the algorithm as published);
+ * 1 = the old NETWORK is evaluated with the current weights and only the old log_std stays fixed -- what the
+ * reference computes once policy.set_param_values has been called with a float32 array (its new and old network
+ * tensors then alias the same memory, mjrl/policies/gaussian_mlp.py:65-87), i.e. from the second iteration on. */
+int mjx_policy_minibatch_adam(mjx_ctx* ctx, int loss, const float* obs, const float* act, const float* adv, const int32_t* idx,
+                              int64_t steps, int B, float* theta, const float* tr, const float* theta_old, const float* tr_old,
+                              int old_tracks_new, float* adam_m, float* adam_v, int64_t step0, float lr, float clip,
+                              double* loss_trace, void* stream);
+
 /* Host-side gather for rollout ingestion: copies blocks [first, first + count) of a list of
  * per-trajectory arrays -- src[i] is rows(i) x row_bytes, C-contiguous -- to their place in one staging block,
  * dst + offsets[i] * row_bytes (offsets = cumulative row counts, n_blocks + 1 entries), with n_threads worker

@@ -46,6 +46,8 @@ PROTOTYPES = {
     "mjx_whiten_cast": (c_int, [c_void_p, c_int64, c_double, c_double, c_double, c_void_p, c_void_p]),
     "mjx_cast_f64_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mjx_policy_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mjx_policy_minibatch_adam": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p]),
     "mjx_host_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "mjx_bl_num_features": (c_int, [c_int, c_int]),
     "mjx_bl_features_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),

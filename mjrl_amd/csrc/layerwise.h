@@ -330,6 +330,109 @@ __global__ __launch_bounds__(256) void k_head(int mode, const float* __restrict_
   if (threadIdx.x == 0) { part[(size_t)blockIdx.x * (2 + MPH)] = s_surr; part[(size_t)blockIdx.x * (2 + MPH) + 1] = s_b; }
 }
 
+// ---- minibatch losses of the torch-optimizer paths, one block per minibatch ----
+// loss 0: MSE(mu, a)            torch.nn.MSELoss, mean over B*m elements        behavior_cloning.py:96-105
+// loss 1: -mean LL(a | mu, s)   mean_LL of gaussian_mlp.py:99-115               behavior_cloning.py:83-94
+// loss 2: -mean min(LR adv, clamp(LR, 1-c, 1+c) adv), LR = exp(LL - LL_old)     ppo_clip.py:49-56
+// writes d3 = dLoss/d(pre-affine output) (B x m), gls = dLoss/dlog_std (m) and the loss value.
+// rows: gathered minibatch (mu, mu_old, act, adv are B-row blocks)
+__global__ __launch_bounds__(256) void k_minibatch_head(int loss, const float* __restrict__ mu, const float* __restrict__ mu_old,
+                                                        const float* __restrict__ act, const float* __restrict__ adv, int B, int m,
+                                                        const float* __restrict__ ls, const float* __restrict__ ls_old,
+                                                        const float* __restrict__ osc, float clip, float* __restrict__ d3,
+                                                        float* __restrict__ gls, double* __restrict__ loss_out) {
+  __shared__ double sh[17];
+  __shared__ float sg[MPH], sgo[MPH], lsn[MPH], lso[MPH], oscs[MPH];
+  __shared__ double glacc[MPH];
+  if (threadIdx.x < m) {
+    lsn[threadIdx.x] = ls[threadIdx.x]; sg[threadIdx.x] = expf(ls[threadIdx.x]);
+    lso[threadIdx.x] = ls_old ? ls_old[threadIdx.x] : 0.f; sgo[threadIdx.x] = ls_old ? expf(ls_old[threadIdx.x]) : 1.f;
+    oscs[threadIdx.x] = osc[threadIdx.x];
+    glacc[threadIdx.x] = 0.0;
+  }
+  __syncthreads();
+  const float invB = 1.0f / (float)B;
+  double lacc = 0.0;
+  float sumn = 0.f, sumo = 0.f;
+  for (int a = 0; a < m; ++a) { sumn += lsn[a]; sumo += lso[a]; }
+  const float c = 0.5f * (float)m * 1.8378770664093453f;
+  // per-row weight w: dLoss/dLL of the row (MLE: -1/B; PPO: -adv LR mask / B)
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    if (loss == 0) {
+      for (int a = 0; a < m; ++a) {
+        const float e = mu[i * m + a] - act[i * m + a];
+        d3[i * m + a] = oscs[a] * (2.0f * e * invB / (float)m);
+        lacc += (double)e * (double)e;
+      }
+    } else {
+      float lln = 0.f, llo = 0.f;
+      for (int a = 0; a < m; ++a) {
+        const float x = act[i * m + a];
+        const float zn = (x - mu[i * m + a]) / sg[a];
+        lln = fmaf(-0.5f * zn, zn, lln);
+        if (loss == 2) { const float zo = (x - mu_old[i * m + a]) / sgo[a]; llo = fmaf(-0.5f * zo, zo, llo); }
+      }
+      lln = lln - sumn - c;
+      float w;
+      if (loss == 1) { w = -invB; lacc += (double)lln; }
+      else {
+        llo = llo - sumo - c;
+        const float LR = expf(lln - llo), ad = adv[i];
+        const float s1 = LR * ad, s2 = fminf(fmaxf(LR, 1.0f - clip), 1.0f + clip) * ad;
+        lacc += (double)fminf(s1, s2);
+        const bool inside = (LR >= 1.0f - clip) && (LR <= 1.0f + clip);
+        // d min(s1, s2)/dLR: adv where the unclipped branch is (co-)active; ties inside the clip range add up to adv
+        w = (inside || s1 < s2) ? -ad * LR * invB : 0.f;
+      }
+      for (int a = 0; a < m; ++a) {
+        const float zn = (act[i * m + a] - mu[i * m + a]) / sg[a];
+        d3[i * m + a] = oscs[a] * (w * zn / sg[a]);                  // dLL/dmu = z / sigma
+      }
+    }
+  }
+  // dLoss/dlog_std[a] = sum_rows w (z^2 - 1): one fixed-order block reduction per action
+  if (loss != 0) {
+    for (int a = 0; a < m; ++a) {
+      double g = 0.0;
+      for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        float lln = 0.f, llo = 0.f, w;
+        if (loss == 1) w = -invB;
+        else {
+          for (int b = 0; b < m; ++b) {
+            const float x = act[i * m + b];
+            const float zn = (x - mu[i * m + b]) / sg[b];
+            lln = fmaf(-0.5f * zn, zn, lln);
+            const float zo = (x - mu_old[i * m + b]) / sgo[b]; llo = fmaf(-0.5f * zo, zo, llo);
+          }
+          const float LR = expf((lln - sumn - c) - (llo - sumo - c)), ad = adv[i];
+          const float s1 = LR * ad, s2 = fminf(fmaxf(LR, 1.0f - clip), 1.0f + clip) * ad;
+          const bool inside = (LR >= 1.0f - clip) && (LR <= 1.0f + clip);
+          w = (inside || s1 < s2) ? -ad * LR * invB : 0.f;
+        }
+        const float z = (act[i * m + a] - mu[i * m + a]) / sg[a];
+        g += (double)(w * (z * z - 1.0f));
+      }
+      g = block_sum(g, sh);
+      if (threadIdx.x == 0) gls[a] = (float)g;
+    }
+  }
+  lacc = block_sum(lacc, sh);
+  if (threadIdx.x == 0 && loss_out) {
+    if (loss == 0) loss_out[0] = lacc / ((double)B * (double)m);
+    else loss_out[0] = -lacc / (double)B;
+  }
+}
+
+// rows idx[0..B) of the batch -> contiguous minibatch blocks
+__global__ void k_gather_minibatch(const float* __restrict__ obs, const float* __restrict__ act, const float* __restrict__ adv,
+                                   const int32_t* __restrict__ idx, int B, int n, int m, float* __restrict__ Xb,
+                                   float* __restrict__ Ab, float* __restrict__ advb) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+  for (int i = t; i < B * n; i += T) { const int r = i / n, c = i - r * n; Xb[i] = obs[(int64_t)idx[r] * n + c]; }
+  for (int i = t; i < B * m; i += T) { const int r = i / m, c = i - r * m; Ab[i] = act[(int64_t)idx[r] * m + c]; }
+  if (adv) for (int i = t; i < B; i += T) advb[i] = adv[idx[i]];
+}
+
 // FVP head: d3 = out_scale * D * mudot / N,  D = 2/(2 sigma^2 + 1e-8)   (in place on mudot)
 __global__ void k_fvp_head(float* __restrict__ mudot, int64_t N, int m, const float* __restrict__ ls,
                            const float* __restrict__ osc, float inv_N) {

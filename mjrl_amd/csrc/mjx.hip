@@ -76,6 +76,8 @@ struct mjx_ctx {
   std::vector<hipEvent_t> prof_ev;   // pairs
   size_t prof_used = 0;
   mjx::LayerwiseWS lw;             // layer-wise path workspace
+  mjx::LayerwiseWS lwmb;           // minibatch trainer workspace (mjx_policy_minibatch_adam)
+  float *mb_x = nullptr, *mb_a = nullptr, *mb_adv = nullptr, *mb_grad = nullptr; int mb_cap = 0;
 };
 
 namespace {
@@ -214,6 +216,7 @@ int mjx_create(mjx_ctx** out, int device, int n, int m, const int* hidden, int n
   HIPCHK(hipMemcpy(c->ident_tr, id.data(), id.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(c->spartials, 0, (size_t)c->grid * 4 * sizeof(double)));
   c->lw.init(n, m, c->hidden);
+  c->lwmb.init(n, m, c->hidden);
   *out = c;
   return MJX_OK;
 }
@@ -222,6 +225,8 @@ void mjx_destroy(mjx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   c->lw.release();
+  c->lwmb.release();
+  hipFree(c->mb_x); hipFree(c->mb_a); hipFree(c->mb_adv); hipFree(c->mb_grad);
   for (auto& e : c->prof_ev) hipEventDestroy(e);
   hipFree(c->hcache);
   hipFree(c->ocache);
@@ -676,6 +681,47 @@ int mjx_policy_forward(mjx_ctx* c, const float* obs, int64_t N, const float* the
   if (c->lw.cap < N) { if (int rc = c->lw.reserve(N)) return fail(rc, "layer-wise workspace allocation failed"); }
   c->lw.invalidate();                           // the hidden activations of the bound policy are overwritten (scratch)
   c->lw.forward(theta, tr ? tr : c->ident_tr, obs, N, c->lw.T, mean_out, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
+int mjx_policy_minibatch_adam(mjx_ctx* c, int loss, const float* obs, const float* act, const float* adv, const int32_t* idx,
+                              int64_t steps, int B, float* theta, const float* tr, const float* theta_old, const float* tr_old,
+                              int old_tracks_new, float* adam_m, float* adam_v, int64_t step0, float lr, float clip,
+                              double* loss_trace, void* stream) {
+  if (!c || loss < 0 || loss > 2 || steps < 0 || B <= 0 || step0 < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (steps == 0) return MJX_OK;
+  if (!obs || !act || !idx || !theta || !adam_m || !adam_v) return fail(MJX_ERR_ARG, "null buffer");
+  if (loss == 2 && (!adv || !theta_old)) return fail(MJX_ERR_ARG, "PPO needs advantages and the old parameters");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(c->device));
+  LayerwiseWS& w = c->lwmb;
+  if (w.cap < B) { if (int rc = w.reserve(B)) return fail(rc, "minibatch workspace allocation failed"); }
+  if (c->mb_cap < B) {
+    hipFree(c->mb_x); hipFree(c->mb_a); hipFree(c->mb_adv);
+    HIPCHK(hipMalloc(&c->mb_x, (size_t)B * c->n * 4)); HIPCHK(hipMalloc(&c->mb_a, (size_t)B * c->m * 4)); HIPCHK(hipMalloc(&c->mb_adv, (size_t)B * 4));
+    c->mb_cap = B;
+  }
+  if (!c->mb_grad) HIPCHK(hipMalloc(&c->mb_grad, (size_t)c->d * 4));
+  const float* trn = tr ? tr : c->ident_tr;
+  const float* tro = tr_old ? tr_old : c->ident_tr;
+  const int64_t cnt = (loss == 0) ? (int64_t)c->oS : c->d;       // MSE: log_std has no gradient -> untouched (like torch's grad None)
+  const int ggrid = (B * (c->n > c->m ? c->n : c->m) + 255) / 256;
+  for (int64_t s = 0; s < steps; ++s) {
+    hipLaunchKernelGGL(k_gather_minibatch, dim3(ggrid < 1 ? 1 : (ggrid > 1024 ? 1024 : ggrid)), dim3(256), 0, st, obs, act,
+                       (loss == 2) ? adv : (const float*)nullptr, idx + s * B, B, c->n, c->m, c->mb_x, c->mb_a, c->mb_adv);
+    const bool old_fwd = (loss == 2) && !old_tracks_new;
+    if (old_fwd) w.forward(theta_old, tro, c->mb_x, B, w.T, w.mu2, st);          // old policy on the minibatch (activations are scratch)
+    w.forward(theta, trn, c->mb_x, B, w.H, w.mu, st);
+    hipLaunchKernelGGL(k_minibatch_head, dim3(1), dim3(256), 0, st, loss, w.mu, (loss == 2) ? (old_fwd ? w.mu2 : w.mu) : (const float*)nullptr, c->mb_a,
+                       c->mb_adv, B, c->m, theta + c->oS, (loss == 2) ? theta_old + c->oS : (const float*)nullptr, trn + 2 * c->n + c->m,
+                       clip, w.d3, c->mb_grad + c->oS, loss_trace ? loss_trace + s : (double*)nullptr);
+    if (int rc = w.backward(theta, B, c->mb_grad, st)) return fail(MJX_ERR_STATE, "minibatch backward failed (%d)", rc);
+    const double t = (double)(step0 + s + 1);
+    const float bc1 = (float)(1.0 - std::pow(0.9, t)), bc2s = (float)std::sqrt(1.0 - std::pow(0.999, t));
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, theta, c->mb_grad, adam_m, adam_v, cnt, lr, 0.f,
+                       0.9f, 0.999f, 1e-8f, bc1, bc2s);
+  }
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }

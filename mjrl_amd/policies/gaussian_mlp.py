@@ -169,6 +169,14 @@ class MLP:
     def set_param_values(self, new_params, set_new=True, set_old=True):
         """gaussian_mlp.py:65-87 (float32 cast, log_std clamped at min_log_std); written in place so
         the torch views handed to optimisers stay valid."""
+        # Reference quirk worth knowing (gaussian_mlp.py:65-87): `torch.from_numpy(vals).float()` is a no-copy view
+        # when `new_params` is float32, so after a call with set_new and set_old the reference's new and old NETWORK
+        # tensors share memory (log_std does not: torch.clamp makes a fresh tensor).  Nothing in NPG / TRPO / DAPG
+        # mutates parameters in place, so it is invisible there; the in-place torch optimizers (PPO) do see it --
+        # `ppo_clip.PPO` reads this flag to reproduce the reference's numbers.
+        self.reference_new_old_alias = bool(set_new and set_old and isinstance(new_params, np.ndarray)
+                                            and new_params.dtype == np.float32) if (set_new or set_old) else \
+            getattr(self, "reference_new_old_alias", False)
         vals = np.asarray(new_params, dtype=np.float32).ravel()
         assert vals.size == self.d
         if set_new:
