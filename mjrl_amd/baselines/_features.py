@@ -35,13 +35,29 @@ def path_inputs(paths, inp):
     return np.ascontiguousarray(o, dtype=np.float64), tpos
 
 
+class _StagerBackend:
+    """what utils/ingest.PathStager needs from a backend"""
+
+    def __init__(self, torch, device, lib):
+        self.torch, self.device, self.lib = torch, device, lib
+
+
 class DeviceBlock:
     def __init__(self, paths, inp):
         self.torch, self.dev = torch_dev()
         self.lib = _lib.load()
-        o, tpos = path_inputs(paths, inp)
-        self.N, self.n = o.shape
-        self.obs = self.torch.from_numpy(o).to(self.dev)
+        first = paths[0]["observations"] if inp != 'env_features' else None
+        if first is not None and first.ndim == 2 and first.dtype == np.float64:
+            # the fp64 observation block of this batch: uploaded once per process (page-locked staging), shared with
+            # the policy update and the other baseline call of the iteration (utils/ingest.stage_shared)
+            from ..utils.ingest import stage_shared
+            self.obs = stage_shared(_StagerBackend(self.torch, self.dev, self.lib), paths, ("observations",))["observations"]["raw"]
+            self.N, self.n = int(self.obs.shape[0]), int(self.obs.shape[1])
+            tpos = np.concatenate([np.arange(len(p["rewards"]), dtype=np.int32) for p in paths])
+        else:
+            o, tpos = path_inputs(paths, inp)
+            self.N, self.n = o.shape
+            self.obs = self.torch.from_numpy(o).to(self.dev)
         self.tpos = self.torch.from_numpy(tpos).to(self.dev)
 
     def st(self):

@@ -200,12 +200,12 @@ class UpdateEngine:
 
     def stage_paths(self, paths, keys=("observations", "actions")):
         """per-path host arrays -> fp32 device blocks through the page-locked stager (utils/ingest.py): no
-        concatenated host copy, chunked transfers overlapped with the staging copies.  The tensors stay valid
-        until the next call."""
-        if getattr(self, "_stager", None) is None:
-            from .utils.ingest import PathStager
-            self._stager = PathStager(self.backend)
-        return self._stager.stage(paths, keys)
+        concatenated host copy, chunked transfers overlapped with the staging copies.  One upload per batch and
+        process: the value baselines (predict before, fit after the update) share it (utils/ingest.stage_shared)."""
+        if getattr(self, "_stager", None) is not None:             # a caller-supplied stager (tools, tests)
+            return self._stager.stage(paths, keys)
+        from .utils.ingest import stage_shared
+        return {k: v["f32"] for k, v in stage_shared(self.backend, paths, keys).items()}
 
     def bind_rows(self, rows, adv=None, N_global=None):
         """(re)bind the first `rows` samples of the uploaded block (DAPG runs the Fisher on the

@@ -45,19 +45,22 @@ class PathStager:
 
     # ------------------------------------------------------------------ buffers
     def _slot(self, key, width, dtype, rows):
+        """the page-locked staging block is kept across batches; the device tensors are allocated per batch (torch's
+        caching allocator recycles the memory), so tensors handed out for an earlier batch stay valid while referenced"""
         torch = self.torch
         s = self._slots.get(key)
+        tdt = torch.float64 if dtype == np.float64 else torch.float32
         if s is None or s["width"] != width or s["dtype"] != dtype or s["cap"] < rows:
             cap = max(rows, int(1.25 * (s["cap"] if s and s["width"] == width and s["dtype"] == dtype else 0)))
-            tdt = torch.float64 if dtype == np.float64 else torch.float32
             pin = torch.empty((cap, width), dtype=tdt, pin_memory=self.on_gpu)
-            dev_raw = torch.empty((cap, width), dtype=tdt, device=self.device) if self.on_gpu else pin
-            if tdt == torch.float64:
-                dev_f32 = torch.empty((cap, width), dtype=torch.float32, device=self.device)
-            else:
-                dev_f32 = dev_raw
-            s = dict(pin=pin, pin_np=pin.numpy(), dev_raw=dev_raw, dev_f32=dev_f32, width=width, dtype=dtype, cap=cap)
+            s = dict(pin=pin, pin_np=pin.numpy(), width=width, dtype=dtype, cap=cap)
             self._slots[key] = s
+        if self.on_gpu:
+            s["dev_raw"] = torch.empty((rows, width), dtype=tdt, device=self.device)
+            s["dev_f32"] = torch.empty((rows, width), dtype=torch.float32, device=self.device) if tdt == torch.float64 else s["dev_raw"]
+        else:                                           # CPU stand-in (tests): same ownership rules, plain memory
+            s["dev_raw"] = torch.empty((rows, width), dtype=tdt)
+            s["dev_f32"] = torch.empty((rows, width), dtype=torch.float32) if tdt == torch.float64 else s["dev_raw"]
         return s
 
     # ------------------------------------------------------------------ incremental interface
@@ -92,6 +95,7 @@ class PathStager:
         for k in self._keys:
             s = self._slots[k]
             if not self.on_gpu:
+                s["dev_raw"][lo:hi].copy_(s["pin"][lo:hi])
                 if s["dev_f32"] is not s["dev_raw"]:
                     s["dev_f32"][lo:hi].copy_(s["pin"][lo:hi])       # fp64 -> fp32 (round to nearest even, like astype)
                 continue
@@ -176,6 +180,10 @@ class PathStager:
             self.torch.cuda.current_stream(self.device).wait_stream(self.side)
         return {k: self._slots[k]["dev_f32"][:self._rows] for k in self._keys}
 
+    def raw(self, key):
+        """the batch as it was uploaded (fp64 when the paths are fp64): what the value baselines' feature kernels read"""
+        return self._slots[key]["dev_raw"][:self._rows]
+
     # ------------------------------------------------------------------ one-shot
     def stage(self, paths, keys=("observations", "actions")):
         first = paths[0]
@@ -190,3 +198,42 @@ class PathStager:
         if self.pool is not None:
             self.pool.shutdown(wait=True)
             self.pool = None
+
+
+# ---------------------------------------------------------------------- one upload per batch and process
+# A training iteration touches the same trajectories three times -- baseline.predict (advantages), the policy
+# update, baseline.fit (mjrl/algos/batch_reinforce.py:61-114) -- and the reference rebuilds / re-casts the
+# concatenated arrays every time.  The registry below keeps the last staged batch per device: whoever asks first
+# uploads, the others get the same device tensors.
+_SHARED = {}
+
+
+def _fingerprint(paths, key):
+    first, last = paths[0][key], paths[-1][key]
+    probe = (float(first.flat[0]), float(first.flat[-1]), float(last.flat[0]), float(last.flat[-1]))
+    return (id(paths), len(paths), id(first), id(last), first.shape, last.shape, probe)
+
+
+def stage_shared(backend, paths, keys):
+    """-> dict key -> dict(f32=(N, w) fp32 device tensor, raw=(N, w) tensor in the paths' dtype).  Re-uses the upload
+    of the same `paths` list (same objects, same end-point values) made earlier in this process on this device."""
+    dev = backend.device
+    reg = _SHARED.setdefault((dev.type, dev.index), {})
+    out = {}
+    for k in keys:
+        fp = _fingerprint(paths, k)
+        ent = reg.get(k)
+        if ent is None or ent["fp"] != fp:
+            st = ent["stager"] if ent is not None else PathStager(backend)
+            f32 = st.stage(paths, (k,))[k]
+            ent = reg[k] = dict(fp=fp, stager=st, f32=f32, raw=st.raw(k))
+        out[k] = dict(f32=ent["f32"], raw=ent["raw"])
+    return out
+
+
+def drop_shared():
+    """forget the staged batches (tests; releasing device memory)"""
+    for reg in _SHARED.values():
+        for ent in reg.values():
+            ent["stager"].close()
+    _SHARED.clear()

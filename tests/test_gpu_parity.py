@@ -766,3 +766,40 @@ def test_update_is_bit_reproducible_and_handles_odd_sizes():
         hvt = O.fvp(th.astype(np.float64), o.astype(np.float64), truth, n, m, hid, tr64)
         assert rel(hv, hvt) < TOL_FVP, Ns
     eng.close()
+
+
+def test_one_upload_per_batch_shared_by_update_and_baselines():
+    """baseline.predict / the policy update / baseline.fit of one iteration read ONE device copy of the observations
+    (utils/ingest.stage_shared); a new batch gets new tensors and leaves the previous ones intact."""
+    import torch
+    from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+    from mjrl_amd.engine import UpdateEngine
+    from mjrl_amd.utils import ingest
+    ingest.drop_shared()
+    n, m = 17, 6
+    spec = type("Spec", (), dict(observation_dim=n, action_dim=m, horizon=100))
+    rng = np.random.RandomState(2)
+
+    def mk():
+        return [dict(observations=rng.randn(T, n), actions=rng.randn(T, m), rewards=rng.randn(T), returns=rng.randn(T)) for T in (50, 77, 100)]
+    paths = mk()
+    bl = QuadraticBaseline(spec)
+    bl.fit(paths)
+    pred = bl.predict(paths[1])
+    eng = UpdateEngine(n, m, (64, 64))
+    st = eng.stage_paths(paths)
+    reg = ingest._SHARED[("cuda", torch.cuda.current_device())]
+    assert st["observations"].data_ptr() == reg["observations"]["f32"].data_ptr()
+    up1 = reg["observations"]["raw"].data_ptr()
+    bl.fit(paths)                                           # same batch again: no new upload
+    assert reg["observations"]["raw"].data_ptr() == up1
+    np.testing.assert_array_equal(st["observations"].cpu().numpy(), np.concatenate([p["observations"] for p in paths]).astype(np.float32))
+    keep = st["observations"]
+    snapshot = keep.cpu().numpy().copy()
+    paths2 = mk()
+    st2 = eng.stage_paths(paths2)
+    assert st2["observations"].data_ptr() != keep.data_ptr()
+    np.testing.assert_array_equal(keep.cpu().numpy(), snapshot)          # the earlier batch is untouched while referenced
+    np.testing.assert_array_equal(st2["observations"].cpu().numpy(), np.concatenate([p["observations"] for p in paths2]).astype(np.float32))
+    assert np.all(np.isfinite(pred))
+    eng.close()

@@ -1,0 +1,30 @@
+"""Device-side cost of one training iteration at 1M timesteps (everything train_step does after sampling,
+mjrl/algos/batch_reinforce.py:93-114): returns, baseline prediction + GAE, the NPG update, the baseline fit."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from mjrl_amd.algos.npg_cg import NPG
+from mjrl_amd.baselines.mlp_baseline import MLPBaseline
+from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+from mjrl_amd.policies.gaussian_mlp import MLP
+from mjrl_amd.utils import process_samples
+spec = type("Spec", (), dict(observation_dim=17, action_dim=6, horizon=1000))
+rng = np.random.RandomState(0)
+out = {}
+for name in ("quadratic", "mlp"):
+    pol = MLP(spec, hidden_sizes=(64, 64), seed=1, init_log_std=-0.5)
+    bl = QuadraticBaseline(spec) if name == "quadratic" else MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3)
+    agent = NPG(None, pol, bl, normalized_step_size=0.05)
+    ts = []
+    for it in range(3):
+        paths = [dict(observations=rng.randn(1000, 17), actions=rng.randn(1000, 6), rewards=rng.randn(1000), terminated=False) for _ in range(1000)]
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        process_samples.compute_returns(paths, 0.995); t1 = time.perf_counter()
+        process_samples.compute_advantages(paths, bl, 0.995, 0.97); t2 = time.perf_counter()
+        agent.train_from_paths(paths); torch.cuda.synchronize(); t3 = time.perf_counter()
+        bl.fit(paths); torch.cuda.synchronize(); t4 = time.perf_counter()
+        ts.append([t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0])
+    best = min(ts[1:], key=lambda r: r[-1])
+    out[name] = dict(zip(["returns_ms", "advantages_ms", "update_ms", "baseline_fit_ms", "total_ms"], [round(1e3 * x, 2) for x in best]))
+print(json.dumps(out))
