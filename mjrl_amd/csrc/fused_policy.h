@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
           if (FWD) wc[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f00];
           if (TAN) vc[mt] = *(const f32x2*)&slotB[L.oW1 + (32 * mt + j) * S1 + f00];
         }
-#pragma unroll(NPC ? NPC / 4 : 1)
+#pragma unroll NPC ? NPC / 4 : 1
         for (int q = 0; q < (NPC ? NPC / 4 : NP / 4); ++q) {
           const int f0 = 4 * q + 2 * hi;
           const int f1 = (q + 1 < NP / 4) ? f0 + 4 : f0;        // next group (clamped on the last trip)
