@@ -692,17 +692,22 @@ struct LayerwiseWS {
         g.B[0] = in; g.b_cs[0] = 1; g.b_ks[0] = hi_;
         g.ldc = hi_;
       }
-      g.C = part; g.c_zs = (int64_t)ho * hi_;
+      // (a single split / row block -- minibatches -- writes the gradient blocks directly: no reduction launches)
+      g.C = (splits == 1) ? grad + oW[l] : part; g.c_zs = (int64_t)ho * hi_;
       g.epi = EPI_STORE;
       launch_gemm(g, splits, st);
-      hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid((int64_t)ho * hi_)), dim3(256), 0, st, part, splits, (int64_t)ho * hi_, grad + oW[l]);
+      if (splits > 1)
+        hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid((int64_t)ho * hi_)), dim3(256), 0, st, part, splits, (int64_t)ho * hi_, grad + oW[l]);
       float* bpart = part + (int64_t)splits * ho * hi_;
       float* cpart = bpart + (int64_t)csplits * ho;
       if (!bias_done) {
-        if (ho <= 32) hipLaunchKernelGGL(k_colsum_narrow<32>, dim3(csplits), dim3(256), 0, st, delta, N, ho, bpart);
-        else hipLaunchKernelGGL(k_colsum, dim3((ho + 63) / 64, csplits), dim3(256), 0, st, delta, N, ho, (int64_t)ho, bpart);
-        hipLaunchKernelGGL(k_reduce_partials, dim3((ho + 15) / 16), dim3(256), 0, st, bpart, csplits, ho, grad + ob[l],
-                           (const float*)nullptr, (const float*)nullptr, 0, 0.f);
+        const int cs = (N <= 4096) ? 1 : csplits;
+        float* dst = (cs == 1) ? grad + ob[l] : bpart;
+        if (ho <= 32) hipLaunchKernelGGL(k_colsum_narrow<32>, dim3(cs), dim3(256), 0, st, delta, N, ho, dst);
+        else hipLaunchKernelGGL(k_colsum, dim3((ho + 63) / 64, cs), dim3(256), 0, st, delta, N, ho, (int64_t)ho, dst);
+        if (cs > 1)
+          hipLaunchKernelGGL(k_reduce_partials, dim3((ho + 15) / 16), dim3(256), 0, st, bpart, cs, ho, grad + ob[l],
+                             (const float*)nullptr, (const float*)nullptr, 0, 0.f);
       }
       if (l > 0) {
         // delta_{l} = (delta_{l+1} W_l) (1 - H_{l-1}^2)   -> T[l-1]   (+ its column sums = grad b_{l-1})
@@ -713,10 +718,11 @@ struct LayerwiseWS {
         b.C = T[l - 1]; b.ldc = hi_; b.c_zs = 0;
         b.aux = H[l - 1]; b.ld_aux = hi_;
         b.epi = EPI_BACK;
-        b.colsum = cpart;
+        b.colsum = (rowblocks == 1) ? grad + ob[l - 1] : cpart;
         launch_gemm(b, 1, st);
-        hipLaunchKernelGGL(k_reduce_partials, dim3((hi_ + 15) / 16), dim3(256), 0, st, cpart, rowblocks, hi_, grad + ob[l - 1],
-                           (const float*)nullptr, (const float*)nullptr, 0, 0.f);
+        if (rowblocks > 1)
+          hipLaunchKernelGGL(k_reduce_partials, dim3((hi_ + 15) / 16), dim3(256), 0, st, cpart, rowblocks, hi_, grad + ob[l - 1],
+                             (const float*)nullptr, (const float*)nullptr, 0, 0.f);
         bias_done = true;
         delta = T[l - 1];
       }
