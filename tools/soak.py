@@ -1,0 +1,41 @@
+"""Soak: 300 NPG / TRPO / PPO iterations with batches of changing size and raggedness; checks finiteness, KL behaviour and that
+device memory does not grow."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from mjrl_amd.algos.npg_cg import NPG
+from mjrl_amd.algos.trpo import TRPO
+from mjrl_amd.algos.ppo_clip import PPO
+from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+from mjrl_amd.policies.gaussian_mlp import MLP
+from mjrl_amd.utils import process_samples
+spec = type("Spec", (), dict(observation_dim=17, action_dim=6, horizon=1000))
+rng = np.random.RandomState(0)
+out = {}
+for name, cls, kw in (("npg", NPG, dict(normalized_step_size=0.05)), ("trpo", TRPO, dict(kl_dist=0.01)), ("ppo", PPO, dict(epochs=1, mb_size=256))):
+    pol = MLP(spec, hidden_sizes=(64, 64), seed=1, init_log_std=-0.5)
+    bl = QuadraticBaseline(spec)
+    agent = cls(None, pol, bl, **kw)
+    mem = []
+    t0 = time.perf_counter()
+    for it in range(100):
+        n_traj = int(rng.randint(20, 200))
+        paths = []
+        for _ in range(n_traj):
+            T = int(rng.randint(1, 1000))
+            obs = rng.randn(T, 17)
+            act = pol.model.forward(np.float32(obs)) + np.exp(pol.log_std_val) * rng.randn(T, 6)
+            paths.append(dict(observations=obs, actions=act, rewards=-np.sum(act ** 2, axis=1) + rng.randn(T) * 0.1, terminated=bool(T < 999)))
+        process_samples.compute_returns(paths, 0.995)
+        process_samples.compute_advantages(paths, bl, 0.995, 0.97)
+        stats = agent.train_from_paths(paths)
+        bl.fit(paths)
+        th = pol.get_param_values()
+        assert np.all(np.isfinite(th)) and np.all(np.isfinite(stats)), (name, it)
+        if name != "ppo":
+            assert 0.0 <= agent.last_update["kl_dist"] < 0.2, (name, it, agent.last_update)
+        mem.append(torch.cuda.memory_allocated())
+    out[name] = dict(seconds=round(time.perf_counter() - t0, 2), mem_first_MB=round(mem[10] / 2**20, 1), mem_last_MB=round(mem[-1] / 2**20, 1),
+                     mem_max_MB=round(max(mem) / 2**20, 1), final_log_std=float(np.mean(pol.log_std_val)))
+print(json.dumps(out))
