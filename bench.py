@@ -148,12 +148,13 @@ def main():
     last = {}
 
     def one_update():
-        g, surr_before = eng.surr_vpg()
-        _, gdotx = eng.cg_solve(g, CG_ITERS, DAMPING)
-        alpha = np.sqrt(np.abs(STEP / (gdotx + 1e-20)))
-        eng.apply_step(alpha, -3.0)
+        # the call sequence of NPG.train_from_paths (mjrl_amd/algos/npg_cg.py): everything is enqueued, one read-back
+        g, _ = eng.surr_vpg(sync=False)
+        eng.cg_solve(g, CG_ITERS, DAMPING, sync=False)
+        eng.apply_npg_step(STEP, -3.0)                  # alpha = sqrt(|delta / (g.x + 1e-20)|) formed on the device
         surr_after, kl = eng.eval_surr_kl()
-        last.update(alpha=float(alpha), kl=kl, surr_improvement=surr_after - surr_before)
+        late = eng.deferred()
+        last.update(alpha=late["alpha"], kl=kl, surr_improvement=surr_after - late["surr_before"])
         # old := new happens here in training; the bench restores theta0 so every step does identical work
         eng.theta_new.copy_(theta0_dev)
         eng.old_is_new = True

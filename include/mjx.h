@@ -131,6 +131,12 @@ int mjx_cg_finish(mjx_ctx* ctx, const float* b, float* x_out, double* bdotx_out,
 int mjx_apply_step(mjx_ctx* ctx, const float* theta, const float* x, float alpha,
                    float min_log_std, float* theta_out, void* stream);
 
+/* The same with the normalised NPG step length formed on the device from the solve's g.x (bdotx_out of mjx_cg_solve /
+ * mjx_cg_finish): alpha = sqrt(|step_size / (g.x + 1e-20)|) in fp64 (npg_cg.py:133), written to alpha_out (device,
+ * optional).  Lets a caller enqueue surrogate -> solve -> step -> evaluation without reading anything back in between. */
+int mjx_apply_npg_step(mjx_ctx* ctx, const float* theta, const float* x, const double* gdotx, double step_size,
+                       float min_log_std, float* theta_out, double* alpha_out, void* stream);
+
 /* ---- K5: returns / GAE over ragged trajectories --------------------------- */
 /* y[t] = x[t] + gamma*y[t+1] within each trajectory [offsets[i], offsets[i+1]),
  * terminal value 0 (process_samples.discount_sum :37-44, compute_returns :3-5). fp64. */

@@ -59,9 +59,9 @@ class NPG(BatchREINFORCE):
         self.engine.set_batch(inputs[0], inputs[1] if len(inputs) > 1 else None)
         return DeviceFisher(self.engine, regu_coef)
 
-    def CG_solve(self, b, iters=None, damping=None):
+    def CG_solve(self, b, iters=None, damping=None, sync=True):
         """x = (H + damping I)^-1 b by CG on the currently bound batch; b is a device tensor or
-        a host vector; returns (x device tensor, b.x)."""
+        a host vector; returns (x device tensor, b.x).  sync=False leaves b.x on the device (engine.deferred())."""
         eng = self.engine
         if not hasattr(b, "data_ptr"):
             b = eng.torch.from_numpy(np.asarray(b, np.float32)).to(eng.device)
@@ -69,7 +69,7 @@ class NPG(BatchREINFORCE):
         damping = self.FIM_invert_args['damping'] if damping is None else damping
         if self.hvp_subsample is not None and self.hvp_subsample < 0.99:
             return self._cg_subsampled(b, iters, damping)
-        return eng.cg_solve(b, iters, damping)
+        return eng.cg_solve(b, iters, damping, sync=sync)
 
     def _cg_subsampled(self, b, iters, damping):
         """hvp_sample_frac < 0.99: a fresh with-replacement row sample per product, drawn from
@@ -124,23 +124,33 @@ class NPG(BatchREINFORCE):
             self.log_rollout_statistics(paths)
         eng = self.engine
 
+        # The whole update is enqueued without reading anything back: the normalised step length is formed on the device
+        # from g.x; surrogate-before, g.x and alpha are fetched once, after the evaluation kernel (t_gLL / t_FIM are
+        # therefore enqueue times unless the constant-alpha branch needs g.x on the host).
+        const_alpha = self.alpha is not None
+        subsampled = self.hvp_subsample is not None and self.hvp_subsample < 0.99
         t0 = timer.time()
-        g, surr_before = eng.surr_vpg()                       # npg_cg.py:111-115
+        g, surr_before = eng.surr_vpg(sync=False)             # npg_cg.py:111-115
         t_gLL = timer.time() - t0
 
         t0 = timer.time()
-        _, gdotx = self.CG_solve(g)                           # npg_cg.py:120-123
+        _, gdotx = self.CG_solve(g, sync=const_alpha or subsampled)   # npg_cg.py:120-123
         t_FIM = timer.time() - t0
 
-        if self.alpha is not None:                            # npg_cg.py:128-133
+        if const_alpha:                                       # npg_cg.py:128-133
+            if gdotx is None:
+                gdotx = eng.deferred()["gdotx"]
             alpha = self.alpha
             n_step_size = (alpha ** 2) * gdotx
+            eng.apply_step(alpha, self.policy.min_log_std)    # npg_cg.py:137-139
         else:
             n_step_size = self.n_step_size
-            alpha = np.sqrt(np.abs(self.n_step_size / (gdotx + 1e-20)))
-
-        eng.apply_step(alpha, self.policy.min_log_std)        # npg_cg.py:137-139
+            eng.apply_npg_step(self.n_step_size, self.policy.min_log_std)   # alpha = sqrt(|delta / (g.x + 1e-20)|), on the device
         surr_after, kl_dist = eng.eval_surr_kl()              # npg_cg.py:140-141
+        late = eng.deferred()
+        surr_before, gdotx = late["surr_before"], late["gdotx"]
+        if not const_alpha:
+            alpha = late["alpha"]
         self.policy.set_param_values(eng.theta_new.cpu().numpy(), set_new=True, set_old=True)
 
         if self.save_logs:

@@ -631,6 +631,15 @@ int mjx_apply_step(mjx_ctx* c, const float* theta, const float* x, float alpha, 
   return MJX_OK;
 }
 
+int mjx_apply_npg_step(mjx_ctx* c, const float* theta, const float* x, const double* gdotx, double step_size, float min_log_std,
+                       float* theta_out, double* alpha_out, void* stream) {
+  if (!c || !theta || !x || !gdotx || !theta_out) return fail(MJX_ERR_ARG, "bad arguments");
+  hipLaunchKernelGGL(k_apply_npg_step, dim3((c->d + 255) / 256), dim3(256), 0, (hipStream_t)stream, theta, x, gdotx, step_size,
+                     min_log_std, theta_out, alpha_out, (int)c->d, c->oS);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
 int mjx_discount_scan(const double* x, const int64_t* offsets, int64_t n_traj, double gamma, double* y, void* stream) {
   if (n_traj == 0) return MJX_OK;
   if (!x || !offsets || !y || n_traj < 0) return fail(MJX_ERR_ARG, "bad arguments");

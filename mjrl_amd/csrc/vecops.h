@@ -176,6 +176,20 @@ __global__ void k_apply_step(const float* __restrict__ theta, const float* __res
   out[i] = v;
 }
 
+// the same with the NPG step length formed on the device: alpha = sqrt(|delta / (g.x + 1e-20)|) in fp64 like
+// npg_cg.py:133, so the host does not have to wait for g.x between the CG solve and the parameter step
+__global__ void k_apply_npg_step(const float* __restrict__ theta, const float* __restrict__ x, const double* __restrict__ gdotx,
+                                 double step_size, float min_log_std, float* out, double* alpha_out, int d, int oS) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double a64 = sqrt(fabs(step_size / (gdotx[0] + 1e-20)));
+  if (i == 0 && alpha_out) alpha_out[0] = a64;
+  if (i >= d) return;
+  const float alpha = (float)a64;
+  float v = __fadd_rn(theta[i], __fmul_rn(alpha, x[i]));
+  if (i >= oS) v = fmaxf(v, min_log_std);
+  out[i] = v;
+}
+
 // ---- K5: reverse discounted scans over ragged trajectories (process_samples.py:21-44) ----
 // One 256-thread block per trajectory; the trajectory is cut into 256 contiguous segments,
 // pass 1 reduces every segment with zero carry, thread 0 chains the 256 carries, pass 2

@@ -108,6 +108,10 @@ class HipBackend:
     def apply_step(self, base, x, alpha, min_log_std, out):
         check(self.lib.mjx_apply_step(self.ctx, ptr(base), ptr(x), float(alpha), float(min_log_std), ptr(out), self.stream()))
 
+    def apply_npg_step(self, base, x, gdotx, step_size, min_log_std, out, alpha_out):
+        check(self.lib.mjx_apply_npg_step(self.ctx, ptr(base), ptr(x), ptr(gdotx), float(step_size), float(min_log_std), ptr(out),
+                                          ptr(alpha_out), self.stream()))
+
 
 class UpdateEngine:
     """Orchestration of one policy update over (possibly) several ranks: owns the tensors, binds
@@ -132,6 +136,8 @@ class UpdateEngine:
         self.Ap = torch.zeros(self.d, **f32)
         self.scal = torch.zeros(4, dtype=torch.float64, device=self.device)
         self.bdotx = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.scal_vpg = torch.zeros(4, dtype=torch.float64, device=self.device)     # K1's sums (kept apart from K3's)
+        self.alpha_dev = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.obs = self.act = self.adv = None
         self.N_local = self.N_global = 0
         self.old_is_new = True
@@ -217,15 +223,17 @@ class UpdateEngine:
         self.backend.bind_rows(int(rows), int(self.N_global), self.adv)
 
     # ------------------------------------------------------------------ kernels + collectives
-    def surr_vpg(self):
+    def surr_vpg(self, sync=True):
         """K1 -> (grad device tensor, surrogate float).  flat_vpg + CPI_surrogate
-        (batch_reinforce.py:40-58)."""
-        self.backend.surr_vpg(self.grad, self.scal)
+        (batch_reinforce.py:40-58).  sync=False: nothing is read back (see deferred())."""
+        self.backend.surr_vpg(self.grad, self.scal_vpg)
         d = _dist()
         if d is not None:
             d.all_reduce(self.grad)
-            d.all_reduce(self.scal)
-        s = self.scal.cpu().numpy()
+            d.all_reduce(self.scal_vpg)
+        if not sync:
+            return self.grad, None                   # the surrogate stays on the device: read it with deferred()
+        s = self.scal_vpg.cpu().numpy()
         return self.grad, float(s[0] / self.N_global)
 
     def fvp(self, v, out=None):
@@ -237,7 +245,7 @@ class UpdateEngine:
             d.all_reduce(out)
         return out
 
-    def cg_solve(self, b, iters, damping, tol=1e-10):
+    def cg_solve(self, b, iters, damping, tol=1e-10, sync=True):
         """K4: x = CG(H + damping I, b), x0 = 0 (cg_solve.py:3-22) -> (x device tensor, b.x).
         One all-reduce of the d-float Fisher-vector product per iteration; the vector updates
         and dot products are recomputed identically on every rank."""
@@ -252,7 +260,7 @@ class UpdateEngine:
                 d.all_reduce(self.Ap)
                 be.cg_step(self.Ap, damping, tol)
             be.cg_finish(b, self.x, self.bdotx)
-        return self.x, float(self.bdotx.item())
+        return self.x, (float(self.bdotx.item()) if sync else None)
 
     def apply_step(self, alpha, min_log_std, base=None):
         """theta_new <- base + alpha * x with the log_std clamp (npg_cg.py:137-139)."""
@@ -260,6 +268,19 @@ class UpdateEngine:
         self.backend.apply_step(base, self.x, alpha, min_log_std, self.theta_new)
         self.old_is_new = False
         self._bind_policy()
+
+    def apply_npg_step(self, step_size, min_log_std, base=None):
+        """theta_new <- base + sqrt(|step_size / (g.x + 1e-20)|) x with the step length formed on the device from the last
+        solve (npg_cg.py:133-139): no read-back between the solve and the step."""
+        base = self.theta_old if base is None else base
+        self.backend.apply_npg_step(base, self.x, self.bdotx, step_size, min_log_std, self.theta_new, self.alpha_dev)
+        self.old_is_new = False
+        self._bind_policy()
+
+    def deferred(self):
+        """-> dict(surr_before, gdotx, alpha) of the calls made with sync=False / apply_npg_step (one read-back after the update)"""
+        s = self.scal_vpg.cpu().numpy()
+        return dict(surr_before=float(s[0] / self.N_global), gdotx=float(self.bdotx.item()), alpha=float(self.alpha_dev.item()))
 
     def eval_surr_kl(self):
         """K3 -> (surrogate, mean KL) (batch_reinforce.py:40-52)."""

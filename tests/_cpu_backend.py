@@ -106,6 +106,11 @@ class OracleBackend:
             self.cg_step(tmp, damping, tol)
         self.cg_finish(b, x_out, bdotx_out)
 
+    def apply_npg_step(self, base, x, gdotx, step_size, min_log_std, out, alpha_out):
+        alpha = np.sqrt(np.abs(float(step_size) / (float(gdotx[0]) + 1e-20)))
+        alpha_out[0] = alpha
+        self.apply_step(base, x, alpha, min_log_std, out)
+
     def apply_step(self, base, x, alpha, min_log_std, out):
         v = base + np.float32(alpha) * x
         v[-self.m:] = torch.clamp(v[-self.m:], min=float(min_log_std))
