@@ -43,6 +43,7 @@ class BatchREINFORCE:
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_engine_obj", None)
+        state.pop("_stage_pool", None)
         return state
 
     def _push_policy(self):
@@ -165,10 +166,19 @@ class BatchREINFORCE:
         host like the reference does, observations / actions go path by path through the engine's page-locked
         stager (utils/ingest.py) -- no concatenated host copy, transfers overlapped with staging.
         -> base_stats; sets self.running_score."""
-        advantages, base_stats, self.running_score = self._advantages_and_statistics(paths)
-        staged = self.engine.stage_paths(paths, ("observations", "actions"))
+        # the gather / upload of observations and actions runs on a helper thread (native memcpy threads + asynchronous
+        # copies, no GIL) while this thread assembles the advantage vector and the path statistics
+        eng = self.engine
+        if getattr(self, "_stage_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._stage_pool = ThreadPoolExecutor(max_workers=1)
+        fut = self._stage_pool.submit(eng.stage_paths, paths, ("observations", "actions"))
+        try:
+            advantages, base_stats, self.running_score = self._advantages_and_statistics(paths)
+        finally:
+            staged = fut.result()
         self._push_policy()
-        self.engine.set_batch(staged["observations"], staged["actions"], advantages)
+        eng.set_batch(staged["observations"], staged["actions"], advantages)
         return base_stats
 
     def _global_mean_std(self, x):

@@ -18,17 +18,23 @@ out = {}
 if len(sys.argv) > 1:
     from mjrl_amd.utils.ingest import PathStager
     agent.engine._stager = PathStager(agent.engine.backend, threads=int(sys.argv[1]), group_rows=int(sys.argv[2]) if len(sys.argv) > 2 else 32768)
-for _ in range(2):
-    agent.train_from_paths(paths)
+def fresh():        # a new batch every time: the staged copy of an earlier list is never reused
+    return [dict(observations=p["observations"].copy(), actions=p["actions"].copy(), rewards=p["rewards"], advantages=p["advantages"],
+                 terminated=False) for p in paths]
+batches = [fresh() for _ in range(8)]
+for b in batches[:2]:
+    agent.train_from_paths(b)
 torch.cuda.synchronize()
 ts = []
-for _ in range(5):
-    t0 = time.perf_counter(); agent.train_from_paths(paths); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+for b in batches[2:7]:
+    t0 = time.perf_counter(); agent.train_from_paths(b); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 out["npg_train_from_paths_end_to_end_ms"] = 1e3 * min(ts)
+out["npg_train_from_paths_end_to_end_ms_median"] = 1e3 * sorted(ts)[len(ts) // 2]
 t0 = time.perf_counter(); agent._advantages_and_statistics(paths); out["advantages_and_statistics_host_ms"] = 1e3 * (time.perf_counter() - t0)
 ts = []
 for _ in range(5):
-    t0 = time.perf_counter(); agent.engine.stage_paths(paths); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    b = fresh()
+    t0 = time.perf_counter(); agent.engine.stage_paths(b); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 out["stage_paths_ms"] = 1e3 * min(ts)
 t0 = time.perf_counter(); o, a, adv, _, _ = agent.process_paths(paths); out["process_paths_concat_host_ms"] = 1e3 * (time.perf_counter() - t0)
 t0 = time.perf_counter(); agent.engine.set_batch(o, a, adv); torch.cuda.synchronize(); out["legacy_upload_ms"] = 1e3 * (time.perf_counter() - t0)
