@@ -1,17 +1,29 @@
-"""mjrl.baselines.zero_baseline.ZeroBaseline drop-in (reference zero_baseline.py:4-14)."""
+"""The "no baseline" baseline: value estimate 0 everywhere, nothing to fit.
+
+Same surface as the other baselines of this package (fit / predict / predict_batch), so the agents and
+utils.process_samples can treat it uniformly; stands in for mjrl.baselines.zero_baseline.ZeroBaseline.
+There is no device work here.
+"""
 import numpy as np
+
+_UNFITTED_ERRORS = (1.0, 1.0)        # (error_before, error_after): a zero predictor explains none of the returns
+
+
+def _zeros_like_rewards(path):
+    return np.zeros(np.shape(path["rewards"])[0], dtype=np.float64)
 
 
 class ZeroBaseline:
-    def __init__(self, env_spec, **kwargs):
-        self._coeffs = None
+    _coeffs = None
 
-    def fit(self, paths, return_errors=False):
-        if return_errors:
-            return 1.0, 1.0
+    def __init__(self, env_spec=None, **unused):
+        self.env_spec = env_spec
 
     def predict(self, path):
-        return np.zeros(len(path["rewards"]))
+        return _zeros_like_rewards(path)
 
     def predict_batch(self, paths):
-        return np.zeros(sum(len(p["rewards"]) for p in paths))
+        return np.concatenate([_zeros_like_rewards(p) for p in paths]) if len(paths) else np.zeros(0)
+
+    def fit(self, paths, return_errors=False):
+        return _UNFITTED_ERRORS if return_errors else None
