@@ -38,22 +38,27 @@ class BC:
             self.set_variance_with_data(out_scale)
         self._adam = None           # (m, v) device tensors + steps taken: the torch.optim.Adam state of the reference
 
-    # ------------------------------------------------------------------ behavior_cloning.py:51-75
+    # ------------------------------------------------------------------ data-driven transforms (behavior_cloning.py:51-75)
+    def _stacked(self, key):
+        return np.concatenate([p[key] for p in self.expert_paths])
+
     def compute_transformations(self):
-        if self.expert_paths == [] or self.expert_paths is None:
-            return None, None, None, None
-        observations = np.concatenate([path["observations"] for path in self.expert_paths])
-        actions = np.concatenate([path["actions"] for path in self.expert_paths])
-        return np.mean(observations, axis=0), np.std(observations, axis=0), np.mean(actions, axis=0), np.std(actions, axis=0)
+        """(in_shift, in_scale, out_shift, out_scale) = per-column mean / std of the expert observations and actions;
+        four Nones without demonstrations."""
+        if not self.expert_paths:
+            return (None,) * 4
+        o, a = self._stacked("observations"), self._stacked("actions")
+        return o.mean(axis=0), o.std(axis=0), a.mean(axis=0), a.std(axis=0)
 
     def set_transformations(self, in_shift=None, in_scale=None, out_shift=None, out_scale=None):
-        self.policy.model.set_transformations(in_shift, in_scale, out_shift, out_scale)
-        self.policy.old_model.set_transformations(in_shift, in_scale, out_shift, out_scale)
+        for net in (self.policy.model, self.policy.old_model):
+            net.set_transformations(in_shift, in_scale, out_shift, out_scale)
 
     def set_variance_with_data(self, out_scale):
-        params = self.policy.get_param_values()
-        params[-self.policy.m:] = np.log(out_scale + 1e-12)
-        self.policy.set_param_values(params)
+        """log_std <- log(std of the expert actions) (+1e-12 inside the log, as the reference)"""
+        theta = self.policy.get_param_values()
+        theta[-self.policy.m:] = np.log(out_scale + 1e-12)
+        self.policy.set_param_values(theta)
 
     # ------------------------------------------------------------------ losses (host values, for logging)
     def loss(self, data, idx=None):
@@ -104,9 +109,7 @@ class BC:
             self.logger.log_kv('time', (timer.time() - ts))
 
     def train(self, **kwargs):
-        observations = np.concatenate([path["observations"] for path in self.expert_paths])
-        expert_actions = np.concatenate([path["actions"] for path in self.expert_paths])
-        self.fit(dict(observations=observations, expert_actions=expert_actions), **kwargs)
+        self.fit(dict(observations=self._stacked("observations"), expert_actions=self._stacked("actions")), **kwargs)
 
     # ------------------------------------------------------------------ device plumbing
     _engine_obj = None

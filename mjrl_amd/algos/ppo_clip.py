@@ -52,6 +52,10 @@ class PPO(BatchREINFORCE):
 
     def train_from_paths(self, paths):
         """ppo_clip.py:59-110"""
+        from ..engine import _dist
+        if _dist() is not None:
+            raise NotImplementedError("PPO's minibatch epochs run on one rank (every rank would draw its own minibatches and the "
+                                      "parameter copies would drift apart); shard trajectories with NPG / TRPO / DAPG instead")
         base_stats = self._process_and_bind(paths)             # concatenation-free ingestion, whitened advantages, statistics
         if self.save_logs:
             self.log_rollout_statistics(paths)
