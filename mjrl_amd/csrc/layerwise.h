@@ -142,42 +142,51 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     };
     constexpr std::integral_constant<int, GBM> RA{};
     constexpr std::integral_constant<int, BN> RB{};
-    gload1(RA, ra, Ap, amode, ars, aks, m0, g.M, kbeg);
-    gload1(RB, rb, Bp, bmode, bcs, bks, n0, g.N, kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-      __syncthreads();                               // the previous tile is fully consumed
-      lstore1(RA, As, ra, amode);
-      lstore1(RB, Bs, rb, bmode);
-      __syncthreads();
-      if (k0 + GBK < kend) {                         // next tile's global loads fly under this tile's MFMAs
-        gload1(RA, ra, Ap, amode, ars, aks, m0, g.M, k0 + GBK);
-        gload1(RB, rb, Bp, bmode, bcs, bks, n0, g.N, k0 + GBK);
-      }
-      f32x4 a4[MT], b4[NT], an[MT], bn[NT];
-#pragma unroll
-      for (int a = 0; a < MT; ++a) a4[a] = frag(RA, As, amode, wm * TM + 32 * a, 0);
-#pragma unroll
-      for (int b = 0; b < NT; ++b) b4[b] = frag(RB, Bs, bmode, wn * TN + 32 * b, 0);
-#pragma unroll
-      for (int q = 0; q < GBK / 8; ++q) {
-        if (q + 1 < GBK / 8) {
-#pragma unroll
-          for (int a = 0; a < MT; ++a) an[a] = frag(RA, As, amode, wm * TM + 32 * a, q + 1);
-#pragma unroll
-          for (int b = 0; b < NT; ++b) bn[b] = frag(RB, Bs, bmode, wn * TN + 32 * b, q + 1);
+    // The K loop is instantiated per LDS image pair (chosen once per operand pair, outside the loop), so that the body
+    // is one straight-line block: fragment reads of group q + 1 and the MFMAs of group q schedule together.
+    auto kloop = [&](auto ta, auto tb) {
+      constexpr int LA = decltype(ta)::value, LB = decltype(tb)::value;     // 1: [k][row] image, 0: [row][k] image
+      gload1(RA, ra, Ap, amode, ars, aks, m0, g.M, kbeg);
+      gload1(RB, rb, Bp, bmode, bcs, bks, n0, g.N, kbeg);
+      for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+        __syncthreads();                               // the previous tile is fully consumed
+        lstore1(RA, As, ra, LA);
+        lstore1(RB, Bs, rb, LB);
+        __syncthreads();
+        if (k0 + GBK < kend) {                         // next tile's global loads fly under this tile's MFMAs
+          gload1(RA, ra, Ap, amode, ars, aks, m0, g.M, k0 + GBK);
+          gload1(RB, rb, Bp, bmode, bcs, bks, n0, g.N, k0 + GBK);
         }
+        f32x4 a4[MT], b4[NT], an[MT], bn[NT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int a = 0; a < MT; ++a) a4[a] = frag(RA, As, LA, wm * TM + 32 * a, 0);
 #pragma unroll
-          for (int a = 0; a < MT; ++a)
+        for (int b = 0; b < NT; ++b) b4[b] = frag(RB, Bs, LB, wn * TN + 32 * b, 0);
 #pragma unroll
-            for (int b = 0; b < NT; ++b) acc[a][b] = MJX_MFMA(a4[a][t], b4[b][t], acc[a][b]);
+        for (int q = 0; q < GBK / 8; ++q) {
+          if (q + 1 < GBK / 8) {
 #pragma unroll
-        for (int a = 0; a < MT; ++a) a4[a] = an[a];
+            for (int a = 0; a < MT; ++a) an[a] = frag(RA, As, LA, wm * TM + 32 * a, q + 1);
 #pragma unroll
-        for (int b = 0; b < NT; ++b) b4[b] = bn[b];
+            for (int b = 0; b < NT; ++b) bn[b] = frag(RB, Bs, LB, wn * TN + 32 * b, q + 1);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+              for (int b = 0; b < NT; ++b) acc[a][b] = MJX_MFMA(a4[a][t], b4[b][t], acc[a][b]);
+#pragma unroll
+          for (int a = 0; a < MT; ++a) a4[a] = an[a];
+#pragma unroll
+          for (int b = 0; b < NT; ++b) b4[b] = bn[b];
+        }
       }
-    }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (amode == 1) { if (bmode == 1) kloop(I1{}, I1{}); else kloop(I1{}, I0{}); }
+    else { if (bmode == 1) kloop(I0{}, I1{}); else kloop(I0{}, I0{}); }
   }
   // Epilogue, specialised once per launch (not per element): per-column constants are fetched once per 32-column
   // block, the activation operands of a 32x32 block as one batch of independent loads.
