@@ -803,3 +803,29 @@ def test_one_upload_per_batch_shared_by_update_and_baselines():
     np.testing.assert_array_equal(st2["observations"].cpu().numpy(), np.concatenate([p["observations"] for p in paths2]).astype(np.float32))
     assert np.all(np.isfinite(pred))
     eng.close()
+
+
+def test_device_step_length_matches_host_formula():
+    """mjx_apply_npg_step: alpha = sqrt(|delta / (g.x + 1e-20)|) formed on the device (fp64) and applied == the host
+    formula of npg_cg.py:133 followed by mjx_apply_step, bit for bit, incl. the log_std clamp."""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    n, m, hid = 17, 6, (64, 64)
+    rng = np.random.RandomState(3)
+    th = synth.perturbed_params(synth.init_params(n, m, hid))
+    th[-m:] = -2.9999                                            # a step may push log_std below the clamp
+    ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    eng = UpdateEngine(n, m, hid)
+    eng.set_policy(th, th, ident, ident)
+    eng.set_batch(rng.randn(5000, n).astype(np.float32), rng.randn(5000, m).astype(np.float32), rng.randn(5000).astype(np.float32))
+    g, _ = eng.surr_vpg()
+    x, gx = eng.cg_solve(g, 10, 1e-4)
+    eng.apply_npg_step(0.05, -3.0)
+    dev = eng.theta_new.cpu().numpy().copy()
+    late = eng.deferred()
+    alpha = np.sqrt(np.abs(0.05 / (gx + 1e-20)))
+    assert late["gdotx"] == gx and late["alpha"] == alpha
+    eng.apply_step(alpha, -3.0)
+    assert np.array_equal(dev, eng.theta_new.cpu().numpy())
+    assert dev[-m:].min() >= -3.0
+    eng.close()
