@@ -49,9 +49,20 @@ def synth_shard(rank, world, n_traj=N_TRAJ, T_=T):
 
 
 def initial_params():
-    from oracle import synth
-    th = synth.init_params(N_OBS, N_ACT, HIDDEN, seed=1, init_log_std=-0.5)
-    return synth.perturbed_params(th)
+    """random-init weights of the benchmark architecture (nn.Linear-style U(-1/sqrt(fan_in), 1/sqrt(fan_in)), last layer
+    x 1e-2, log_std -0.5) + the 0.1 N(0,1) perturbation of SURVEY 8d.  (No checkpoints, no network: "data": "synthetic".)"""
+    rng = np.random.RandomState(1)
+    sizes = (N_OBS,) + tuple(HIDDEN) + (N_ACT,)
+    flat = []
+    for i in range(len(sizes) - 1):
+        k = 1.0 / np.sqrt(sizes[i])
+        W, b = rng.uniform(-k, k, (sizes[i + 1], sizes[i])), rng.uniform(-k, k, sizes[i + 1])
+        if i == len(sizes) - 2:
+            W, b = 1e-2 * W, 1e-2 * b
+        flat += [W.ravel(), b]
+    flat.append(np.full(N_ACT, -0.5))
+    th = np.concatenate(flat).astype(np.float32)
+    return (th + 0.1 * np.random.RandomState(1).randn(th.size)).astype(np.float32)
 
 
 def cpu_baseline(theta0, sample_traj):

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from mjrl_amd.engine import UpdateEngine
-from oracle import synth
+import _synth as synth
 out = {}
 rng = np.random.RandomState(0)
 def timeit(fn, reps):

@@ -12,7 +12,7 @@ import torch
 
 from mjrl_amd.engine import UpdateEngine
 from mjrl_amd.utils import process_samples
-from oracle import synth
+import _synth as synth
 
 
 def timeit(fn, reps=3):

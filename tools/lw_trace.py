@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from mjrl_amd.engine import UpdateEngine
-from oracle import synth
+import _synth as synth
 rng = np.random.RandomState(0)
 n, m, hid, N = 376, 17, (256, 256), 200000
 th = synth.perturbed_params(synth.init_params(n, m, hid), scale=0.02)

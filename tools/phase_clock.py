@@ -7,7 +7,7 @@ import numpy as np, torch
 from mjrl_amd import _lib
 _lib.LIB_PATH = os.environ.get("MJX_LIB", _lib.LIB_PATH)
 from mjrl_amd.engine import UpdateEngine
-from oracle import synth
+import _synth as synth
 n, m, hid, N = 17, 6, (64, 64), 1000000
 rng = np.random.RandomState(0)
 th = synth.perturbed_params(synth.init_params(n, m, hid))

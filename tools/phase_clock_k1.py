@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from mjrl_amd.engine import UpdateEngine
-from oracle import synth
+import _synth as synth
 n, m, hid, N = 17, 6, (64, 64), 1000000
 rng = np.random.RandomState(0)
 th = synth.perturbed_params(synth.init_params(n, m, hid))
