@@ -50,6 +50,18 @@ def test_product_never_imports_oracle():
                 assert "import_module" not in src and "__import__" not in src, (dirpath, f)
 
 
+def test_oracle_is_only_used_by_the_checkers():
+    """outside tests/ only smoke() and bench.py's cpu_baseline leg may touch oracle/: the measurement tools do not, and
+    in bench.py every oracle import sits inside cpu_baseline()"""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            assert not pat.search(open(os.path.join(ROOT, "tools", f)).read()), f
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def cpu_baseline("):src.index("def main(")]
+    assert len(pat.findall(src)) == len(pat.findall(body)) >= 1
+
+
 def _spec(n, m):
     return type("Spec", (), dict(observation_dim=n, action_dim=m, horizon=100))
 
