@@ -161,6 +161,12 @@ class BatchREINFORCE:
         running_score = mean_return if self.running_score is None else 0.9 * self.running_score + 0.1 * mean_return
         return advantages, base_stats, running_score
 
+    def _staging_pool(self):
+        if getattr(self, "_stage_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._stage_pool = ThreadPoolExecutor(max_workers=1)
+        return self._stage_pool
+
     def _process_and_bind(self, paths):
         """process_paths + upload + binding for train_from_paths: the (whitened, fp64) advantages are assembled on the
         host like the reference does, observations / actions go path by path through the engine's page-locked
@@ -169,10 +175,7 @@ class BatchREINFORCE:
         # the gather / upload of observations and actions runs on a helper thread (native memcpy threads + asynchronous
         # copies, no GIL) while this thread assembles the advantage vector and the path statistics
         eng = self.engine
-        if getattr(self, "_stage_pool", None) is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._stage_pool = ThreadPoolExecutor(max_workers=1)
-        fut = self._stage_pool.submit(eng.stage_paths, paths, ("observations", "actions"))
+        fut = self._staging_pool().submit(eng.stage_paths, paths, ("observations", "actions"))
         try:
             advantages, base_stats, self.running_score = self._advantages_and_statistics(paths)
         finally:

@@ -206,6 +206,7 @@ class PathStager:
 # concatenated arrays every time.  The registry below keeps the last staged batch per device: whoever asks first
 # uploads, the others get the same device tensors.
 _SHARED = {}
+_SHARED_LOCK = threading.Lock()     # a prefetch thread and the main thread may ask for the same batch at the same time
 
 
 def _fingerprint(paths, key):
@@ -218,22 +219,24 @@ def stage_shared(backend, paths, keys):
     """-> dict key -> dict(f32=(N, w) fp32 device tensor, raw=(N, w) tensor in the paths' dtype).  Re-uses the upload
     of the same `paths` list (same objects, same end-point values) made earlier in this process on this device."""
     dev = backend.device
-    reg = _SHARED.setdefault((dev.type, dev.index), {})
     out = {}
-    for k in keys:
-        fp = _fingerprint(paths, k)
-        ent = reg.get(k)
-        if ent is None or ent["fp"] != fp:
-            st = ent["stager"] if ent is not None else PathStager(backend)
-            f32 = st.stage(paths, (k,))[k]
-            ent = reg[k] = dict(fp=fp, stager=st, f32=f32, raw=st.raw(k))
-        out[k] = dict(f32=ent["f32"], raw=ent["raw"])
+    with _SHARED_LOCK:
+        reg = _SHARED.setdefault((dev.type, dev.index), {})
+        for k in keys:
+            fp = _fingerprint(paths, k)
+            ent = reg.get(k)
+            if ent is None or ent["fp"] != fp:
+                st = ent["stager"] if ent is not None else PathStager(backend)
+                f32 = st.stage(paths, (k,))[k]
+                ent = reg[k] = dict(fp=fp, stager=st, f32=f32, raw=st.raw(k))
+            out[k] = dict(f32=ent["f32"], raw=ent["raw"])
     return out
 
 
 def drop_shared():
     """forget the staged batches (tests; releasing device memory)"""
-    for reg in _SHARED.values():
-        for ent in reg.values():
-            ent["stager"].close()
-    _SHARED.clear()
+    with _SHARED_LOCK:
+        for reg in _SHARED.values():
+            for ent in reg.values():
+                ent["stager"].close()
+        _SHARED.clear()
