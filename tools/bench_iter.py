@@ -17,7 +17,7 @@ for name in ("quadratic", "mlp"):
     bl = QuadraticBaseline(spec) if name == "quadratic" else MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3)
     agent = NPG(None, pol, bl, normalized_step_size=0.05)
     ts = []
-    for it in range(3):
+    for it in range(7):
         paths = [dict(observations=rng.randn(1000, 17), actions=rng.randn(1000, 6), rewards=rng.randn(1000), terminated=False) for _ in range(1000)]
         torch.cuda.synchronize(); t0 = time.perf_counter()
         process_samples.compute_returns(paths, 0.995); t1 = time.perf_counter()
@@ -27,4 +27,6 @@ for name in ("quadratic", "mlp"):
         ts.append([t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0])
     best = min(ts[1:], key=lambda r: r[-1])
     out[name] = dict(zip(["returns_ms", "advantages_ms", "update_ms", "baseline_fit_ms", "total_ms"], [round(1e3 * x, 2) for x in best]))
+    out[name]["update_ms_all"] = [round(1e3 * r[2], 1) for r in ts]
+    out[name]["total_ms_median"] = round(1e3 * sorted(r[-1] for r in ts[1:])[len(ts[1:]) // 2], 2)
 print(json.dumps(out))
