@@ -300,6 +300,11 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       kcs[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cst[9 * MP + 2 * a + 1])));
     }
   }
+  float kc3r[RA], kcsr[RA];                       // the same for the actions this lane half owns: a = unit_of(r, hi)
+  if (MODE == MODE_FVP) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) { kc3r[r] = cst[9 * MP + 2 * unit_of(r, hi)]; kcsr[r] = cst[9 * MP + 2 * unit_of(r, hi) + 1]; }
+  }
   constexpr int OC_TILE = (MP + 1) * 32;
   float ocn[MP + 1];                              // next tile's old-policy outputs (MODE_EVAL)
   auto load_oc = [&](int64_t t) {
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   constexpr int NT3 = H2 / 16;                    // gW3 lives in 16x16 tiles: [action 4(l>>4)+r][unit 16nt + (l&15)]
   f32x16 gW1[MT1][NT1], gW2[MT2][MT1];
   f32x4 gW3[NT3];
-  float sb2[MT2], sb3 = 0.f, gls[RA];     // grad b2[32*nt + j] (every lane), grad b3[lane], grad log_std[unit_of(r,hi)]
+  float sb2[MT2], sb3r[RA], gls[RA];      // grad b2[32*nt + j] (every lane); grad b3 / grad log_std of action unit_of(r, hi), this lane's samples
 #pragma unroll
   for (int a = 0; a < MT1; ++a)
 #pragma unroll
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
   for (int a = 0; a < NT3; ++a) gW3[a] = (f32x4)(0.f);
 #pragma unroll
-  for (int a = 0; a < RA; ++a) gls[a] = 0.f;
+  for (int a = 0; a < RA; ++a) { gls[a] = 0.f; sb3r[a] = 0.f; }
 #pragma unroll
   for (int a = 0; a < MT2; ++a) sb2[a] = 0.f;
   double s_surr = 0.0, s_kl = 0.0, s_cnt = 0.0;
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       }
       MJX_STAMP(7);
       float md[MP];
-      out_finish(og, md);
+      if (DBG) out_finish(og, md);
       if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0) {
         float* g = A.dbg;
 #pragma unroll
@@ -699,15 +704,22 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
             g[2048 * 3 + (32 * mt + unit_of(r, hi)) * 32 + j] = t2[mt][r];
           }
       }
-      float d3a[MP];
+      if (DBG) {
 #pragma unroll
-      for (int a = 0; a < MP; ++a) {
-        const f32x2 kc = f32x2{kc3[a], kcs[a]};                      // {c3[a], out_scale^2 * Dk / N} (wave-uniform, SGPRs)
-        d3a[a] = valid ? (md[a] + kc.x) * kc.y : 0.f;
-        if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0 && hi == 0) A.dbg[2048 * 4 + a * 32 + j] = cst[C_OSC * MP + a] * (md[a] + kc.x);
+        for (int a = 0; a < MP; ++a)
+          if (A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0 && hi == 0) A.dbg[2048 * 4 + a * 32 + j] = cst[C_OSC * MP + a] * (md[a] + kc3[a]);
       }
+      // Each lane half needs the full sums of ITS actions only (a = unit_of(r, hi): group 2(r>>2) + hi, column r&3):
+      // v_permlane32_swap of the two groups' partial sums hands the lower half both halves' values of group 2(r>>2)
+      // and the upper half both of group 2(r>>2)+1 -- one swap and one add per owned action, no selects.
+      const float vmask = valid ? 1.0f : 0.0f;
 #pragma unroll
-      for (int r = 0; r < RA; ++r) d3r[r] = hi ? d3a[unit_of(r, 1)] : d3a[unit_of(r, 0)];
+      for (int r = 0; r < RA; ++r) {
+        const int g0 = 2 * (r >> 2), c = r & 3;
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(og[g0][c]), __float_as_uint(og[g0 + 1][c]), false, false);
+        const float mdr = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        d3r[r] = (mdr + kc3r[r]) * (kcsr[r] * vmask);               // d3 = (md + c3) * out_scale^2 Dk / N, 0 past the batch end
+      }
     } else {
       // ---- likelihoods (mean_LL, gaussian_mlp.py:99-115); each lane owns the actions a = unit_of(r, hi)
       float sum_lsA = 0.f, sum_lsB = 0.f;
@@ -874,13 +886,8 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) dl2u[nt][4 * q + t] *= fmaf(-fc[nt][q][t], fc[nt][q][t], 1.0f);
       }
-      if (lane < MP) {                              // grad b3[a] = sum_s d3[s][a]
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          f32x4 v = *(const f32x4*)&d3T[lane * ST + 4 * q];
-          sb3 += (v.x + v.y) + (v.z + v.w);
-        }
-      }
+      for (int r = 0; r < RA; ++r) sb3r[r] += d3r[r];   // grad b3[a] = sum_s d3[s][a]: per-lane partial sums, reduced over the lanes after the tile loop
       // grad b2[32nt + j] = sum over this tile's samples (16 registers x 2 lane halves)
 #pragma unroll
       for (int nt = 0; nt < MT2; ++nt) {
@@ -1002,12 +1009,13 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   MJX_GSTAMP(19);
   if (MODE != MODE_EVAL) {
     // log_std gradient: reduce over the 32 samples (lanes j) within each half (the halves own different actions)
-    if (MODE == MODE_VPG) {
 #pragma unroll
-      for (int off = 1; off < 32; off <<= 1)
+    for (int off = 1; off < 32; off <<= 1)
 #pragma unroll
-        for (int a = 0; a < RA; ++a) gls[a] += __shfl_xor(gls[a], off);
-    }
+      for (int a = 0; a < RA; ++a) {
+        if (MODE == MODE_VPG) gls[a] += __shfl_xor(gls[a], off);
+        sb3r[a] += __shfl_xor(sb3r[a], off);
+      }
     // each wave drops its partial gradient into its own LDS region [wave][d], then the
     // workgroup sums the four copies.  (weights in LDS are dead by now)
     float* red = lds;                             // 4 * d floats <= TOTAL (checked on host)
@@ -1044,11 +1052,11 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
       for (int nt = 0; nt < MT2; ++nt) mine[fo.b2 + 32 * nt + j] = sb2f[nt];
     }
-    if (lane < m) mine[fo.b3 + lane] = sb3;
     if (j == 0) {
 #pragma unroll
       for (int r = 0; r < RA; ++r) {
         const int a = unit_of(r, hi);
+        if (a < m) mine[fo.b3 + a] = sb3r[r];
         if (a < m) mine[fo.S + a] = (MODE == MODE_VPG) ? gls[r] : 0.f;
       }
     }
