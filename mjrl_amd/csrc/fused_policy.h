@@ -91,6 +91,11 @@ __device__ __forceinline__ float fast_div(float a, float b) {
   return a * r;
 }
 
+// mask ? a : b on bit patterns (mask = all ones / all zeros per lane)
+__device__ __forceinline__ float half_select(uint32_t mask, float a, float b) {
+  return __uint_as_float((__float_as_uint(a) & mask) | (__float_as_uint(b) & ~mask));
+}
+
 // x[lane] + x[lane ^ 32] in every lane: v_permlane32_swap exchanges the upper half of one copy with the
 // lower half of the other (one VALU op, no LDS round trip like ds_bpermute)
 __device__ __forceinline__ float half_sum(float p) {
@@ -159,6 +164,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   constexpr int RA = MP / 2;                      // accumulator rows per lane that map to actions: a = unit_of(r, hi), r < RA
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+  const uint32_t himask = hi ? 0xffffffffu : 0u;
   const int n = A.n, m = A.m;
   const LT L(n);
   const int NP = NPC ? NPC : L.NP;                // compile-time when the variant is specialised for the obs dim
@@ -798,8 +804,10 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
         }
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-          d3r[r] = hi ? d3a[unit_of(r, 1)] : d3a[unit_of(r, 0)];
-          float zr = hi ? z[unit_of(r, 1)] : z[unit_of(r, 0)];
+          // (bit-select on the lane-half mask: one v_bfi each; a ?: on array elements becomes a dynamically indexed
+          //  register array, i.e. a chain of 8 compares and selects per value)
+          d3r[r] = half_select(himask, d3a[unit_of(r, 1)], d3a[unit_of(r, 0)]);
+          const float zr = half_select(himask, z[unit_of(r, 1)], z[unit_of(r, 0)]);
           gls[r] += w * (zr * zr - 1.0f);
         }
         if (DBG && A.dbg && blockIdx.x == 0 && wave == 0 && tile == 0 && hi == 0) {
