@@ -72,7 +72,8 @@ int mjx_stream_sync(void* stream);
  * N_global = total samples over all ranks (means are taken over N_global).
  * obs must be 16-byte aligned (it is read with 16-byte loads, and up to 12 bytes past its
  * end may be read -- always inside the allocation for hipMalloc / torch memory).
- * act / adv may be NULL when only mjx_fvp is used. */
+ * act / adv may be NULL when only mjx_fvp is used.
+ * Every call drops what earlier calls cached for the previous batch (see mjx_surr_vpg). */
 int mjx_bind_batch(mjx_ctx* ctx, const float* obs, const float* act, const float* adv,
                    int64_t N_local, int64_t N_global);
 
@@ -94,7 +95,12 @@ int mjx_bind_policy(mjx_ctx* ctx, const float* theta_new, const float* theta_old
 /* grad_out[d] = sum over local samples of d/dtheta_new [LR_i * adv_i] / N_global
  * (BatchREINFORCE.flat_vpg, batch_reinforce.py:54-58);
  * scal_out[0] = sum_i LR_i*adv_i (local, NOT divided; CPI_surrogate :40-46),
- * scal_out[1] = number of local samples.  scal_out is 4 doubles. */
+ * scal_out[1] = number of local samples.  scal_out is 4 doubles.
+ * With old_is_new the call also keeps, per sample of the bound batch, the hidden activations, the normalised
+ * observations and the policy's mean / log-likelihood (about 630 B per sample of device memory, owned by the context):
+ * the mjx_fvp calls of the same update then skip the forward pass, mjx_eval_surr_kl skips the old policy's (the latter
+ * after checking in the kernel that theta_old / tr_old still hold the values they had here).  mjx_bind_policy drops
+ * the activations, mjx_bind_batch drops everything, mjx_bind_rows keeps both. */
 int mjx_surr_vpg(mjx_ctx* ctx, float* grad_out, double* scal_out, void* stream);
 
 /* ---- K2: Fisher-vector product ------------------------------------------- */
