@@ -498,6 +498,16 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
           if (FWD) h1[mt][r] = fast_tanh(z1[mt][r]);
           if (TAN) t1[mt][r] *= fmaf(-h1[mt][r], h1[mt][r], 1.0f);
         }
+      if (MODE == MODE_VPG && writeT && A.hcache) {
+        // keep h1 for the Fisher-vector products of this update (theta is fixed during CG); issued here so that the
+        // stores drain under the layer-2 MFMAs
+        float* base = A.hcache + tile * HC_TILE + lane * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *(f32x4*)(base + (mt * 4 + q) * 256) = f32x4{h1[mt][4 * q], h1[mt][4 * q + 1], h1[mt][4 * q + 2], h1[mt][4 * q + 3]};
+      }
       MJX_STAMP(3);
       // layer 2: accumulators start at the bias (b2 / c2), K = h1 units chained from registers
       f32x16 z2[MT2];
@@ -662,13 +672,8 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     if (MODE == MODE_FVP) layers12(std::true_type{}, slotA, trs, trs + NP, true, h1, h2, t1, t2);
     else layers12(std::false_type{}, slotA, trs, trs + NP, MODE != MODE_EVAL, h1, h2, t1, t2);
     if (MODE == MODE_VPG && A.hcache) {
-      // keep h1 / h2 for the Fisher-vector products of this update (theta is fixed during CG)
+      // ... and h2 (h1 was stored right after its tanh)
       float* base = A.hcache + tile * HC_TILE + lane * 4;
-#pragma unroll
-      for (int mt = 0; mt < MT1; ++mt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *(f32x4*)(base + (mt * 4 + q) * 256) = f32x4{h1[mt][4 * q], h1[mt][4 * q + 1], h1[mt][4 * q + 2], h1[mt][4 * q + 3]};
 #pragma unroll
       for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
