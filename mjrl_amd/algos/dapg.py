@@ -39,28 +39,30 @@ class DAPG(NPG):
 
     def train_from_paths(self, paths):
         """dapg.py:54-141"""
-        observations, actions, advantages, base_stats, self.running_score = self.process_paths(paths)
+        # advantages (whitened over all ranks) and path statistics on the host; observations / actions of the on-policy
+        # paths and of the demonstrations go path by path through the page-locked stager (no concatenated host copies)
+        advantages, base_stats, self.running_score = self._advantages_and_statistics(paths)
         if self.save_logs:
             self.log_rollout_statistics(paths)
-        N = observations.shape[0]
+        N = advantages.shape[0]
         use_demos = self.demo_paths is not None and self.lam_0 > 0.0
+        batch = list(paths)
         if use_demos:                                          # dapg.py:62-70
             from ..engine import _dist
             d = _dist()
             demos = self.demo_paths if d is None else self.demo_paths[d.get_rank()::d.get_world_size()]   # shard demos too
-            demo_obs = np.concatenate([p["observations"] for p in demos]) if demos else np.zeros((0, observations.shape[1]))
-            demo_act = np.concatenate([p["actions"] for p in demos]) if demos else np.zeros((0, actions.shape[1]))
-            demo_adv = self.lam_0 * (self.lam_1 ** self.iter_count) * np.ones(demo_obs.shape[0])
+            n_demo = int(sum(len(p["observations"]) for p in demos))
+            demo_adv = self.lam_0 * (self.lam_1 ** self.iter_count) * np.ones(n_demo)
             self.iter_count += 1
-            all_obs = np.concatenate([observations, demo_obs])
-            all_act = np.concatenate([actions, demo_act])
+            batch = batch + list(demos)
             all_adv = 1e-2 * np.concatenate([advantages / (self._global_mean_std(advantages)[1] + 1e-8), demo_adv])
         else:
-            all_obs, all_act, all_adv = observations, actions, advantages
+            all_adv = advantages
 
         eng = self.engine
+        staged = eng.stage_paths(batch, ("observations", "actions"))
         self._push_policy()
-        eng.set_batch(all_obs, all_act, all_adv)               # [on-policy ; demos] uploaded once
+        eng.set_batch(staged["observations"], staged["actions"], all_adv)   # [on-policy ; demos] uploaded once
         N_all_global = eng.N_global
         N_on_global = eng.global_count(N)
 
