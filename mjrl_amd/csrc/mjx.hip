@@ -15,6 +15,7 @@
 
 #include "baseline.h"
 #include "fused_policy.h"
+#include "policy_fit.h"
 #include "layerwise.h"
 #include "mlp_fit.h"
 #include "vecops.h"
@@ -704,6 +705,26 @@ int mjx_policy_minibatch_adam(mjx_ctx* c, int loss, const float* obs, const floa
   if (loss == 2 && (!adv || !theta_old)) return fail(MJX_ERR_ARG, "PPO needs advantages and the old parameters");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->device));
+  const float* trn0 = tr ? tr : c->ident_tr;
+  const float* tro0 = tr_old ? tr_old : c->ident_tr;
+  // small two-layer nets, minibatches of up to 64 rows: the whole chain of steps in ONE launch (policy_fit.h)
+  const char* no_fit_env = getenv("MJX_NO_POLICY_FIT");      // read per call: the tests run both paths in one process
+  const bool no_fit = no_fit_env && no_fit_env[0] == '1';
+  if (!no_fit && c->hidden.size() == 2 && c->hidden[0] == c->hidden[1] && (c->hidden[0] == 64 || c->hidden[0] == 32) &&
+      B % 4 == 0 && B >= 8 && B <= 64 && c->n <= c->hidden[0] && c->n <= 63 && c->m <= 16) {
+    const bool old_net = (loss == 2) && !old_tracks_new;
+    const int H = c->hidden[0];
+    const size_t bytes = 4 * (H == 64 ? PolicyFitLayout<64>(c->n, c->m).lds_floats(B, old_net) : PolicyFitLayout<32>(c->n, c->m).lds_floats(B, old_net));
+    if (bytes <= 160 * 1024) {
+      PolicyFitArgs a{obs, act, adv, idx, steps, B, c->n, c->m, theta, theta_old, trn0, tro0, loss, old_tracks_new, adam_m, adam_v,
+                      step0, lr, clip, loss_trace, (int)(bytes / 4)};
+      void (*k)(PolicyFitArgs) = (H == 64) ? k_policy_fit<64> : k_policy_fit<32>;
+      HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      hipLaunchKernelGGL(k, dim3(1), dim3(256), bytes, st, a);
+      HIPCHK(hipGetLastError());
+      return MJX_OK;
+    }
+  }
   LayerwiseWS& w = c->lwmb;
   if (w.cap < B) { if (int rc = w.reserve(B)) return fail(rc, "minibatch workspace allocation failed"); }
   if (c->mb_cap < B) {

@@ -733,6 +733,47 @@ def test_ppo_fixed_old_policy_vs_torch_autograd():
     assert moved > 0.05 and err < 1e-3 * moved, (err, moved)
 
 
+@pytest.mark.parametrize("n,m,H,B", [(17, 6, 64, 64), (5, 2, 32, 8), (63, 16, 64, 32), (11, 3, 32, 64)])
+def test_persistent_policy_trainer_equals_launch_path(n, m, H, B, monkeypatch):
+    """mjx_policy_minibatch_adam has two implementations: one persistent workgroup for small nets / minibatches
+    (csrc/policy_fit.h) and ~19 launches per step for everything else.  Same inputs -> same parameters, Adam moments and
+    per-step losses (to fp32 summation-order noise), for MSE, MLE and both flavours of the clipped surrogate, with
+    non-trivial input / output transforms and ragged feature counts."""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    from mjrl_amd._lib import check, ptr
+    rng = np.random.RandomState(n * 100 + B)
+    hid, N, steps = (H, H), 5000, 24
+    eng = UpdateEngine(n, m, hid)
+    th0 = synth.perturbed_params(synth.init_params(n, m, hid))
+    tho0 = (th0 + 0.02 * rng.randn(th0.size)).astype(np.float32)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    obs, act, adv = dev(rng.randn(N, n).astype(np.float32)), dev(rng.randn(N, m).astype(np.float32)), dev(rng.randn(N).astype(np.float32))
+    idx = dev(rng.randint(0, N, size=(steps, B)).astype(np.int32))
+    mk_tr = lambda: dev(np.concatenate([0.1 * rng.randn(n), 1 + 0.2 * rng.rand(n), 0.1 * rng.randn(m), 1 + 0.2 * rng.rand(m)]).astype(np.float32))
+    tr, tro = mk_tr(), mk_tr()
+    for loss, track in ((0, 1), (1, 1), (2, 1), (2, 0)):
+        out = []
+        for no_fit in ("0", "1"):
+            monkeypatch.setenv("MJX_NO_POLICY_FIT", no_fit)
+            th, tho = dev(th0.copy()), dev(tho0.copy())
+            am, av = torch.zeros_like(th), torch.zeros_like(th)
+            lt = torch.zeros(steps, dtype=torch.float64).cuda()
+            for part in range(2):                                  # two calls: the Adam state carries over (step0)
+                check(eng.lib.mjx_policy_minibatch_adam(eng.ctx, loss, ptr(obs), ptr(act), ptr(adv), ptr(idx[part * 12:]), 12, B, ptr(th),
+                                                        ptr(tr), ptr(tho), ptr(tro), track, ptr(am), ptr(av), part * 12, 3e-4, 0.2,
+                                                        ptr(lt[part * 12:]), eng.stream()))
+            torch.cuda.synchronize()
+            out.append([t.cpu().numpy().astype(np.float64) for t in (th, am, av, lt)])
+        (th_a, am_a, av_a, lt_a), (th_b, am_b, av_b, lt_b) = out
+        moved = np.linalg.norm(th_b - th0)
+        assert moved > 1e-3
+        assert np.linalg.norm(th_a - th_b) < 2e-3 * moved, (loss, track, np.linalg.norm(th_a - th_b), moved)
+        np.testing.assert_allclose(lt_a, lt_b, rtol=2e-4, atol=1e-6)
+        assert np.linalg.norm(am_a - am_b) < 1e-3 * np.linalg.norm(am_b)
+        assert np.linalg.norm(av_a - av_b) < 1e-3 * np.linalg.norm(av_b)
+
+
 def test_update_is_bit_reproducible_and_handles_odd_sizes():
     """Fixed-order reductions everywhere: the same update twice gives identical bits (no atomics, no dependence on
     dispatch order); batch sizes that are not tile multiples (1, 31, 33, 4097 samples) agree with the oracle."""
