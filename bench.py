@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fvp-event-stride", type=int, default=11,
+                    help="bracket every k-th Fisher-vector-product launch with HIP events (k coprime to the CG iteration count: every CG position is sampled equally); 0: none")
     ap.add_argument("--cpu-sample-traj", type=int, default=200)
     ap.add_argument("--rehearse-world", type=int, default=0,
                     help="diagnostic, 1 GPU: run rank 0's share of an R-rank job (1/R of the batch, global N, "
@@ -179,7 +181,7 @@ def main():
     for _ in range(args.warmup):
         one_update()
     fence()
-    check(eng.lib.mjx_profile_enable(eng.ctx, 1))
+    check(eng.lib.mjx_profile_enable(eng.ctx, args.fvp_event_stride))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_update()
@@ -194,7 +196,7 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
-        fvp_ms = prof[0] / max(prof[1], 1.0)
+        fvp_ms = prof[0] / prof[1] if prof[1] > 0 else float("nan")      # (--fvp-event-stride 0: no roofline figures)
         P = N_OBS * 64 + 64 * 64 + 64 * N_ACT
         # The CG loop runs the cached-forward FVP instance: K1 stores h1 / h2 and the normalised observation image once
         # per update (theta is fixed during CG), each product then costs the tangent + backward passes:
@@ -232,6 +234,7 @@ def main():
                          "achieved": achieved_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP32_MFMA_PEAK_TF, "traffic": traffic,
                          "avg_launch_ms": fvp_ms, "launches": int(prof[1]),
+                         "launches_timed": "every %d-th of %d (HIP events on the launch stream, inside the timed region)" % (max(args.fvp_event_stride, 1), args.steps * CG_ITERS),
                          "flop_per_launch": flop_per_sample * n_loc,
                          "algorithmic_bytes_per_launch": bytes_per_sample * n_loc,
                          "hbm_GBps_algorithmic": bytes_per_sample * n_loc / (fvp_ms * 1e-3) / 1e9,

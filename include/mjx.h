@@ -229,10 +229,13 @@ int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, con
                      float lr, float wd, double* epoch_loss_out, void* stream);
 
 /* ---- in-library kernel timing (bench.py roofline) ------------------------- */
-/* While enabled, every launch of the dominant Fisher-vector-product kernel (fused k_fused
- * MODE_FVP, or the whole layer-wise FVP chain) is bracketed by hipEvents recorded on the
- * launch stream.  mjx_profile_read synchronises and returns out[0] = total milliseconds,
- * out[1] = number of launches measured since the last mjx_profile_enable(ctx, 1). */
+/* While enabled (on = k >= 1), every k-th launch of the dominant Fisher-vector-product kernel
+ * (fused k_fused MODE_FVP, or the whole layer-wise FVP chain) is bracketed by hipEvents recorded
+ * on the launch stream.  An event pair costs ~10 us of dispatch serialisation (its markers carry
+ * release fences), so a timed run samples with a stride that is coprime to the CG iteration count
+ * instead of bracketing every launch.  mjx_profile_read synchronises and returns out[0] = total
+ * milliseconds, out[1] = number of launches measured since the last mjx_profile_enable(ctx, k);
+ * on = 0 switches the events off. */
 int mjx_profile_enable(mjx_ctx* ctx, int on);
 int mjx_profile_read(mjx_ctx* ctx, double* out_host);
 

@@ -50,6 +50,7 @@ struct FusedArgs {
   float* ocache;         // old-policy outputs [tile][MP + 1][32]: mean per action + log-likelihood; written by MODE_VPG
                          // (old == new), read by MODE_EVAL when thetaB / trB still equal `snap`
   const float* snap;     // [d + 2n + 2m] parameters and transforms the ocache was computed with
+  float* snap_out;       // MODE_VPG: the kernel writes that snapshot (thetaB | trB) while it fills the ocache
   int n, m;
 };
 
@@ -226,6 +227,11 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   if (MODE == MODE_EVAL && A.ocache) {
     for (int idx = tid; idx < fo.d; idx += 256) mism |= (A.thetaB[idx] != A.snap[idx]);
     for (int idx = tid; idx < 2 * (n + m); idx += 256) mism |= (A.trB[idx] != A.snap[fo.d + idx]);
+  }
+  if (MODE == MODE_VPG && A.snap_out) {           // every block copies a slice: at most a few elements per thread
+    const int nsnap = fo.d + 2 * (n + m);
+    for (int idx = blockIdx.x * 256 + tid; idx < nsnap; idx += gridDim.x * 256)
+      A.snap_out[idx] = idx < fo.d ? A.thetaB[idx] : A.trB[idx - fo.d];
   }
   // zero what is read before (or without) being written: the weight slots' pads, the constants, and each wave's
   // xs slack / xT / d3T.  bufA / bufB are fully rewritten every tile before they are read.

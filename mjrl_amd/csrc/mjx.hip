@@ -76,6 +76,8 @@ struct mjx_ctx {
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;   // pairs
   size_t prof_used = 0;
+  int prof_stride = 1;               // bracket every prof_stride-th launch
+  size_t prof_seen = 0;
   mjx::LayerwiseWS lw;             // layer-wise path workspace
   mjx::LayerwiseWS lwmb;           // minibatch trainer workspace (mjx_policy_minibatch_adam)
   float *mb_x = nullptr, *mb_a = nullptr, *mb_adv = nullptr, *mb_grad = nullptr; int mb_cap = 0;
@@ -159,7 +161,7 @@ FusedArgs make_args(mjx_ctx* c, const float* thetaB) {
   a.old_is_new = c->old_is_new;
   a.partials = c->partials; a.spartials = c->spartials;
   a.dbg = c->dbg;
-  a.hcache = nullptr; a.ocache = nullptr; a.snap = nullptr;
+  a.hcache = nullptr; a.ocache = nullptr; a.snap = nullptr; a.snap_out = nullptr;
   a.n = c->n; a.m = c->m;
   return a;
 }
@@ -462,7 +464,7 @@ int mjx_profile_enable(mjx_ctx* c, int on) {
     for (auto& e : c->prof_ev) HIPCHK(hipEventCreate(&e));
   }
   c->prof_on = on != 0;
-  if (on) c->prof_used = 0;
+  if (on) { c->prof_used = 0; c->prof_seen = 0; c->prof_stride = on; }
   return MJX_OK;
 }
 
@@ -524,8 +526,7 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
     if (!c->snap && hipMalloc(&c->snap, (size_t)(c->d + 2 * (c->n + c->m)) * sizeof(float)) != hipSuccess) { c->snap = nullptr; (void)hipGetLastError(); }
     c->ocache_valid = false;
     if (c->ocache && c->snap) {
-      HIPCHK(hipMemcpyAsync(c->snap, c->theta_old, c->d * sizeof(float), hipMemcpyDeviceToDevice, st));
-      HIPCHK(hipMemcpyAsync(c->snap + c->d, a.trB, 2 * (c->n + c->m) * sizeof(float), hipMemcpyDeviceToDevice, st));
+      a.snap_out = c->snap;                      // written by the kernel itself (no separate copies on the stream)
       a.ocache = c->ocache; c->ocache_valid = true; c->ocache_rows = c->N_local;
     }
   }
@@ -552,7 +553,7 @@ int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
     return rc ? fail(MJX_ERR_STATE, "general Hessian-vector product failed (%d)", rc) : MJX_OK;
   }
   const float frac = (float)((double)c->N_local / (double)c->N_global);
-  const bool prof = c->prof_on && c->prof_used + 2 <= c->prof_ev.size();
+  const bool prof = c->prof_on && (c->prof_seen++ % (size_t)c->prof_stride == 0) && c->prof_used + 2 <= c->prof_ev.size();
   if (prof) HIPCHK(hipEventRecord(c->prof_ev[c->prof_used], st));
   if (!c->fused) {
     int rc = c->lw.fvp(c->obs, c->N_local, c->N_global, c->theta_new, c->tr_new ? c->tr_new : c->ident_tr, v, out, st);

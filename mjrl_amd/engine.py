@@ -134,10 +134,12 @@ class UpdateEngine:
         self.grad = torch.zeros(self.d, **f32)
         self.x = torch.zeros(self.d, **f32)
         self.Ap = torch.zeros(self.d, **f32)
-        self.scal = torch.zeros(4, dtype=torch.float64, device=self.device)
-        self.bdotx = torch.zeros(1, dtype=torch.float64, device=self.device)
-        self.scal_vpg = torch.zeros(4, dtype=torch.float64, device=self.device)     # K1's sums (kept apart from K3's)
-        self.alpha_dev = torch.zeros(1, dtype=torch.float64, device=self.device)
+        # every scalar an update produces sits in one device block, so that one read-back fetches them all:
+        # K3's sums | K1's sums (kept apart from K3's) | b.x of the last solve | step length formed on the device
+        self.results = torch.zeros(16, dtype=torch.float64, device=self.device)
+        self.scal, self.scal_vpg = self.results[0:4], self.results[4:8]
+        self.bdotx, self.alpha_dev = self.results[8:9], self.results[9:10]
+        self._host_results = None                   # host copy of `results`, valid until the next launch that writes it
         self.obs = self.act = self.adv = None
         self.N_local = self.N_global = 0
         self.old_is_new = True
@@ -226,6 +228,7 @@ class UpdateEngine:
     def surr_vpg(self, sync=True):
         """K1 -> (grad device tensor, surrogate float).  flat_vpg + CPI_surrogate
         (batch_reinforce.py:40-58).  sync=False: nothing is read back (see deferred())."""
+        self._host_results = None
         self.backend.surr_vpg(self.grad, self.scal_vpg)
         d = _dist()
         if d is not None:
@@ -251,6 +254,7 @@ class UpdateEngine:
         and dot products are recomputed identically on every rank."""
         d = _dist()
         be = self.backend
+        self._host_results = None
         if d is None:
             be.cg_solve_local(b, iters, damping, tol, self.x, self.bdotx)
         else:
@@ -273,14 +277,17 @@ class UpdateEngine:
         """theta_new <- base + sqrt(|step_size / (g.x + 1e-20)|) x with the step length formed on the device from the last
         solve (npg_cg.py:133-139): no read-back between the solve and the step."""
         base = self.theta_old if base is None else base
+        self._host_results = None
         self.backend.apply_npg_step(base, self.x, self.bdotx, step_size, min_log_std, self.theta_new, self.alpha_dev)
         self.old_is_new = False
         self._bind_policy()
 
     def deferred(self):
         """-> dict(surr_before, gdotx, alpha) of the calls made with sync=False / apply_npg_step (one read-back after the update)"""
-        s = self.scal_vpg.cpu().numpy()
-        return dict(surr_before=float(s[0] / self.N_global), gdotx=float(self.bdotx.item()), alpha=float(self.alpha_dev.item()))
+        r = self._host_results                       # eval_surr_kl() already fetched the block: no further round trip
+        if r is None:
+            r = self._host_results = self.results.cpu().numpy()
+        return dict(surr_before=float(r[4] / self.N_global), gdotx=float(r[8]), alpha=float(r[9]))
 
     def eval_surr_kl(self):
         """K3 -> (surrogate, mean KL) (batch_reinforce.py:40-52)."""
@@ -288,7 +295,7 @@ class UpdateEngine:
         d = _dist()
         if d is not None:
             d.all_reduce(self.scal)
-        s = self.scal.cpu().numpy()
+        s = self._host_results = self.results.cpu().numpy()      # the whole block: deferred() needs no second read-back
         return float(s[0] / self.N_global), float(s[1] / self.N_global)
 
     def enable_debug(self):
