@@ -721,7 +721,7 @@ int mjx_policy_minibatch_adam(mjx_ctx* c, int loss, const float* obs, const floa
                       step0, lr, clip, loss_trace, (int)(bytes / 4)};
       void (*k)(PolicyFitArgs) = (H == 64) ? k_policy_fit<64> : k_policy_fit<32>;
       HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-      hipLaunchKernelGGL(k, dim3(1), dim3(256), bytes, st, a);
+      hipLaunchKernelGGL(k, dim3(1), dim3(PFIT_THREADS), bytes, st, a);
       HIPCHK(hipGetLastError());
       return MJX_OK;
     }

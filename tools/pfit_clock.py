@@ -25,3 +25,7 @@ for track in (1, 0):
     for k, nm in enumerate(names):
         print("  %-38s %8d cycles" % (nm, st[k + 1] - st[k]))
     print("  step total %d cycles" % (st[8] - st[0]))
+    fw = lt.cpu().numpy()[110:116]
+    if fw[0] > 0:
+        print("  forward detail (thread 0): layer1 %d + barrier %d | layer2 %d + barrier %d | layer3 %d + barrier %d" %
+              (fw[0] - st[1], fw[1] - fw[0], fw[2] - fw[1], fw[3] - fw[2], fw[4] - fw[3], fw[5] - fw[4]))
