@@ -733,7 +733,8 @@ def test_ppo_fixed_old_policy_vs_torch_autograd():
     assert moved > 0.05 and err < 1e-3 * moved, (err, moved)
 
 
-@pytest.mark.parametrize("n,m,H,B", [(17, 6, 64, 64), (5, 2, 32, 8), (63, 16, 64, 32), (11, 3, 32, 64)])
+@pytest.mark.parametrize("n,m,H,B", [(17, 6, 64, 64), (5, 2, 32, 8), (63, 16, 64, 32), (11, 3, 32, 64), (17, 6, 64, 48), (39, 16, 64, 12),
+                                     (33, 7, 64, 20)])
 def test_persistent_policy_trainer_equals_launch_path(n, m, H, B, monkeypatch):
     """mjx_policy_minibatch_adam has two implementations: one persistent workgroup for small nets / minibatches
     (csrc/policy_fit.h) and ~19 launches per step for everything else.  Same inputs -> same parameters, Adam moments and
@@ -769,7 +770,7 @@ def test_persistent_policy_trainer_equals_launch_path(n, m, H, B, monkeypatch):
         moved = np.linalg.norm(th_b - th0)
         assert moved > 1e-3
         assert np.linalg.norm(th_a - th_b) < 2e-3 * moved, (loss, track, np.linalg.norm(th_a - th_b), moved)
-        np.testing.assert_allclose(lt_a, lt_b, rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(lt_a, lt_b, rtol=2e-4, atol=1e-5)      # (a PPO minibatch loss is a sum of cancelling O(1) terms)
         assert np.linalg.norm(am_a - am_b) < 1e-3 * np.linalg.norm(am_b)
         assert np.linalg.norm(av_a - av_b) < 1e-3 * np.linalg.norm(av_b)
 
