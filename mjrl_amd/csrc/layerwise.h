@@ -49,7 +49,8 @@ constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = GBK + 4, GLT = GBM + 4;
 //   * a row-contiguous operand (W as "NN", the sample-major operands of the weight gradient) is kept as [k][row]
 //     (stride 132) and read with ds_read_b32;
 //   k-slot `hi` of step (q, t) carries k = 8q + 4hi + t for A and B alike (the permutation trick of the fused kernels).
-// The next tile's global loads are issued before the MFMAs of the current one (register-staged prefetch).  blockIdx.z splits the K range of pair 0 (wgrad: K = samples).
+// Operand tiles are double-buffered in LDS (one barrier per k-tile); tile k + 1 is stored and tile k + 2 requested from
+// global memory (register-staged) before the MFMAs of tile k.  blockIdx.z splits the K range of pair 0 (wgrad: K = samples).
 // BN = 128: 2x2 waves of 64x64; BN = 32 (narrow outputs: action heads, value heads): 4x1 waves of 32x32, so a
 // 17-column product is padded to 32 instead of 128 columns.
 template <int BN>
@@ -58,8 +59,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   constexpr int WMc = 4 / WN;                     // waves along M
   constexpr int TM = GBM / WMc, TN = BN / WN;     // per-wave tile
   constexpr int MT = TM / 32, NT = TN / 32;
-  __shared__ __attribute__((aligned(16))) float As[GBM * GLD];
-  __shared__ __attribute__((aligned(16))) float Bs[(BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4)];
+  // two buffers per operand (dynamic LDS: 72 KB at BN = 128, two workgroups per CU): tile k + 1 is stored while tile k is
+  // being multiplied, ONE barrier per k-tile
+  constexpr int ASZ = GBM * GLD, BSZ = (BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4);
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  float* As = gsm;                       // [2][ASZ]
+  float* Bs = gsm + 2 * ASZ;             // [2][BSZ]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * BN;
@@ -146,29 +151,42 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     // is one straight-line block: fragment reads of group q + 1 and the MFMAs of group q schedule together.
     auto kloop = [&](auto ta, auto tb) {
       constexpr int LA = decltype(ta)::value, LB = decltype(tb)::value;     // 1: [k][row] image, 0: [row][k] image
+      const int ntile = (kend - kbeg + GBK - 1) / GBK;
       gload1(RA, ra, Ap, amode, ars, aks, m0, g.M, kbeg);
       gload1(RB, rb, Bp, bmode, bcs, bks, n0, g.N, kbeg);
-      for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        __syncthreads();                               // the previous tile is fully consumed
-        lstore1(RA, As, ra, LA);
-        lstore1(RB, Bs, rb, LB);
-        __syncthreads();
-        if (k0 + GBK < kend) {                         // next tile's global loads fly under this tile's MFMAs
-          gload1(RA, ra, Ap, amode, ars, aks, m0, g.M, k0 + GBK);
-          gload1(RB, rb, Bp, bmode, bcs, bks, n0, g.N, k0 + GBK);
+      __syncthreads();                                 // (a previous operand pair is fully consumed)
+      lstore1(RA, As, ra, LA);
+      lstore1(RB, Bs, rb, LB);
+      if (ntile > 1) {
+        gload1(RA, ra, Ap, amode, ars, aks, m0, g.M, kbeg + GBK);
+        gload1(RB, rb, Bp, bmode, bcs, bks, n0, g.N, kbeg + GBK);
+      }
+      __syncthreads();
+      for (int kt = 0; kt < ntile; ++kt) {
+        const float* Ac = As + (kt & 1) * ASZ;
+        const float* Bc = Bs + (kt & 1) * BSZ;
+        if (kt + 1 < ntile) {
+          // tile kt + 1 goes into the other buffer (its last readers passed the barrier that ended iteration kt - 1), the
+          // global loads of tile kt + 2 then fly under this tile's MFMAs
+          lstore1(RA, As + ((kt + 1) & 1) * ASZ, ra, LA);
+          lstore1(RB, Bs + ((kt + 1) & 1) * BSZ, rb, LB);
+          if (kt + 2 < ntile) {
+            gload1(RA, ra, Ap, amode, ars, aks, m0, g.M, kbeg + (kt + 2) * GBK);
+            gload1(RB, rb, Bp, bmode, bcs, bks, n0, g.N, kbeg + (kt + 2) * GBK);
+          }
         }
         f32x4 a4[MT], b4[NT], an[MT], bn[NT];
 #pragma unroll
-        for (int a = 0; a < MT; ++a) a4[a] = frag(RA, As, LA, wm * TM + 32 * a, 0);
+        for (int a = 0; a < MT; ++a) a4[a] = frag(RA, Ac, LA, wm * TM + 32 * a, 0);
 #pragma unroll
-        for (int b = 0; b < NT; ++b) b4[b] = frag(RB, Bs, LB, wn * TN + 32 * b, 0);
+        for (int b = 0; b < NT; ++b) b4[b] = frag(RB, Bc, LB, wn * TN + 32 * b, 0);
 #pragma unroll
         for (int q = 0; q < GBK / 8; ++q) {
           if (q + 1 < GBK / 8) {
 #pragma unroll
-            for (int a = 0; a < MT; ++a) an[a] = frag(RA, As, LA, wm * TM + 32 * a, q + 1);
+            for (int a = 0; a < MT; ++a) an[a] = frag(RA, Ac, LA, wm * TM + 32 * a, q + 1);
 #pragma unroll
-            for (int b = 0; b < NT; ++b) bn[b] = frag(RB, Bs, LB, wn * TN + 32 * b, q + 1);
+            for (int b = 0; b < NT; ++b) bn[b] = frag(RB, Bc, LB, wn * TN + 32 * b, q + 1);
           }
 #pragma unroll
           for (int t = 0; t < 4; ++t)
@@ -181,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 #pragma unroll
           for (int b = 0; b < NT; ++b) b4[b] = bn[b];
         }
+        __syncthreads();
       }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -630,13 +649,23 @@ struct LayerwiseWS {
     return 0;
   }
 
+  template <int BN>
+  static constexpr size_t gemm_lds_bytes() {
+    return 2 * sizeof(float) * (size_t)(GBM * GLD + ((BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4)));
+  }
   static void launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
+    static const bool attr_set = [] {                 // double-buffered operand tiles: 72 KB of dynamic LDS at BN = 128
+      (void)hipFuncSetAttribute((const void*)k_gemm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<32>());
+      (void)hipFuncSetAttribute((const void*)k_gemm<GBN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<GBN>());
+      return true;
+    }();
+    (void)attr_set;
     if (g.N <= 32) {
       dim3 grid(1, (g.M + GBM - 1) / GBM, splits);
-      hipLaunchKernelGGL(k_gemm<32>, grid, dim3(256), 0, st, g);
+      hipLaunchKernelGGL(k_gemm<32>, grid, dim3(256), gemm_lds_bytes<32>(), st, g);
     } else {
       dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, splits);
-      hipLaunchKernelGGL(k_gemm<GBN>, grid, dim3(256), 0, st, g);
+      hipLaunchKernelGGL(k_gemm<GBN>, grid, dim3(256), gemm_lds_bytes<GBN>(), st, g);
     }
   }
   static int ew_grid(int64_t cnt) { int64_t g = (cnt + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
