@@ -40,7 +40,7 @@ struct GemmArgs {
   int epi;
 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = GBK + 4, GLT = GBM + 4;
+constexpr int GBN = 128, GBK = 32, GLD = GBK + 4;
 
 // C = sum_p A_p * B_p with v_mfma_f32_32x32x2_f32; 4 waves in a 2x2 grid of 64x64 sub-tiles, K tiles of 32.
 // Operand tiles go global -> registers -> LDS in the 16-byte granules they are contiguous in:
@@ -53,21 +53,28 @@ constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = GBK + 4, GLT = GBM + 4;
 // global memory (register-staged) before the MFMAs of tile k.  blockIdx.z splits the K range of pair 0 (wgrad: K = samples).
 // BN = 128: 2x2 waves of 64x64; BN = 32 (narrow outputs: action heads, value heads): 4x1 waves of 32x32, so a
 // 17-column product is padded to 32 instead of 128 columns.
+// threads per workgroup: 8 waves of 32 x 64 sub-tiles at BN = 128 (one workgroup per CU, two waves per SIMD, 169 VGPRs, no
+// spills; 4 waves of 64 x 64 needed all 256 VGPRs and spilled in the k-loop), 4 waves of 32 x 32 at BN = 32
+template <int BN> constexpr int gemm_threads() { return BN >= 128 ? 512 : 256; }
+// rows per workgroup tile (256 x 128 tiles -- 8 waves of 64 x 64 -- were measured 3-4 % slower than 128 x 128 at cfg4 / cfg5)
+template <int BN> constexpr int gemm_bm() { return 128; }
+
 template <int BN>
-__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+__global__ __launch_bounds__(gemm_threads<BN>(), 2) void k_gemm(GemmArgs g) {      // (second argument: waves per SIMD; 4 would need <= 128 VGPRs: spills, measured slower)
+  constexpr int NTH = gemm_threads<BN>(), BM = gemm_bm<BN>();
   constexpr int WN = BN / 64 > 0 ? BN / 64 : 1;   // waves along N
-  constexpr int WMc = 4 / WN;                     // waves along M
-  constexpr int TM = GBM / WMc, TN = BN / WN;     // per-wave tile
+  constexpr int WMc = (NTH / 64) / WN;            // waves along M
+  constexpr int TM = BM / WMc, TN = BN / WN;     // per-wave tile
   constexpr int MT = TM / 32, NT = TN / 32;
   // two buffers per operand (dynamic LDS: 72 KB at BN = 128, two workgroups per CU): tile k + 1 is stored while tile k is
   // being multiplied, ONE barrier per k-tile
-  constexpr int ASZ = GBM * GLD, BSZ = (BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4);
+  constexpr int ASZ = BM * GLD, BSZ = (BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4);
   extern __shared__ __attribute__((aligned(16))) float gsm[];
   float* As = gsm;                       // [2][ASZ]
   float* Bs = gsm + 2 * ASZ;             // [2][BSZ]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
       kend = min(g.K[p], kbeg + chunk);
     }
     if (kbeg >= kend) continue;
-    // one operand tile = 128 rows x 32 k = 1024 float4; 4 per thread.  mode 0: K-contiguous, mode 1: row-contiguous,
+    // one operand tile = 128 rows x 32 k = 1024 float4; 2 (4) per thread.  mode 0: K-contiguous, mode 1: row-contiguous,
     // mode 2: anything else (scalar gather)
     auto mode_of = [](const float* ptr, int64_t rs, int64_t ks) {
       if (ks == 1 && (rs & 3) == 0 && (((uintptr_t)ptr) & 15) == 0) return 0;
@@ -94,26 +101,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     const float* __restrict__ Bp = g.B[p];
     const int64_t ars = g.a_rs[p], aks = g.a_ks[p], bcs = g.b_cs[p], bks = g.b_ks[p];
     const int amode = mode_of(Ap, ars, aks), bmode = mode_of(Bp, bcs, bks);
-    constexpr int CA = GBM / 32, CB = BN / 32;        // float4 per thread and operand tile
+    constexpr int CA = BM * 8 / NTH, CB = BN * 8 / NTH;        // float4 per thread and operand tile
     f32x4 ra[CA], rb[CB];
     // RT = rows of the tile (128 or 32): 8 float4 per row in the [row][k] image, RT/4 per k-row in the [k][row] image
     auto gload1 = [&](auto rt, auto& r, const float* __restrict__ P, int mode, int64_t rs, int64_t ks, int r0, int R, int k0) {
-      constexpr int RT = decltype(rt)::value, NC = RT / 32, Q = RT / 4;
+      constexpr int RT = decltype(rt)::value, NC = RT * 8 / NTH, Q = RT / 4;
       // interior tiles (block-uniform test): unconditional 16-byte loads, nothing else in the way
       if (mode != 2 && r0 + RT <= R && k0 + GBK <= kend) {
         if (mode == 0) {
 #pragma unroll
-          for (int c = 0; c < NC; ++c) { const int idx = tid + 256 * c; r[c] = *(const f32x4*)(P + (int64_t)(r0 + (idx >> 3)) * rs + k0 + 4 * (idx & 7)); }
+          for (int c = 0; c < NC; ++c) { const int idx = tid + NTH * c; r[c] = *(const f32x4*)(P + (int64_t)(r0 + (idx >> 3)) * rs + k0 + 4 * (idx & 7)); }
         } else {
 #pragma unroll
-          for (int c = 0; c < NC; ++c) { const int idx = tid + 256 * c; r[c] = *(const f32x4*)(P + (int64_t)(k0 + idx / Q) * ks + r0 + 4 * (idx % Q)); }
+          for (int c = 0; c < NC; ++c) { const int idx = tid + NTH * c; r[c] = *(const f32x4*)(P + (int64_t)(k0 + idx / Q) * ks + r0 + 4 * (idx % Q)); }
         }
         return;
       }
       // edge tiles / unaligned operands: element-wise, clamped address + select (no branches)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int idx = tid + 256 * c;
+        const int idx = tid + NTH * c;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = (mode == 1) ? r0 + 4 * (idx % Q) + e : r0 + (idx >> 3);
@@ -127,10 +134,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     // LDS image: K-contiguous operands as [row][k] (stride GLD), row-contiguous ones as [k][row] (stride RT + 4) --
     // either way the 16-byte granule that was loaded is stored with one conflict-free ds_write_b128
     auto lstore1 = [&](auto rt, float* S, const auto& r, int mode) {
-      constexpr int RT = decltype(rt)::value, NC = RT / 32, Q = RT / 4;
+      constexpr int RT = decltype(rt)::value, NC = RT * 8 / NTH, Q = RT / 4;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int idx = tid + 256 * c;
+        const int idx = tid + NTH * c;
         if (mode == 1) *(f32x4*)&S[(idx / Q) * (RT + 4) + 4 * (idx % Q)] = r[c];
         else *(f32x4*)&S[(idx >> 3) * GLD + 4 * (idx & 7)] = r[c];
       }
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
       }
       return *(const f32x4*)&S[(row0 + j) * GLD + 8 * q + 4 * hi];
     };
-    constexpr std::integral_constant<int, GBM> RA{};
+    constexpr std::integral_constant<int, BM> RA{};
     constexpr std::integral_constant<int, BN> RB{};
     // The K loop is instantiated per LDS image pair (chosen once per operand pair, outside the loop), so that the body
     // is one straight-line block: fragment reads of group q + 1 and the MFMAs of group q schedule together.
@@ -651,8 +658,9 @@ struct LayerwiseWS {
 
   template <int BN>
   static constexpr size_t gemm_lds_bytes() {
-    return 2 * sizeof(float) * (size_t)(GBM * GLD + ((BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4)));
+    return 2 * sizeof(float) * (size_t)(gemm_bm<BN>() * GLD + ((BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4)));
   }
+  static int bm_of(int ncols) { return ncols <= 32 ? gemm_bm<32>() : gemm_bm<GBN>(); }     // row-block height launch_gemm will use
   static void launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
     static const bool attr_set = [] {                 // double-buffered operand tiles: 72 KB of dynamic LDS at BN = 128
       (void)hipFuncSetAttribute((const void*)k_gemm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<32>());
@@ -661,11 +669,11 @@ struct LayerwiseWS {
     }();
     (void)attr_set;
     if (g.N <= 32) {
-      dim3 grid(1, (g.M + GBM - 1) / GBM, splits);
-      hipLaunchKernelGGL(k_gemm<32>, grid, dim3(256), gemm_lds_bytes<32>(), st, g);
+      dim3 grid(1, (g.M + gemm_bm<32>() - 1) / gemm_bm<32>(), splits);
+      hipLaunchKernelGGL(k_gemm<32>, grid, dim3(gemm_threads<32>()), gemm_lds_bytes<32>(), st, g);
     } else {
-      dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, splits);
-      hipLaunchKernelGGL(k_gemm<GBN>, grid, dim3(256), gemm_lds_bytes<GBN>(), st, g);
+      dim3 grid((g.N + GBN - 1) / GBN, (g.M + gemm_bm<GBN>() - 1) / gemm_bm<GBN>(), splits);
+      hipLaunchKernelGGL(k_gemm<GBN>, grid, dim3(gemm_threads<GBN>()), gemm_lds_bytes<GBN>(), st, g);
     }
   }
   static int ew_grid(int64_t cnt) { int64_t g = (cnt + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
@@ -703,14 +711,14 @@ struct LayerwiseWS {
   // epilogue, reduced in a fixed order); only the top delta (d3, written by the head kernel) needs its own pass.
   int backward(const float* theta, int64_t N, float* grad, hipStream_t st) {
     const float* delta = d3;
-    const int rowblocks = (int)((N + GBM - 1) / GBM);
     bool bias_done = false;
     for (int l = nL() - 1; l >= 0; --l) {
       const int ho = sizes[l + 1], hi_ = sizes[l];
       const float* in = (l == 0) ? Xn : H[l - 1];
       // weight gradient: gW[ho x hi] = delta^T (ho x N) * in (N x hi), split over samples
       const bool narrow = ho <= 32;                 // action head: compute gW^T (hi x ho) so the padding goes to 32 columns, not 128 rows
-      int tiles = narrow ? (hi_ + GBM - 1) / GBM : ((ho + GBM - 1) / GBM) * ((hi_ + GBN - 1) / GBN);
+      const int rowblocks = (int)((N + bm_of(hi_) - 1) / bm_of(hi_));      // of the delta GEMM below (its column sums)
+      int tiles = narrow ? (hi_ + bm_of(ho) - 1) / bm_of(ho) : ((ho + bm_of(hi_) - 1) / bm_of(hi_)) * ((hi_ + GBN - 1) / GBN);
       int splits = (int)((N + 2047) / 2048);
       int maxs = (1024 + tiles - 1) / tiles;
       if (splits > maxs) splits = maxs;
@@ -859,7 +867,7 @@ struct LayerwiseWS {
       const int ho = sizes[l + 1], hi_ = sizes[l];
       const float* in = (l == 0) ? Xn : H[l - 1];
       const float* tinl = (l == 0) ? nullptr : T[l - 1];
-      int tiles = ((ho + GBM - 1) / GBM) * ((hi_ + GBN - 1) / GBN);
+      int tiles = ((ho + bm_of(hi_) - 1) / bm_of(hi_)) * ((hi_ + GBN - 1) / GBN);
       int splits = (int)((N + 2047) / 2048);
       int maxs = (1024 + tiles - 1) / tiles;
       if (splits > maxs) splits = maxs;
