@@ -326,7 +326,9 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 
   MJX_GSTAMP(17);
   // ---------------- persistent accumulators ----------------
-  constexpr int NT3 = H2 / 16;                    // gW3 lives in 16x16 tiles: [action 4(l>>4)+r][unit 16nt + (l&15)]
+  // gW3 lives in 4x4 blocks of v_mfma_f32_4x4x1: lane l = (block b = l >> 2, column l & 3), block b = (action group
+  // g = b / QPI3, unit quad uq = b % QPI3); accumulator i, register r: gW3[4 g + r][4 uq + (l & 3) + UPI3 i]
+  constexpr int QPI3 = 16 / (MP / 4), UPI3 = 4 * QPI3, NT3 = H2 / UPI3;
   f32x16 gW1[MT1][NT1], gW2[MT2][MT1];
   f32x4 gW3[NT3];
   float sb2[MT2], sb3r[RA], gls[RA];      // grad b2[32*nt + j] (every lane); grad b3 / grad log_std of action unit_of(r, hi), this lane's samples
@@ -871,19 +873,14 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       if (MODE == MODE_FVP && CACHED && tile + tstride < ntiles) load_h(tile + tstride);
       wave_sync();
       MJX_STAMP(9);
-      // gW3[a][k] += sum_s d3[s][a] * h2[s][k] on v_mfma_f32_16x16x4_f32 (M = actions padded to 16, N = 16 units,
-      // K = 4 samples; 32 cycles each): half the matrix-pipe time of padding the actions to a 32-row tile.
-      // k-slot (l>>4) of step (half, t) carries sample 16 half + 4 (l>>4) + t, so one ds_read_b128 feeds 4 steps.
+      // gW3[a][k] += sum_s d3[s][a] * h2[s][k] on v_mfma_f32_4x4x1_16b_f32: one instruction = 16 independent 4 x 4 outer
+      // products (8 cycles), here one SAMPLE's contribution to (MP / 4 action groups) x (QPI3 unit quads) blocks -- no
+      // padding of the action dimension (6 -> 8 instead of 6 -> 16 on a 16x16x4 tile: half the matrix-pipe time).
+      // Operands straight from the [action][sample] / [unit][sample] LDS copies: one ds_read_b128 = 4 samples = 4 steps.
       {
-        const int u16 = lane & 15, kq = lane >> 4;
-        const float* arow = &d3T[(u16 < MP ? u16 : 0) * ST + 4 * kq];
-        f32x4 a4[2], b4[NT3][2];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          a4[hf] = *(const f32x4*)(arow + 16 * hf);
-#pragma unroll
-          for (int nt = 0; nt < NT3; ++nt) b4[nt][hf] = *(const f32x4*)&bufA[(16 * nt + u16) * ST + 16 * hf + 4 * kq];
-        }
+        const int blk = lane >> 2, g3 = blk / QPI3, uq3 = blk % QPI3;
+        const float* arow = &d3T[(4 * g3 + (lane & 3)) * ST];
+        const float* brow = &bufA[(4 * uq3 + (lane & 3)) * ST];
         // delta2u *= (1 - h2^2): h2[sample unit_of(4q+t, hi)][unit 32nt + j] from the [unit][sample] copy
         f32x4 fc[MT2][4];
 #pragma unroll
@@ -891,12 +888,15 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) fc[nt][q] = *(const f32x4*)&bufA[(32 * nt + j) * ST + 8 * q + 4 * hi];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          if (u16 >= MP) a4[hf] = (f32x4)(0.f);
+        for (int s4 = 0; s4 < 8; ++s4) {
+          const f32x4 av = *(const f32x4*)(arow + 4 * s4);
+          f32x4 bv[NT3];
+#pragma unroll
+          for (int nt = 0; nt < NT3; ++nt) bv[nt] = *(const f32x4*)(brow + UPI3 * nt * ST + 4 * s4);
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int nt = 0; nt < NT3; ++nt) gW3[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[hf][t], b4[nt][hf][t], gW3[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT3; ++nt) gW3[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[t], bv[nt][t], gW3[nt], 0, 0, 0);
         }
 #pragma unroll
         for (int nt = 0; nt < MT2; ++nt)
@@ -1061,8 +1061,8 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     for (int nt = 0; nt < NT3; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int a = 4 * (lane >> 4) + r;
-        if (a < m) mine[fo.W3 + a * H2 + 16 * nt + (lane & 15)] = gW3[nt][r];
+        const int blk = lane >> 2, a = 4 * (blk / QPI3) + r, u = 4 * (blk % QPI3) + (lane & 3) + UPI3 * nt;
+        if (a < m) mine[fo.W3 + a * H2 + u] = gW3[nt][r];
       }
     float sb2f[MT2];
 #pragma unroll
