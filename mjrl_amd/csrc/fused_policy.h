@@ -330,12 +330,22 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   // g = b / QPI3, unit quad uq = b % QPI3); accumulator i, register r: gW3[4 g + r][4 uq + (l & 3) + UPI3 i]
   constexpr int QPI3 = 16 / (MP / 4), UPI3 = 4 * QPI3, NT3 = H2 / UPI3;
   f32x16 gW1[MT1][NT1], gW2[MT2][MT1];
+  // compile-time feature count (NPC != 0): gW1 on v_mfma_f32_4x4x1 instead -- block b = lane >> 2 holds
+  // gW1[32 mt + 4 (b & 7) + r][4 fq + (lane & 3)] of accumulator (mt, fq), register r, summed over the samples of the
+  // lane's half (the two halves are added once, after the tile loop): NPC / 4 instructions per sample pair instead of a
+  // 32-column tile for NPC = 20 columns
+  constexpr int NFQ = NPC ? NPC / 4 : 1;
+  f32x4 gW1q[MT1][NFQ];
   f32x4 gW3[NT3];
   float sb2[MT2], sb3r[RA], gls[RA];      // grad b2[32*nt + j] (every lane); grad b3 / grad log_std of action unit_of(r, hi), this lane's samples
 #pragma unroll
   for (int a = 0; a < MT1; ++a)
 #pragma unroll
     for (int b = 0; b < NT1; ++b) gW1[a][b] = (f32x16)(0.f);
+#pragma unroll
+  for (int a = 0; a < MT1; ++a)
+#pragma unroll
+    for (int b = 0; b < NFQ; ++b) gW1q[a][b] = (f32x4)(0.f);
 #pragma unroll
   for (int a = 0; a < MT2; ++a)
 #pragma unroll
@@ -995,7 +1005,24 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       }
       MJX_STAMP(12);
       // gW1a[u1][f] += sum_s delta1[s][u1] * x~a[s][f]   (column n = bias gradient); A from registers
-      {
+      if constexpr (NPC != 0) {
+        // 4x4x1 blocks: A = delta1 of the block's 4 units (lanes 4b .. 4b+3, this half's sample of register r),
+        // B = x~ of that sample for the lane's feature 4 fq + (lane & 3); one ds_read_b128 of x~^T covers 4 registers
+        const float* xrow = &xT[(lane & 3) * ST + 4 * hi];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 bx[NFQ];
+#pragma unroll
+          for (int fq = 0; fq < NFQ; ++fq) bx[fq] = *(const f32x4*)(xrow + 4 * fq * ST + 8 * q);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int fq = 0; fq < NFQ; ++fq)
+#pragma unroll
+              for (int mt = 0; mt < MT1; ++mt)
+                gW1q[mt][fq] = __builtin_amdgcn_mfma_f32_4x4x1f32(dl1u[mt][4 * q + t], bx[fq][t], gW1q[mt][fq], 0, 0, 0);
+        }
+      } else {
         f32x4 bc[NT1], bn[NT1];
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt) { int f = 32 * nt + j; bc[nt] = *(const f32x4*)&xT[(f < NP ? f : 0) * ST + 4 * hi]; }
@@ -1040,16 +1067,32 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     float* red = lds;                             // 4 * d floats <= TOTAL (checked on host)
     float* mine = red + wave * fo.d;
     // (every entry of the wave's copy is written below: W1a/b1, W2, W3, b2, b3 and the log_std block)
+    if constexpr (NPC != 0) {
 #pragma unroll
-    for (int mt = 0; mt < MT1; ++mt)
+      for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT1; ++nt)
+        for (int fq = 0; fq < NFQ; ++fq)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int u = 32 * mt + unit_of(r, hi), f = 32 * nt + j;
-          if (f < n) mine[fo.W1 + u * n + f] = gW1[mt][nt][r];
-          else if (f == n) mine[fo.b1 + u] = gW1[mt][nt][r];
-        }
+          for (int r = 0; r < 4; ++r) {
+            const float v = half_sum(gW1q[mt][fq][r]);
+            const int u = 32 * mt + 4 * ((lane >> 2) & 7) + r, f = 4 * fq + (lane & 3);
+            if (hi == 0) {
+              if (f < n) mine[fo.W1 + u * n + f] = v;
+              else if (f == n) mine[fo.b1 + u] = v;
+            }
+          }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int u = 32 * mt + unit_of(r, hi), f = 32 * nt + j;
+            if (f < n) mine[fo.W1 + u * n + f] = gW1[mt][nt][r];
+            else if (f == n) mine[fo.b1 + u] = gW1[mt][nt][r];
+          }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
