@@ -1,4 +1,4 @@
-"""one layer-wise FVP at cfg4 shapes (for rocprofv3 --kernel-trace): prints nothing; analyse the trace with tools/lw_trace_report.py"""
+"""one layer-wise FVP at cfg4 shapes (for rocprofv3 --kernel-trace): prints nothing; read the per-launch durations from <out>_kernel_trace.csv (the last ~25 dispatches are one FVP)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
