@@ -531,8 +531,12 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
     }
   }
   if (int rc = dispatch_fused(c, MODE_VPG, a, st)) return rc;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
-                     grad_out, (const float*)nullptr, (const float*)nullptr, c->oS, 0.f);
+  if ((c->d & 3) == 0)
+    hipLaunchKernelGGL(k_reduce_partials4, dim3((c->d + 31) / 32), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
+                       grad_out, (const float*)nullptr, (const float*)nullptr, c->oS, 0.f);
+  else
+    hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
+                       grad_out, (const float*)nullptr, (const float*)nullptr, c->oS, 0.f);
   hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, c->grid, scal_out);
   HIPCHK(hipGetLastError());
   return MJX_OK;
@@ -564,8 +568,12 @@ int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
   if (c->hcache_valid && c->N_local <= c->hcache_rows) a.hcache = c->hcache;
   if (int rc = dispatch_fused(c, MODE_FVP, a, st)) return rc;
   if (prof) { HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], st)); c->prof_used += 2; }
-  hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
-                     out, c->theta_new, v, c->oS, frac);
+  if ((c->d & 3) == 0)
+    hipLaunchKernelGGL(k_reduce_partials4, dim3((c->d + 31) / 32), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
+                       out, c->theta_new, v, c->oS, frac);
+  else
+    hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
+                       out, c->theta_new, v, c->oS, frac);
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }

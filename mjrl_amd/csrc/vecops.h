@@ -7,9 +7,41 @@
 
 namespace mjx {
 
+// Sum over the 64 lanes of a wave, every lane gets the total.  Register-level cross-lane moves only (DPP inside the
+// 16-lane rows, v_permlane16_swap / v_permlane32_swap across them): the ds_bpermute butterfly this replaces cost
+// twelve LDS-crossbar round trips per fp64 sum.  Fixed order, identical on every lane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+// the value of lane ^ 16 (ROWS == 16) or lane ^ 32 (ROWS == 32): after a swap of a register with itself every lane
+// holds {own, partner} in the two results, so partner = r0 ^ r1 ^ own
+template <int ROWS>
+__device__ __forceinline__ double partner_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+  unsigned plo, phi;
+  if (ROWS == 16) {
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    plo = a[0] ^ a[1] ^ lo; phi = c[0] ^ c[1] ^ hi;
+  } else {
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    plo = a[0] ^ a[1] ^ lo; phi = c[0] ^ c[1] ^ hi;
+  }
+  return __longlong_as_double((long long)(((unsigned long long)phi << 32) | plo));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  v += dpp_move_f64<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_move_f64<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += dpp_move_f64<0x141>(v);      // row_half_mirror
+  v += dpp_move_f64<0x140>(v);      // row_mirror
+  v += partner_f64<16>(v);
+  v += partner_f64<32>(v);
   return v;
 }
 
@@ -44,6 +76,39 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += sh[k][cl];
+    if (v != nullptr && c >= oS) {
+      float s = expf(theta[c]);
+      float u = s * s, e = 1e-8f;
+      float den = 2.0f * u + e;
+      float cc = 16.0f * u * u / (den * den) - 4.0f * u / den;
+      t = (double)(frac * cc * v[c]);
+    }
+    out[c] = (float)t;
+  }
+}
+
+// the same for d % 4 == 0 with 16-byte loads: 32 columns (8 float4) x 32 row groups per block, i.e. 128-byte row
+// segments instead of 64-byte ones and a quarter of the load instructions (7 -> ~4.5 us for 256 x 5.7 k partials)
+__global__ __launch_bounds__(256) void k_reduce_partials4(const float* __restrict__ partials, int G, int d,
+                                                           float* __restrict__ out, const float* theta,
+                                                           const float* v, int oS, float frac) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ double sh[32][33];
+  const int cq = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const int c0 = (blockIdx.x * 8 + cq) * 4;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (c0 < d)
+    for (int g = rg; g < G; g += 32) {
+      const f4 p = *(const f4*)(partials + (size_t)g * d + c0);
+      a0 += (double)p.x; a1 += (double)p.y; a2 += (double)p.z; a3 += (double)p.w;
+    }
+  sh[rg][4 * cq] = a0; sh[rg][4 * cq + 1] = a1; sh[rg][4 * cq + 2] = a2; sh[rg][4 * cq + 3] = a3;
+  __syncthreads();
+  const int cl = threadIdx.x, c = blockIdx.x * 32 + cl;
+  if (cl < 32 && c < d) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += sh[k][cl];
     if (v != nullptr && c >= oS) {
       float s = expf(theta[c]);
       float u = s * s, e = 1e-8f;
