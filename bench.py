@@ -123,10 +123,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
+    # (test hooks: MJX_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and MJX_BENCH_BACKEND=gloo replaces RCCL, which refuses
+    #  two ranks on one device -- tests/test_gpu_parity.py runs the N = 2 path of this script on a 1-GPU box that way)
+    dev_index = 0 if os.environ.get("MJX_BENCH_SHARE_GPU") == "1" else local_rank
+    backend = os.environ.get("MJX_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     shards = world
     if args.rehearse_world > 1:
         assert world == 1

@@ -1,0 +1,53 @@
+"""Worker of test_two_ranks_on_one_gpu_equal_one_rank: one of two ranks (torch.distributed.run, gloo backend -- RCCL
+refuses two ranks on one device) that share the GPU.  Each rank binds its trajectory shard, the engine all-reduces
+device tensors exactly as it does over RCCL; rank 0 writes the update's results."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from oracle import synth
+    from mjrl_amd.engine import UpdateEngine
+    out_path = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, m, hid, N = 17, 6, (64, 64), 60000
+    rng = np.random.RandomState(5)                       # identical on all ranks
+    obs, act, adv = rng.randn(N, n).astype(np.float32), rng.randn(N, m).astype(np.float32), rng.randn(N).astype(np.float32)
+    cut = 23456                                          # ragged shards
+    lo, hi = (0, cut) if rank == 0 else (cut, N)
+    th = synth.perturbed_params(synth.init_params(n, m, hid))
+    ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    eng = UpdateEngine(n, m, hid)
+    eng.set_policy(th, th, ident, ident)
+    eng.set_batch(obs[lo:hi], act[lo:hi], adv[lo:hi])    # N_global through the process group
+    assert eng.N_global == N
+    g, _ = eng.surr_vpg(sync=False)
+    eng.cg_solve(g, 10, 1e-4, sync=False)
+    eng.apply_npg_step(0.05, -3.0)
+    surr_after, kl = eng.eval_surr_kl()
+    late = eng.deferred()
+    res = dict(grad=g.cpu().numpy(), x=eng.x.cpu().numpy(), theta=eng.theta_new.cpu().numpy(),
+               scal=np.array([late["surr_before"], late["gdotx"], late["alpha"], surr_after, kl]))
+    # every rank must hold identical results (the CG scalars are recomputed redundantly from the reduced vectors)
+    t = torch.from_numpy(np.concatenate([res["x"], res["theta"], res["scal"].astype(np.float32)])).cuda()
+    lo_t, hi_t = t.clone(), t.clone()
+    dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+    res["ranks_identical"] = np.array([bool(torch.equal(lo_t, hi_t))])
+    if rank == 0:
+        np.savez(out_path, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

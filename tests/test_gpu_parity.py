@@ -16,6 +16,8 @@ from tests._cases import NPG_CASES, NpgCase, load
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 TOL_VPG = 3e-6
 TOL_FVP = 3e-6
 TOL_STEP = 1e-5          # the north-star bar
@@ -218,6 +220,71 @@ def test_shard_sum_parity():
     assert rel(g_sum.cpu().numpy(), g_full.cpu().numpy()) < 5e-7
     assert rel(h_sum.cpu().numpy(), h_full.cpu().numpy()) < 5e-7
     eng.close()
+
+
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
+    """The multi-rank control flow on real kernels: two processes (torch.distributed.run, gloo collectives on device
+    tensors -- RCCL refuses two ranks on one device) share the GPU, each binds a ragged trajectory shard and runs the
+    engine's update sequence (K1 + all-reduce, the per-iteration FVP / all-reduce / CG-step loop, device-side step
+    length, K3 + all-reduce, one read-back).  Result == the one-process update on the whole batch; all ranks hold
+    bit-identical vectors."""
+    import subprocess
+    import sys
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    out = str(tmp_path / "two_rank.npz")
+    port = 29600 + (os.getpid() % 300)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_two_rank_gpu_worker.py"), out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    two = np.load(out)
+    assert bool(two["ranks_identical"][0])
+    n, m, hid, N = 17, 6, (64, 64), 60000
+    rng = np.random.RandomState(5)
+    obs, act, adv = rng.randn(N, n).astype(np.float32), rng.randn(N, m).astype(np.float32), rng.randn(N).astype(np.float32)
+    th = synth.perturbed_params(synth.init_params(n, m, hid))
+    ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    eng = UpdateEngine(n, m, hid)
+    eng.set_policy(th, th, ident, ident)
+    eng.set_batch(obs, act, adv)
+    g, _ = eng.surr_vpg(sync=False)
+    eng.cg_solve(g, 10, 1e-4, sync=False)
+    eng.apply_npg_step(0.05, -3.0)
+    surr_after, kl = eng.eval_surr_kl()
+    late = eng.deferred()
+    assert rel(two["grad"], g.cpu().numpy()) < 2e-6
+    assert rel(two["x"], eng.x.cpu().numpy()) < 2e-5                 # (CG amplifies the fp32 summation-order noise)
+    assert rel(two["theta"], eng.theta_new.cpu().numpy()) < 1e-6
+    one = np.array([late["surr_before"], late["gdotx"], late["alpha"], surr_after, kl])
+    np.testing.assert_allclose(two["scal"], one, rtol=2e-5, atol=1e-7)
+    eng.close()
+
+
+def test_bench_two_rank_path_on_one_gpu():
+    """bench.py's N = 2 path (sharding, global whitening, barrier + max-over-ranks timing, rank-0 JSON line) with both
+    ranks on this GPU and gloo in place of RCCL: same update as the N = 1 run (alpha, KL, surrogate improvement)."""
+    import json
+    import subprocess
+    import sys
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         env=base, capture_output=True, text=True, timeout=280)
+    assert one.returncode == 0, one.stderr[-3000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    port = 29300 + (os.getpid() % 300)
+    env = dict(base, MJX_BENCH_SHARE_GPU="1", MJX_BENCH_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=280)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                # rank 0 only
+    j2 = json.loads(lines[0])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j2["value"] > 0 and j2["config"]["global_batch"] == j1["config"]["global_batch"]
+    for k in ("alpha", "kl", "surr_improvement"):
+        assert abs(j2["check"][k] - j1["check"][k]) <= 2e-4 * abs(j1["check"][k]) + 1e-9, (k, j1["check"], j2["check"])
 
 
 def test_fvp_properties_full_size():
