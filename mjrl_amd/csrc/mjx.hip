@@ -136,6 +136,8 @@ int dispatch_fused(mjx_ctx* c, int mode, const FusedArgs& a, hipStream_t st) {
   if (c->fused == 1 && NPr == 20) return launch_fused<64, 64, 1, 8, false, 20>(c, mode, a, st);
 #endif
   if (c->fused == 1 && NPr == 20 && !c->dbg) return launch_fused<64, 64, 1, 8, false, 20>(c, mode, a, st);   // obs 16..19 (HalfCheetah 17)
+  if (c->fused == 1 && NPr == 12 && !c->dbg) return launch_fused<64, 64, 1, 8, false, 12>(c, mode, a, st);   // obs 8..11 (Hopper 11, Reacher 11, Swimmer 8)
+  if (c->fused == 1 && NPr == 8 && !c->dbg) return launch_fused<64, 64, 1, 8, false, 8>(c, mode, a, st);     // obs 4..7 (InvertedPendulum 4, point_mass 6)
   switch (c->fused) {
 #ifdef MJX_PHASE_CLOCK
     case 1: return launch_fused<64, 64, 1, 8>(c, mode, a, st);          // stamps go to the debug buffer of the production kernel

@@ -540,6 +540,11 @@ def test_hvp_sample_frac_rng_parity():
 
 
 @pytest.mark.parametrize("n,m,hid,expect_fused", [
+    (11, 3, (64, 64), True),       # compile-time feature count 12 (Hopper-sized observations)
+    (8, 2, (64, 64), True),        # ... 12 at its lower edge (n + 1 = 9)
+    (6, 2, (64, 64), True),        # compile-time feature count 8
+    (4, 1, (64, 64), True),        # ... and n + 1 = 5
+    (19, 6, (64, 64), True),       # compile-time feature count 20 at its upper edge (no pad column)
     (17, 12, (64, 64), True),      # MP = 16 variant
     (9, 10, (32, 32), True),       # 32x32, MP = 16
     (40, 4, (32, 32), True),       # NT1 = 2 (obs dim > 31)
