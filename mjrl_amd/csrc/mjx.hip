@@ -126,6 +126,7 @@ int pick_variant(int n, int m, const std::vector<int>& hid, int64_t d, size_t* b
   if (variant_fits<64, 64, 1, 16>(n, m, h1, h2, d, bytes)) return 3;
   if (variant_fits<32, 32, 1, 16>(n, m, h1, h2, d, bytes)) return 4;
   if (variant_fits<32, 32, 2, 8>(n, m, h1, h2, d, bytes)) return 5;
+  if (variant_fits<32, 32, 2, 32>(n, m, h1, h2, d, bytes)) return 6;      // Adroit-class: 39-46 observations, 24-30 actions, 32 x 32 (hand_dapg)
   return 0;
 }
 
@@ -148,6 +149,7 @@ int dispatch_fused(mjx_ctx* c, int mode, const FusedArgs& a, hipStream_t st) {
     case 3: return launch_fused<64, 64, 1, 16>(c, mode, a, st);
     case 4: return launch_fused<32, 32, 1, 16>(c, mode, a, st);
     case 5: return launch_fused<32, 32, 2, 8>(c, mode, a, st);
+    case 6: return launch_fused<32, 32, 2, 32>(c, mode, a, st);
   }
   return fail(MJX_ERR_STATE, "no fused variant");
 }
@@ -519,7 +521,7 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
     if (c->hcache) { a.hcache = c->hcache; c->hcache_valid = true; c->hcache_obs = c->obs; c->hcache_rows = c->N_local; }
     // ... and the old policy's means / log-likelihoods for mjx_eval_surr_kl (old == new here), with a snapshot of
     // the parameters they belong to (the EVAL kernel compares before trusting them)
-    const size_t oneed = (size_t)((c->N_local + 31) / 32) * 17 * 32 * sizeof(float);
+    const size_t oneed = (size_t)((c->N_local + 31) / 32) * 33 * 32 * sizeof(float);     // [tile][MP + 1][32] with MP <= 32 (largest fused variant)
     if (oneed > c->ocache_bytes) {
       if (c->ocache) hipFree(c->ocache);
       c->ocache = nullptr; c->ocache_bytes = 0;
