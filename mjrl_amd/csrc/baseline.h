@@ -117,13 +117,80 @@ __global__ __launch_bounds__(256) void k_bl_gram(int nbt, const FeatDesc* __rest
     }
 }
 
-// G[r][c] = sum_z part[z][min][max]  (upper-triangle tiles were computed; mirror)
-__global__ void k_bl_gram_reduce(const double* __restrict__ part, int Z, int FA, double* __restrict__ G) {
+// The same on the fp64 matrix cores for up to 176 augmented features (obs dim <= 17 quadratic, any linear baseline of that
+// size): v_mfma_f64_16x16x4_f64, lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15] and receives
+// D[4 r + (l >> 4)][l & 15] in register r (probed: not the 4 (l >> 4) + r of the fp32 16x16x4 form).  One workgroup walks its own sample range in chunks of 32: ALL features of a chunk are
+// generated once into LDS ([sample][feature], row stride == 16 (mod 32) doubles: the 8-byte operand reads of the two
+// 32-lane halves hit disjoint banks), then the 4 waves update the upper-triangle 16 x 16 tiles they own (round-robin,
+// <= 17 accumulator tiles per wave, registers for the whole run).  The FMA kernel above re-generates a 64-column block
+// per tile pair and is bound by LDS operand bandwidth (8 x 8 bytes per 16 FMAs): 5.0 ms at 1M x 175; this one ~0.7 ms.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int GM_TMAX = 11, GM_TPW = (GM_TMAX * (GM_TMAX + 1) / 2 + 3) / 4;      // 66 tiles / 4 waves -> 17
+__global__ __launch_bounds__(256, 2) void k_bl_gram_mfma(const FeatDesc* __restrict__ table, int F, int n,
+                                                         const double* __restrict__ obs, const int32_t* __restrict__ tpos,
+                                                         const double* __restrict__ y, int64_t N, double* __restrict__ part) {
+  extern __shared__ double sm[];
+  const int FA = F + 1, T = (FA + 15) >> 4, FS = 16 * (T | 1), NTILE = T * (T + 1) / 2;
+  double* so = sm;                       // [32][n] clipped obs
+  double* ft = so + 32 * n;              // [32][FS] features (+ y in column F, zeros beyond)
+  __shared__ double stau[32];
+  __shared__ int16_t tile_i[GM_TMAX * (GM_TMAX + 1) / 2], tile_j[GM_TMAX * (GM_TMAX + 1) / 2];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
+  if (tid < NTILE) {                     // row-major upper triangle
+    int t = tid, i = 0;
+    while (t >= T - i) { t -= T - i; ++i; }
+    tile_i[tid] = (int16_t)i; tile_j[tid] = (int16_t)(i + t);
+  }
+  __syncthreads();
+  int ai[GM_TPW], bj[GM_TPW];            // this wave's tiles: LDS column offsets of the A / B operand of tile slot e
+  f64x4 acc[GM_TPW];
+#pragma unroll
+  for (int e = 0; e < GM_TPW; ++e) {
+    const int t = wave + 4 * e;
+    ai[e] = 16 * tile_i[t < NTILE ? t : 0] + r16; bj[e] = 16 * tile_j[t < NTILE ? t : 0] + r16;
+    acc[e] = (f64x4)(0.0);
+  }
+  const int nmine = wave < NTILE ? (NTILE - wave + 3) >> 2 : 0;
+  int64_t chunk = (N + gridDim.x - 1) / gridDim.x;
+  chunk = (chunk + 31) & ~(int64_t)31;
+  const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
+  for (int64_t s0 = lo; s0 < hi; s0 += 32) {
+    const int ks = (int)((hi - s0 < 32) ? hi - s0 : 32);
+    for (int i = tid; i < ks * n; i += 256) so[i] = fmin(fmax(obs[s0 * n + i], -10.0), 10.0) / 10.0;
+    if (tid < 32) stau[tid] = tid < ks ? (double)tpos[s0 + tid] / 1000.0 : 0.0;
+    __syncthreads();
+    for (int i = tid; i < 32 * 16 * T; i += 256) {
+      const int k = i / (16 * T), c = i - k * 16 * T;
+      double v = 0.0;
+      if (k < ks) { if (c < F) v = feat_value(table[c], so + k * n, stau[k]); else if (c == F) v = y[s0 + k]; }
+      ft[k * FS + c] = v;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < 32; k0 += 4) {
+      const double* row = ft + (k0 + q) * FS;
+#pragma unroll
+      for (int e = 0; e < GM_TPW; ++e)
+        if (e < nmine) acc[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(row[ai[e]], row[bj[e]], acc[e], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  double* out = part + (size_t)blockIdx.x * FA * FA;
+#pragma unroll
+  for (int e = 0; e < GM_TPW; ++e) {
+    const int c = bj[e];                                   // = 16 tj + (lane & 15)
+    const int r0 = ai[e] - r16 + q;                        // 16 ti + (lane >> 4): register r holds row 4 r + (lane >> 4)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (e < nmine && r0 + 4 * r < FA && c < FA) out[(size_t)(r0 + 4 * r) * FA + c] = acc[e][r];
+  }
+}
+
+// G[r][c] = sum_z part[z][min][max]  (upper-triangle tiles of TS x TS were computed; mirror)
+__global__ void k_bl_gram_reduce(const double* __restrict__ part, int Z, int FA, double* __restrict__ G, int TS) {
   const int64_t tot = (int64_t)FA * FA;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
     int r = (int)(i / FA), c = (int)(i - (int64_t)r * FA);
     int rr = r, cc = c;
-    if (r / GT > c / GT) { rr = c; cc = r; }       // tile (bi > bj) was not computed: take the mirrored element
+    if (r / TS > c / TS) { rr = c; cc = r; }       // tile (bi > bj) was not computed: take the mirrored element
     double a = 0.0;
     for (int z = 0; z < Z; ++z) a += part[(size_t)z * tot + (size_t)rr * FA + cc];
     G[i] = a;

@@ -330,17 +330,35 @@ int mjx_bl_gram(int kind, const double* obs, const int32_t* tpos, const double* 
   FeatTableCache* ft;
   if (int rc = get_feat_table(kind, n, &ft)) return rc;
   const int F = ft->F, FA = F + 1, nbt = (FA + GT - 1) / GT, npairs = nbt * (nbt + 1) / 2;
+  static thread_local Scratch part;
+  const int T16 = (FA + 15) / 16;
+  const char* no_mfma = getenv("MJX_GRAM_FMA");
+  if (T16 <= GM_TMAX && !(no_mfma && no_mfma[0] == '1')) {
+    // fp64 matrix cores: one persistent workgroup per sample range, all features generated once per chunk
+    int Z = (int)((N + 2047) / 2048);
+    if (Z > 512) Z = 512;
+    if (Z < 1) Z = 1;
+    if (int rc = get_scratch(part, (size_t)Z * FA * FA * sizeof(double))) return rc;
+    HIPCHK(hipMemsetAsync(part.p, 0, (size_t)Z * FA * FA * sizeof(double), (hipStream_t)stream));
+    const size_t lds = ((size_t)32 * n + (size_t)32 * 16 * (T16 | 1)) * sizeof(double);
+    static thread_local bool attr_set = false;
+    if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_bl_gram_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_set = true; }
+    if (lds > 64 * 1024) return fail(MJX_ERR_UNSUPPORTED, "Gram kernel LDS staging");
+    hipLaunchKernelGGL(k_bl_gram_mfma, dim3(Z), dim3(256), lds, (hipStream_t)stream, ft->dev, F, n, obs, tpos, y, N, (double*)part.p);
+    hipLaunchKernelGGL(k_bl_gram_reduce, dim3(LayerwiseWS::ew_grid((int64_t)FA * FA)), dim3(256), 0, (hipStream_t)stream, (const double*)part.p, Z, FA, G, 16);
+    HIPCHK(hipGetLastError());
+    return MJX_OK;
+  }
   int Z = (int)((N + 4095) / 4096);
   int maxz = (2048 + npairs - 1) / npairs;
   if (Z > maxz) Z = maxz;
   if (Z < 1) Z = 1;
-  static thread_local Scratch part;
   if (int rc = get_scratch(part, (size_t)Z * FA * FA * sizeof(double))) return rc;
   HIPCHK(hipMemsetAsync(part.p, 0, (size_t)Z * FA * FA * sizeof(double), (hipStream_t)stream));
   size_t lds = ((size_t)GKS * n + 2 * (size_t)GKS * (GT + 1)) * sizeof(double);
   if (lds > 64 * 1024) return fail(MJX_ERR_UNSUPPORTED, "obs dim too large for the Gram kernel's LDS staging");
   hipLaunchKernelGGL(k_bl_gram, dim3(npairs, Z), dim3(256), lds, (hipStream_t)stream, nbt, ft->dev, F, n, obs, tpos, y, N, (double*)part.p);
-  hipLaunchKernelGGL(k_bl_gram_reduce, dim3(LayerwiseWS::ew_grid((int64_t)FA * FA)), dim3(256), 0, (hipStream_t)stream, (const double*)part.p, Z, FA, G);
+  hipLaunchKernelGGL(k_bl_gram_reduce, dim3(LayerwiseWS::ew_grid((int64_t)FA * FA)), dim3(256), 0, (hipStream_t)stream, (const double*)part.p, Z, FA, G, GT);
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }

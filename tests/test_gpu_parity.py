@@ -317,6 +317,32 @@ def test_whole_update_other_variants_vs_oracle(n, m, hid, N):
     eng.close()
 
 
+@pytest.mark.parametrize("kind,n,N", [(2, 17, 100003), (2, 6, 777), (1, 39, 5000), (2, 11, 31), (2, 16, 4096), (1, 3, 1)])
+def test_gram_on_matrix_cores_equals_fma_gram(kind, n, N, monkeypatch):
+    """mjx_bl_gram has two kernels: fp64 MFMA tiles for up to 176 augmented features, fp64 FMA register tiles beyond.
+    Same normal equations (to fp64 summation-order noise), symmetric, for ragged sample counts and partial tiles."""
+    import torch
+    from mjrl_amd import _lib
+    from mjrl_amd._lib import check, ptr
+    lib = _lib.load()
+    rng = np.random.RandomState(n * 7 + N % 1000)
+    obs = torch.from_numpy(rng.randn(N, n) * 4.0).cuda()          # (some entries beyond the +-10 clip)
+    tpos = torch.from_numpy((np.arange(N) % 1000).astype(np.int32)).cuda()
+    y = torch.from_numpy(rng.randn(N)).cuda()
+    F = n + 5 if kind == 1 else n + n * (n + 1) // 2 + 5
+    FA = F + 1
+    out = []
+    for fma in ("0", "1"):
+        monkeypatch.setenv("MJX_GRAM_FMA", fma)
+        G = torch.zeros(FA * FA, dtype=torch.float64).cuda()
+        check(lib.mjx_bl_gram(kind, ptr(obs), ptr(tpos), ptr(y), N, n, ptr(G), None))
+        torch.cuda.synchronize()
+        out.append(G.cpu().numpy().reshape(FA, FA))
+    a, b = out
+    assert np.array_equal(a, a.T)
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+
+
 def test_fvp_properties_full_size():
     """BASELINE size (1M x 17, 64x64): size-independent properties of the Fisher-vector product --
     linearity, symmetry, positive semi-definiteness, and fused == layer-wise."""
