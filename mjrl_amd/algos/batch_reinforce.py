@@ -55,19 +55,25 @@ class BatchREINFORCE:
         self._push_policy()
         self.engine.set_batch(observations, actions, advantages)
 
-    # ------------------------------------------------------------------ operators (host ndarrays in, python / ndarray out)
+    # ------------------------------------------------------------------ operators (host ndarrays in; same return types as the reference)
+    def _scalar(self, v):
+        """a 0-dim CPU tensor, like the reference's torch.mean(...) results (its callers unwrap them with
+        ``.data.numpy().ravel()[0]``, batch_reinforce.py:139, npg_cg.py:111); float(x) works as well.  fp64: the device
+        sums are fp64, nothing is rounded on the way out."""
+        return self.engine.torch.tensor(float(v), dtype=self.engine.torch.float64)
+
     def CPI_surrogate(self, observations, actions, advantages):
         """mean(LR * adv) -- batch_reinforce.py:40-46."""
         self._bind(observations, actions, advantages)
-        return self.engine.eval_surr_kl()[0]
+        return self._scalar(self.engine.eval_surr_kl()[0])
 
     def kl_old_new(self, observations, actions):
         """mean KL(new || old) -- batch_reinforce.py:48-52."""
         self._bind(observations, actions, np.zeros(len(observations), np.float32))
-        return self.engine.eval_surr_kl()[1]
+        return self._scalar(self.engine.eval_surr_kl()[1])
 
     def flat_vpg(self, observations, actions, advantages):
-        """flattened gradient of the CPI surrogate -- batch_reinforce.py:54-58."""
+        """flattened gradient of the CPI surrogate as a float32 ndarray -- batch_reinforce.py:54-58."""
         self._bind(observations, actions, advantages)
         return self.engine.surr_vpg()[0].cpu().numpy()
 
@@ -103,6 +109,8 @@ class BatchREINFORCE:
             self.logger.log_kv('VF_error_after', error_after)
         else:
             self.baseline.fit(paths)
+        from ..utils.ingest import drop_shared_batch
+        drop_shared_batch()                     # the iteration's one upload served predict, update and fit; nothing may outlive it
         return eval_statistics
 
     # ------------------------------------------------------------------ vanilla PG update
@@ -167,6 +175,21 @@ class BatchREINFORCE:
             self._stage_pool = ThreadPoolExecutor(max_workers=1)
         return self._stage_pool
 
+    def _stage_on_callers_stream(self):
+        """eng.stage_paths wrapped for a helper thread: torch's current device / stream are thread-local, so the worker
+        adopts the CALLER's (the stager orders the caller's stream after its side-stream transfers, and page-locked
+        allocations must not initialise a context on GPU 0 from a rank that owns another GPU)."""
+        eng = self.engine
+        torch, dev = eng.torch, eng.device
+        if dev.type != "cuda":
+            return eng.stage_paths
+        cur = torch.cuda.current_stream(dev)
+
+        def run(paths, keys):
+            with torch.cuda.device(dev), torch.cuda.stream(cur):
+                return eng.stage_paths(paths, keys)
+        return run
+
     def _process_and_bind(self, paths):
         """process_paths + upload + binding for train_from_paths: the (whitened, fp64) advantages are assembled on the
         host like the reference does, observations / actions go path by path through the engine's page-locked
@@ -175,7 +198,7 @@ class BatchREINFORCE:
         # the gather / upload of observations and actions runs on a helper thread (native memcpy threads + asynchronous
         # copies, no GIL) while this thread assembles the advantage vector and the path statistics
         eng = self.engine
-        fut = self._staging_pool().submit(eng.stage_paths, paths, ("observations", "actions"))
+        fut = self._staging_pool().submit(self._stage_on_callers_stream(), paths, ("observations", "actions"))
         try:
             advantages, base_stats, self.running_score = self._advantages_and_statistics(paths)
         finally:
@@ -196,6 +219,21 @@ class BatchREINFORCE:
         q = torch.tensor([((x - mean) ** 2).sum()], dtype=torch.float64, device=self.engine.device)
         d.all_reduce(q)
         return mean, float(np.sqrt(q.item() / s[1].item()))
+
+    def _global_column_mean_std(self, X):
+        """column-wise population mean / std of a (rows, n) block that is sharded over the ranks (the observation
+        statistics of npg_cg.py:104-105 must be the same on every rank, or the ranks' transforms drift apart)"""
+        d = _dist()
+        if d is None:
+            return np.mean(X, axis=0), np.std(X, axis=0)
+        torch = self.engine.torch
+        s = torch.from_numpy(np.concatenate([X.sum(axis=0, dtype=np.float64), [float(X.shape[0])]])).to(self.engine.device)
+        d.all_reduce(s)
+        cnt = float(s[-1].item())
+        mean = s[:-1].cpu().numpy() / cnt
+        q = torch.from_numpy(((X - mean) ** 2).sum(axis=0, dtype=np.float64)).to(self.engine.device)
+        d.all_reduce(q)
+        return mean, np.sqrt(q.cpu().numpy() / cnt)
 
     def log_rollout_statistics(self, paths):
         """batch_reinforce.py:200-214"""

@@ -73,32 +73,37 @@ class NPG(BatchREINFORCE):
 
     def _cg_subsampled(self, b, iters, damping):
         """hvp_sample_frac < 0.99: a fresh with-replacement row sample per product, drawn from
-        NumPy's global RNG exactly like npg_cg.py:65-69."""
+        NumPy's global RNG exactly like npg_cg.py:65-69.  Rows are drawn from the rows that are BOUND (DAPG binds the
+        on-policy prefix of its [on-policy ; demonstrations] block before the solve, dapg.py:103), and the engine's
+        block / prefix binding is restored afterwards."""
         eng, be, torch = self.engine, self.engine.backend, self.engine.torch
-        full = (eng.obs, eng.act, eng.adv, eng.N_local, eng.N_global)
-        Nl, Ng = full[3], full[4]
-        k = int(self.hvp_subsample * Nl)
+        Nb = eng.N_bound
+        k = int(self.hvp_subsample * Nb)
         from ..engine import _dist
         d = _dist()
+        kg = eng.global_count(k)
         be.cg_init(b)
-        for _ in range(int(iters)):
-            idx = torch.from_numpy(np.random.choice(Nl, size=k)).to(eng.device)
-            sub = full[0].index_select(0, idx)
-            be.bind_batch(sub, None, None, k, eng.global_count(k))
-            be.fvp_of_cg_direction(eng.Ap)
-            if d is not None:
-                d.all_reduce(eng.Ap)
-            be.cg_step(eng.Ap, damping, 1e-10)
-        be.cg_finish(b, eng.x, eng.bdotx)
-        be.bind_batch(full[0], full[1], full[2], Nl, Ng)       # back to the whole shard
+        try:
+            for _ in range(int(iters)):
+                idx = torch.from_numpy(np.random.choice(Nb, size=k)).to(eng.device)
+                sub = eng.obs.index_select(0, idx)
+                be.bind_batch(sub, None, None, k, kg)
+                be.fvp_of_cg_direction(eng.Ap)
+                if d is not None:
+                    d.all_reduce(eng.Ap)
+                be.cg_step(eng.Ap, damping, 1e-10)
+            be.cg_finish(b, eng.x, eng.bdotx)
+        finally:
+            eng.rebind()                                       # back to the whole shard (and DAPG's on-policy prefix)
         return eng.x, float(eng.bdotx.item())
 
     # ------------------------------------------------------------------ update
     def _normalize_inputs(self, observations):
         """running input normalisation, npg_cg.py:101-107 (touches only policy.model)."""
         m = self.policy.model
-        shift = self.input_normalization * m.in_shift + (1 - self.input_normalization) * np.mean(observations, axis=0)
-        scale = self.input_normalization * m.in_scale + (1 - self.input_normalization) * np.std(observations, axis=0)
+        mean, std = self._global_column_mean_std(observations)
+        shift = self.input_normalization * m.in_shift + (1 - self.input_normalization) * mean
+        scale = self.input_normalization * m.in_scale + (1 - self.input_normalization) * std
         m.set_transformations(shift, scale, m.out_shift, m.out_scale)
 
     def _log_update(self, paths, alpha, n_step_size, t_gLL, t_FIM, kl_dist, surr_before, surr_after):

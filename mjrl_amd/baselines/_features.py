@@ -43,11 +43,13 @@ class _StagerBackend:
 
 
 class DeviceBlock:
-    def __init__(self, paths, inp):
+    def __init__(self, paths, inp, shared=True):
+        """shared=False (single-path predictions, throw-away path lists): a plain upload that leaves the iteration's
+        shared batch registered."""
         self.torch, self.dev = torch_dev()
         self.lib = _lib.load()
         first = paths[0]["observations"] if inp != 'env_features' else None
-        if first is not None and first.ndim == 2 and first.dtype == np.float64:
+        if shared and first is not None and first.ndim == 2 and first.dtype == np.float64:
             # the fp64 observation block of this batch: uploaded once per process (page-locked staging), shared with
             # the policy update and the other baseline call of the iteration (utils/ingest.stage_shared)
             from ..utils.ingest import stage_shared

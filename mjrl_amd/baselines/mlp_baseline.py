@@ -73,10 +73,10 @@ class MLPBaseline:
             error_after = np.sum(errors ** 2) / (np.sum(returns ** 2) + 1e-8)
             return error_before, error_after
 
-    def predict_batch(self, paths):
-        blk = DeviceBlock(paths, self.inp)
+    def predict_batch(self, paths, shared=True):
+        blk = DeviceBlock(paths, self.inp, shared)
         p = blk.torch.from_numpy(self.params).to(blk.dev)
         return self._forward(blk, blk.mlp_features(), p).cpu().numpy()
 
     def predict(self, path):
-        return self.predict_batch([path])
+        return self.predict_batch([path], shared=False)

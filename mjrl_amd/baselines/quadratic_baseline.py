@@ -47,17 +47,17 @@ class _RidgeBaseline:
             error_after = np.sum((returns - predictions) ** 2) / np.sum(returns ** 2)
             return error_before, error_after
 
-    def predict_batch(self, paths):
+    def predict_batch(self, paths, shared=True):
         """concatenated predictions for a list of paths in one device pass"""
         N = sum(len(p["rewards"]) for p in paths)
         if self._coeffs is None:
             return np.zeros(N)
-        return DeviceBlock(paths, self.inp).predict_linear(self._kind, self._coeffs)
+        return DeviceBlock(paths, self.inp, shared).predict_linear(self._kind, self._coeffs)
 
     def predict(self, path):
         if self._coeffs is None:
             return np.zeros(len(path["rewards"]))
-        return self.predict_batch([path])
+        return self.predict_batch([path], shared=False)
 
 
 class QuadraticBaseline(_RidgeBaseline):

@@ -23,7 +23,7 @@
 
 namespace mjx {
 
-enum { EPI_STORE = 0, EPI_BIAS_TANH, EPI_BIAS_AFFINE, EPI_TANGENT, EPI_BACK, EPI_BIAS, EPI_BIAS_RELU, EPI_BACK_RELU, EPI_RBACK };
+enum { EPI_STORE = 0, EPI_BIAS_TANH, EPI_BIAS_AFFINE, EPI_TANGENT, EPI_BACK, EPI_BIAS, EPI_BIAS_RELU, EPI_BACK_RELU, EPI_RBACK, EPI_FVP_HEAD };
 
 struct GemmArgs {
   int M, N, npairs;
@@ -32,11 +32,13 @@ struct GemmArgs {
   const float* B[2]; int64_t b_cs[2], b_ks[2];   // B(k,j) = B[j*b_cs + k*b_ks]
   float* C; int64_t ldc;                          // C(i,j) = C[i*ldc + j*c_cs] (+ z*c_zs for split-K); c_cs == 0 means 1
   int64_t c_zs, c_cs;
-  float* colsum;                                  // optional [gridDim.y][N]: per-block column sums of the stored values (bias gradients)
+  float* colsum;                                  // optional [gridDim.y][cs_ld]: per-block column sums of the stored values (bias gradients)
+  int64_t cs_ld;                                  // row stride of colsum (0: N)
   const float* bias;                              // per column
   const float* aux; int64_t ld_aux;               // activation for the (1 - y^2) factor
   const float* aux2; const float* aux3;           // EPI_RBACK: tangent activation t and the pre-activation cotangent
   const float* osc; const float* osh;             // per-column affine (EPI_BIAS_AFFINE)
+  const float* ls; float inv_N;                   // EPI_FVP_HEAD: log_std per column, 1 / N_global
   int epi;
 };
 
@@ -53,22 +55,25 @@ constexpr int GBN = 128, GBK = 32, GLD = GBK + 4;
 // global memory (register-staged) before the MFMAs of tile k.  blockIdx.z splits the K range of pair 0 (wgrad: K = samples).
 // BN = 128: 2x2 waves of 64x64; BN = 32 (narrow outputs: action heads, value heads): 4x1 waves of 32x32, so a
 // 17-column product is padded to 32 instead of 128 columns.
-// threads per workgroup: 8 waves of 32 x 64 sub-tiles at BN = 128 (one workgroup per CU, two waves per SIMD, 169 VGPRs, no
-// spills; 4 waves of 64 x 64 needed all 256 VGPRs and spilled in the k-loop), 4 waves of 32 x 32 at BN = 32
+// threads per workgroup: 8 waves at BN >= 128 (one workgroup per CU, two waves per SIMD), 4 waves of 32 x 32 at BN = 32.
+// Tile shapes (BM x BN, per-wave sub-tile, accumulator registers):
+//   128 x 128   32 x 64    32     the round-1 shape: every operand is re-read once per 128 output columns / rows
+//   128 x 256   64 x 64    64     sample-major products with >= 256 output columns (hidden layers of 256 / 512 units):
+//                                 the activation operand is read ONCE per 256 columns -- these GEMMs sit at the ridge of
+//                                 the roofline when their operands stream from HBM, so halving the re-reads
+//                                 is worth more than occupancy
 template <int BN> constexpr int gemm_threads() { return BN >= 128 ? 512 : 256; }
-// rows per workgroup tile (256 x 128 tiles -- 8 waves of 64 x 64 -- were measured 3-4 % slower than 128 x 128 at cfg4 / cfg5)
-template <int BN> constexpr int gemm_bm() { return 128; }
 
-template <int BN>
+template <int BM, int BN>
 __global__ __launch_bounds__(gemm_threads<BN>(), 2) void k_gemm(GemmArgs g) {      // (second argument: waves per SIMD; 4 would need <= 128 VGPRs: spills, measured slower)
-  constexpr int NTH = gemm_threads<BN>(), BM = gemm_bm<BN>();
+  constexpr int NTH = gemm_threads<BN>();
   constexpr int WN = BN / 64 > 0 ? BN / 64 : 1;   // waves along N
   constexpr int WMc = (NTH / 64) / WN;            // waves along M
   constexpr int TM = BM / WMc, TN = BN / WN;     // per-wave tile
   constexpr int MT = TM / 32, NT = TN / 32;
-  // two buffers per operand (dynamic LDS: 72 KB at BN = 128, two workgroups per CU): tile k + 1 is stored while tile k is
-  // being multiplied, ONE barrier per k-tile
-  constexpr int ASZ = BM * GLD, BSZ = (BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4);
+  // two buffers per operand (dynamic LDS: 72 KB at 128 x 128, 108 KB at 128 x 256, 144 KB at 256 x 256): tile k + 1 is
+  // stored while tile k is being multiplied, ONE barrier per k-tile
+  constexpr int ASZ = (BM * GLD > GBK * (BM + 4)) ? BM * GLD : GBK * (BM + 4), BSZ = (BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4);
   extern __shared__ __attribute__((aligned(16))) float gsm[];
   float* As = gsm;                       // [2][ASZ]
   float* Bs = gsm + 2 * ASZ;             // [2][BSZ]
@@ -219,7 +224,8 @@ __global__ __launch_bounds__(gemm_threads<BN>(), 2) void k_gemm(GemmArgs g) {   
   float* Cz = g.C + (int64_t)blockIdx.z * g.c_zs;
   auto epilogue = [&](auto tag) {
     constexpr int EPI = decltype(tag)::value;
-    constexpr bool USE_BIAS = EPI == EPI_BIAS_TANH || EPI == EPI_BIAS_AFFINE || EPI == EPI_TANGENT || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU;
+    constexpr bool USE_BIAS = EPI == EPI_BIAS_TANH || EPI == EPI_BIAS_AFFINE || EPI == EPI_TANGENT || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU ||
+                              EPI == EPI_FVP_HEAD;
     constexpr bool USE_AUX = EPI == EPI_TANGENT || EPI == EPI_BACK || EPI == EPI_RBACK || EPI == EPI_BACK_RELU;
     constexpr bool CSUM = EPI == EPI_BACK || EPI == EPI_BACK_RELU;      // launches that may carry g.colsum
     const int64_t ccs = g.c_cs ? g.c_cs : 1;
@@ -234,8 +240,10 @@ __global__ __launch_bounds__(gemm_threads<BN>(), 2) void k_gemm(GemmArgs g) {   
         const bool cok = col < g.N;
         const int colc = cok ? col : 0;
         const float bias = USE_BIAS ? g.bias[colc] : 0.f;
-        const float osc = (EPI == EPI_BIAS_AFFINE) ? g.osc[colc] : 1.f;
+        const float osc = (EPI == EPI_BIAS_AFFINE || EPI == EPI_FVP_HEAD) ? g.osc[colc] : 1.f;
         const float osh = (EPI == EPI_BIAS_AFFINE && g.osh) ? g.osh[colc] : 0.f;
+        float dk = 0.f;                           // EPI_FVP_HEAD: D = 2 / (2 sigma^2 + 1e-8) of the column's action
+        if (EPI == EPI_FVP_HEAD) { const float sg = expf(g.ls[colc]); dk = 2.0f / (2.0f * sg * sg + 1e-8f); }
         const int rbase = m0 + wm * TM + mt * 32;
         float y[16], t2[16], pre[16];
         if (USE_AUX) {
@@ -253,6 +261,7 @@ __global__ __launch_bounds__(gemm_threads<BN>(), 2) void k_gemm(GemmArgs g) {   
           float v = acc[mt][nt][r];
           if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
           else if (EPI == EPI_BIAS_AFFINE) v = (v + bias) * osc + osh;
+          else if (EPI == EPI_FVP_HEAD) { v = (v + bias) * osc; v = osc * (dk * v * g.inv_N); }     // the tangent of mu, then d3 = out_scale D mudot / N
           else if (EPI == EPI_TANGENT) v = (v + bias) * fmaf(-y[r], y[r], 1.0f);
           else if (EPI == EPI_BACK) v = v * fmaf(-y[r], y[r], 1.0f);
           else if (EPI == EPI_RBACK) v = v * fmaf(-y[r], y[r], 1.0f) - 2.0f * y[r] * t2[r] * pre[r];   // Pearlmutter R-backward through tanh
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(gemm_threads<BN>(), 2) void k_gemm(GemmArgs g) {   
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < WMc; ++w) t += As[w * BN + tid];
-        g.colsum[(int64_t)blockIdx.y * g.N + n0 + tid] = t;
+        g.colsum[(int64_t)blockIdx.y * (g.cs_ld ? g.cs_ld : g.N) + n0 + tid] = t;
       }
     }
   };
@@ -290,6 +299,7 @@ __global__ __launch_bounds__(gemm_threads<BN>(), 2) void k_gemm(GemmArgs g) {   
     case EPI_BIAS: epilogue(std::integral_constant<int, EPI_BIAS>{}); break;
     case EPI_BIAS_RELU: epilogue(std::integral_constant<int, EPI_BIAS_RELU>{}); break;
     case EPI_BACK_RELU: epilogue(std::integral_constant<int, EPI_BACK_RELU>{}); break;
+    case EPI_FVP_HEAD: epilogue(std::integral_constant<int, EPI_FVP_HEAD>{}); break;
     default: epilogue(std::integral_constant<int, EPI_STORE>{}); break;
   }
 }
@@ -575,6 +585,32 @@ __global__ void k_reduce_split(const float* __restrict__ part, int Z, int64_t cn
   }
 }
 
+// the same with 16-byte loads and the splits spread over the 4 waves of a workgroup (cnt % 4 == 0): thread (w, c) sums
+// slabs w, w + 4, ... of column group c in fp64, the four partial sums are added in a fixed order.  One coalesced 1 KB
+// read per wave and slab; Z / 4 independent loads per thread (the scalar kernel above walks all Z slabs with one thread
+// and ran at ~130 GB/s: 27 % of a cfg4 Fisher-vector product in round 1).
+__global__ __launch_bounds__(256) void k_reduce_split4(const float* __restrict__ part, int Z, int64_t cnt4, float* __restrict__ out) {
+  __shared__ double sh[3][64][4];
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + c;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (i < cnt4) {
+    const f32x4* __restrict__ p = (const f32x4*)part + i;
+#pragma unroll 4
+    for (int z = w; z < Z; z += 4) {
+      const f32x4 v = p[(int64_t)z * cnt4];
+      a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+    }
+  }
+  if (w > 0) { sh[w - 1][c][0] = a0; sh[w - 1][c][1] = a1; sh[w - 1][c][2] = a2; sh[w - 1][c][3] = a3; }
+  __syncthreads();
+  if (w == 0 && i < cnt4) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a0 += sh[k][c][0]; a1 += sh[k][c][1]; a2 += sh[k][c][2]; a3 += sh[k][c][3]; }
+    ((f32x4*)out)[i] = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
+  }
+}
+
 __global__ void k_reduce_head(const double* __restrict__ part, int G, int m, int mode, double* __restrict__ scal, float* __restrict__ gls) {
   __shared__ double sh[17];
   for (int k = 0; k < 2 + ((mode == 0) ? m : 0); ++k) {
@@ -656,25 +692,74 @@ struct LayerwiseWS {
     return 0;
   }
 
-  template <int BN>
+  template <int BM, int BN>
   static constexpr size_t gemm_lds_bytes() {
-    return 2 * sizeof(float) * (size_t)(gemm_bm<BN>() * GLD + ((BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4)));
+    return 2 * sizeof(float) * (size_t)(((BM * GLD > GBK * (BM + 4)) ? BM * GLD : GBK * (BM + 4)) + ((BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4)));
   }
-  static int bm_of(int ncols) { return ncols <= 32 ? gemm_bm<32>() : gemm_bm<GBN>(); }     // row-block height launch_gemm will use
-  static void launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
-    static const bool attr_set = [] {                 // double-buffered operand tiles: 72 KB of dynamic LDS at BN = 128
-      (void)hipFuncSetAttribute((const void*)k_gemm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<32>());
-      (void)hipFuncSetAttribute((const void*)k_gemm<GBN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<GBN>());
+  // MJX_LW_TILES=0: the round-1 tile shapes only (128 x 128 / 128 x 32) -- A/B measurements; default: wide tiles
+  static bool wide_tiles() {
+    static const bool w = [] { const char* e = getenv("MJX_LW_TILES"); return !(e && e[0] == '0'); }();
+    return w;
+  }
+  // rows per workgroup tile (256-row tiles were tried for the weight gradients: 256 x 256 needs 128 accumulator + 80 operand
+  // registers per lane and spills 874 VGPRs at two waves per SIMD; 256 x 128 buys nothing over 128 x 256)
+  static int bm_of(int, bool) { return 128; }
+  // column blocks a launch_gemm call covers N columns with
+  static int col_blocks(int N) {
+    if (N <= 32) return 1;
+    if (!wide_tiles()) return (N + 127) / 128;
+    const int rem = N % 256;
+    return N / 256 + (rem ? 1 : 0);
+  }
+  template <int BM, int BN>
+  static void launch_tile(const GemmArgs& g, int splits, hipStream_t st) {
+    void (*const kern)(GemmArgs) = k_gemm<BM, BN>;
+    static const bool attr_set = [kern] {             // double-buffered operand tiles: dynamic LDS beyond the 64 KB default
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<BM, BN>());
       return true;
     }();
     (void)attr_set;
-    if (g.N <= 32) {
-      dim3 grid(1, (g.M + gemm_bm<32>() - 1) / gemm_bm<32>(), splits);
-      hipLaunchKernelGGL(k_gemm<32>, grid, dim3(gemm_threads<32>()), gemm_lds_bytes<32>(), st, g);
-    } else {
-      dim3 grid((g.N + GBN - 1) / GBN, (g.M + gemm_bm<GBN>() - 1) / gemm_bm<GBN>(), splits);
-      hipLaunchKernelGGL(k_gemm<GBN>, grid, dim3(gemm_threads<GBN>()), gemm_lds_bytes<GBN>(), st, g);
-    }
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
+    constexpr size_t lds = gemm_lds_bytes<BM, BN>();
+    constexpr int nth = gemm_threads<BN>();
+    hipLaunchKernelGGL(kern, grid, dim3(nth), lds, st, g);
+  }
+  // the launch restricted to columns [j0, j0 + ncols)
+  static GemmArgs col_slice(const GemmArgs& g, int j0, int ncols) {
+    GemmArgs h = g;
+    if (!h.cs_ld) h.cs_ld = g.N;
+    h.N = ncols;
+    for (int p = 0; p < g.npairs; ++p) h.B[p] = g.B[p] + (int64_t)j0 * g.b_cs[p];
+    h.C = g.C + (int64_t)j0 * (g.c_cs ? g.c_cs : 1);
+    if (g.colsum) h.colsum = g.colsum + j0;
+    if (g.bias) h.bias = g.bias + j0;
+    if (g.aux) h.aux = g.aux + j0;
+    if (g.aux2) h.aux2 = g.aux2 + j0;
+    if (g.aux3) h.aux3 = g.aux3 + j0;
+    if (g.osc) h.osc = g.osc + j0;
+    if (g.osh) h.osh = g.osh + j0;
+    if (g.ls) h.ls = g.ls + j0;
+    return h;
+  }
+  // wgrad: the contraction runs over samples (split over blockIdx.z) and the M x N output is small
+  static void launch_gemm(const GemmArgs& g, int splits, hipStream_t st, bool wgrad = false) {
+    (void)wgrad;
+    if (g.N <= 32) { launch_tile<128, 32>(g, splits, st); return; }
+    if (!wide_tiles()) { launch_tile<128, 128>(g, splits, st); return; }
+    // 256-column blocks; a remainder of up to 128 columns gets its own 128-column launch (a half-empty 256-column
+    // block would spend matrix-core time on padding), a larger one rides in one more 256-column block
+    int n256 = (g.N / 256) * 256, rem = g.N - n256;
+    if (rem > 128) { n256 = g.N; rem = 0; }
+    if (n256 == g.N) { launch_tile<128, 256>(g, splits, st); return; }
+    if (n256) launch_tile<128, 256>(col_slice(g, 0, n256), splits, st);
+    launch_tile<128, 128>(col_slice(g, n256, rem), splits, st);
+  }
+  // sum of `splits` partial slabs of cnt floats (fixed order, fp64 accumulation)
+  static void reduce_split(const float* part, int splits, int64_t cnt, float* out, hipStream_t st) {
+    if ((cnt & 3) == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0 && wide_tiles())
+      hipLaunchKernelGGL(k_reduce_split4, dim3((unsigned)((cnt / 4 + 63) / 64)), dim3(256), 0, st, part, splits, cnt / 4, out);
+    else
+      hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid(cnt)), dim3(256), 0, st, part, splits, cnt, out);
   }
   static int ew_grid(int64_t cnt) { int64_t g = (cnt + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 
@@ -717,8 +802,9 @@ struct LayerwiseWS {
       const float* in = (l == 0) ? Xn : H[l - 1];
       // weight gradient: gW[ho x hi] = delta^T (ho x N) * in (N x hi), split over samples
       const bool narrow = ho <= 32;                 // action head: compute gW^T (hi x ho) so the padding goes to 32 columns, not 128 rows
-      const int rowblocks = (int)((N + bm_of(hi_) - 1) / bm_of(hi_));      // of the delta GEMM below (its column sums)
-      int tiles = narrow ? (hi_ + bm_of(ho) - 1) / bm_of(ho) : ((ho + bm_of(hi_) - 1) / bm_of(hi_)) * ((hi_ + GBN - 1) / GBN);
+      const int rowblocks = (int)((N + 127) / 128);      // of the delta GEMM below (its column sums; sample-major launches use 128-row tiles)
+      const int tbm = (narrow || hi_ <= 32) ? 128 : bm_of(ho, true);
+      int tiles = narrow ? (hi_ + tbm - 1) / tbm : ((ho + tbm - 1) / tbm) * col_blocks(hi_);
       int splits = (int)((N + 2047) / 2048);
       int maxs = (1024 + tiles - 1) / tiles;
       if (splits > maxs) splits = maxs;
@@ -741,9 +827,8 @@ struct LayerwiseWS {
       // (a single split / row block -- minibatches -- writes the gradient blocks directly: no reduction launches)
       g.C = (splits == 1) ? grad + oW[l] : part; g.c_zs = (int64_t)ho * hi_;
       g.epi = EPI_STORE;
-      launch_gemm(g, splits, st);
-      if (splits > 1)
-        hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid((int64_t)ho * hi_)), dim3(256), 0, st, part, splits, (int64_t)ho * hi_, grad + oW[l]);
+      launch_gemm(g, splits, st, true);
+      if (splits > 1) reduce_split(part, splits, (int64_t)ho * hi_, grad + oW[l], st);
       float* bpart = part + (int64_t)splits * ho * hi_;
       float* cpart = bpart + (int64_t)csplits * ho;
       if (!bias_done) {
@@ -812,12 +897,12 @@ struct LayerwiseWS {
       }
       g.bias = v + ob[l];
       g.c_zs = 0;
-      if (last) { g.C = d3; g.ldc = m; g.epi = EPI_BIAS_AFFINE; g.osc = tr + 2 * n + m; g.osh = nullptr; }
+      // the output layer's tangent goes straight to d3 = out_scale D mudot / N in the GEMM epilogue (no pass over N x m)
+      if (last) { g.C = d3; g.ldc = m; g.epi = EPI_FVP_HEAD; g.osc = tr + 2 * n + m; g.ls = theta + oS; g.inv_N = (float)(1.0 / (double)Ng); }
       else { g.C = T[l]; g.ldc = sizes[l + 1]; g.epi = EPI_TANGENT; g.aux = H[l]; g.ld_aux = sizes[l + 1]; }
       launch_gemm(g, 1, st);
       tin = last ? nullptr : T[l];
     }
-    hipLaunchKernelGGL(k_fvp_head, dim3(ew_grid(N * m)), dim3(256), 0, st, d3, N, m, theta + oS, tr + 2 * n + m, (float)(1.0 / (double)Ng));
     hipLaunchKernelGGL(k_fvp_logstd, dim3(1), dim3(64), 0, st, theta + oS, v + oS, m, (float)((double)N / (double)Ng), out + oS);
     return backward(theta, N, out, st);
   }
@@ -867,7 +952,8 @@ struct LayerwiseWS {
       const int ho = sizes[l + 1], hi_ = sizes[l];
       const float* in = (l == 0) ? Xn : H[l - 1];
       const float* tinl = (l == 0) ? nullptr : T[l - 1];
-      int tiles = ((ho + bm_of(hi_) - 1) / bm_of(hi_)) * ((hi_ + GBN - 1) / GBN);
+      const int tbm = hi_ <= 32 ? 128 : bm_of(ho, true);
+      int tiles = ((ho + tbm - 1) / tbm) * col_blocks(hi_);
       int splits = (int)((N + 2047) / 2048);
       int maxs = (1024 + tiles - 1) / tiles;
       if (splits > maxs) splits = maxs;
@@ -878,8 +964,8 @@ struct LayerwiseWS {
       g.K[0] = (int)N; g.A[0] = rdl; g.a_rs[0] = 1; g.a_ks[0] = ho; g.B[0] = in; g.b_cs[0] = 1; g.b_ks[0] = hi_;
       if (tinl) { g.K[1] = (int)N; g.A[1] = dl; g.a_rs[1] = 1; g.a_ks[1] = ho; g.B[1] = tinl; g.b_cs[1] = 1; g.b_ks[1] = hi_; }
       g.C = part; g.ldc = hi_; g.c_zs = (int64_t)ho * hi_; g.epi = EPI_STORE;
-      launch_gemm(g, splits, st);
-      hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid((int64_t)ho * hi_)), dim3(256), 0, st, part, splits, (int64_t)ho * hi_, out + oW[l]);
+      launch_gemm(g, splits, st, true);
+      reduce_split(part, splits, (int64_t)ho * hi_, out + oW[l], st);
       float* bpart = part + (int64_t)splits * ho * hi_;
       hipLaunchKernelGGL(k_colsum, dim3((ho + 63) / 64, splits), dim3(256), 0, st, rdl, N, ho, (int64_t)ho, bpart);
       hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid(ho)), dim3(256), 0, st, bpart, splits, (int64_t)ho, out + ob[l]);

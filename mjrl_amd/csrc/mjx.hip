@@ -97,10 +97,18 @@ int launch_fused(mjx_ctx* c, int mode, const FusedArgs& a, hipStream_t st) {
   else if (mode == MODE_FVP) k = cached ? k_fused<H1, H2, NT1, MP, MODE_FVP, false, NPC, true> : k_fused<H1, H2, NT1, MP, MODE_FVP, DBG, NPC>;
   else k = k_fused<H1, H2, NT1, MP, MODE_EVAL, false, NPC>;
   if (cached) mode = 3;
-  static thread_local const void* configured[4] = {nullptr, nullptr, nullptr, nullptr};
-  if (configured[mode] != (const void*)k) {
-    HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    configured[mode] = (const void*)k;
+  // the dynamic-LDS limit is a per-kernel, per-device attribute and FusedLayout::bytes() depends on the runtime observation
+  // count (the generic NPC = 0 instances serve many): remember the largest size configured per (device, kernel) and raise it
+  // whenever a context needs more
+  static thread_local std::vector<std::pair<std::pair<int, const void*>, size_t>> configured;
+  {
+    size_t* have = nullptr;
+    for (auto& e : configured) if (e.first.first == c->device && e.first.second == (const void*)k) have = &e.second;
+    if (!have) { configured.push_back({{c->device, (const void*)k}, 0}); have = &configured.back().second; }
+    if (*have < bytes) {
+      HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      *have = bytes;
+    }
   }
   hipLaunchKernelGGL(k, dim3(c->grid), dim3(256), bytes, st, a);
   HIPCHK(hipGetLastError());

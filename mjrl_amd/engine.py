@@ -141,7 +141,8 @@ class UpdateEngine:
         self.bdotx, self.alpha_dev = self.results[8:9], self.results[9:10]
         self._host_results = None                   # host copy of `results`, valid until the next launch that writes it
         self.obs = self.act = self.adv = None
-        self.N_local = self.N_global = 0
+        self.N_local = self.N_global = self.N_bound = 0
+        self._block = self._prefix = None
         self.old_is_new = True
         self._dbg = None
 
@@ -204,6 +205,9 @@ class UpdateEngine:
         self.adv = None if adv is None else self.to_device_f32(adv)
         self.N_local = int(self.obs.shape[0])
         self.N_global = self.global_count(self.N_local) if N_global is None else int(N_global)
+        self.N_bound = self.N_local                  # rows the kernels currently run over (bind_rows narrows it)
+        self._block = (self.obs, self.act, self.adv, self.N_local, int(self.N_global))
+        self._prefix = None
         self.backend.bind_batch(self.obs, self.act, self.adv, self.N_local, int(self.N_global))
 
     def stage_paths(self, paths, keys=("observations", "actions")):
@@ -222,7 +226,17 @@ class UpdateEngine:
             self.adv = self.to_device_f32(adv)
         if N_global is not None:
             self.N_global = int(N_global)
+        self.N_bound = int(rows)
+        self._prefix = (int(rows), int(self.N_global), self.adv)
         self.backend.bind_rows(int(rows), int(self.N_global), self.adv)
+
+    def rebind(self):
+        """bind the uploaded block again, then the row prefix that was in force (after a caller bound something else on
+        the backend, e.g. the row samples of hvp_sample_frac)."""
+        obs, act, adv, rows, Ng = self._block
+        self.backend.bind_batch(obs, act, adv, rows, Ng)
+        if self._prefix is not None:
+            self.backend.bind_rows(*self._prefix)
 
     # ------------------------------------------------------------------ kernels + collectives
     def surr_vpg(self, sync=True):

@@ -209,28 +209,54 @@ _SHARED = {}
 _SHARED_LOCK = threading.Lock()     # a prefetch thread and the main thread may ask for the same batch at the same time
 
 
-def _fingerprint(paths, key):
-    first, last = paths[0][key], paths[-1][key]
-    probe = (float(first.flat[0]), float(first.flat[-1]), float(last.flat[0]), float(last.flat[-1]))
-    return (id(paths), len(paths), id(first), id(last), first.shape, last.shape, probe)
+def _probe(a):
+    """a few values of one per-path array: catches in-place rewrites of arrays that are still the same objects"""
+    f = a.reshape(-1)
+    k = f.shape[0]
+    return (float(f[0]), float(f[k // 3]), float(f[(2 * k) // 3]), float(f[-1])) if k else ()
+
+
+def _same_batch(ent, paths, key):
+    """is `paths` the very batch `ent` uploaded?  Identity of the list AND of every per-path array, against STRONG
+    references the entry holds (an id() can be recycled once the objects are freed; a held object's cannot), plus a
+    few probe values per array against in-place edits."""
+    if ent["paths"] is not paths or len(ent["arrays"]) != len(paths):
+        return False
+    for a, p, pr in zip(ent["arrays"], paths, ent["probes"]):
+        b = p[key]
+        if a is not b or _probe(b) != pr:
+            return False
+    return True
 
 
 def stage_shared(backend, paths, keys):
     """-> dict key -> dict(f32=(N, w) fp32 device tensor, raw=(N, w) tensor in the paths' dtype).  Re-uses the upload
-    of the same `paths` list (same objects, same end-point values) made earlier in this process on this device."""
+    of the same `paths` list (the same list object holding the same array objects, see _same_batch) made earlier in
+    this process on this device; train_step drops the entries when its iteration ends (drop_shared_batch)."""
     dev = backend.device
     out = {}
     with _SHARED_LOCK:
         reg = _SHARED.setdefault((dev.type, dev.index), {})
         for k in keys:
-            fp = _fingerprint(paths, k)
             ent = reg.get(k)
-            if ent is None or ent["fp"] != fp:
+            if ent is None or ent.get("paths") is None or not _same_batch(ent, paths, k):
                 st = ent["stager"] if ent is not None else PathStager(backend)
                 f32 = st.stage(paths, (k,))[k]
-                ent = reg[k] = dict(fp=fp, stager=st, f32=f32, raw=st.raw(k))
+                arrays = [p[k] for p in paths]
+                ent = reg[k] = dict(stager=st, f32=f32, raw=st.raw(k), paths=paths, arrays=arrays,
+                                    probes=[_probe(a) for a in arrays])
             out[k] = dict(f32=ent["f32"], raw=ent["raw"])
     return out
+
+
+def drop_shared_batch():
+    """forget WHICH batch is staged (the stagers and their page-locked blocks stay): the next stage_shared uploads
+    again whatever it is given, and the host trajectories of the finished iteration are released."""
+    with _SHARED_LOCK:
+        for reg in _SHARED.values():
+            for ent in reg.values():
+                ent["paths"] = ent["arrays"] = ent["probes"] = None
+                ent["f32"] = ent["raw"] = None
 
 
 def drop_shared():

@@ -194,6 +194,28 @@ def npg_update(theta, obs, act, adv, n, m, hidden, tr=None, cg_iters=10, damping
     return out
 
 
+# DAPG.train_from_paths core  (mjrl/algos/dapg.py:58-121): gradient over [on-policy ; demonstrations] with the demo
+# "advantages" lam_0 * lam_1^iter and the 1e-2 / std rescaling (:62-70), rescaled by N_all / N (:97-98); Fisher,
+# surrogate and KL on the on-policy block only (:103-121); delta = 2 kl_dist (:111)
+def dapg_update(theta, obs, act, adv, demo_obs, demo_act, n, m, hidden, tr=None, cg_iters=10, damping=1e-4,
+                kl_dist=0.025, lam_0=1.0, lam_1=0.95, iter_count=0.0, min_log_std=-3.0):
+    """adv: whitened on-policy advantages (dapg.py:61)."""
+    dt = theta.dtype
+    demo_adv = lam_0 * (lam_1 ** iter_count) * np.ones(demo_obs.shape[0])
+    all_obs, all_act = np.concatenate([obs, demo_obs]), np.concatenate([act, demo_act])
+    all_adv = 1e-2 * np.concatenate([adv / (np.std(adv) + 1e-8), demo_adv])
+    coef = all_adv.shape[0] / adv.shape[0]
+    g = dt.type(coef) * vpg(theta, theta, all_obs, all_act, all_adv, n, m, hidden, tr, tr)
+    x = cg_solve(lambda p: fvp(theta, obs, p, n, m, hidden, tr, damping), g, cg_iters)
+    alpha = np.sqrt(np.abs(2.0 * kl_dist / (np.dot(g, x) + 1e-20)))
+    new = theta + dt.type(alpha) * x
+    new[-m:] = np.maximum(new[-m:], dt.type(min_log_std))
+    return dict(vpg=g, npg=x, alpha=float(alpha), new_params=new,
+                surr_before=surrogate(theta, theta, obs, act, adv, n, m, hidden, tr, tr),
+                surr_after=surrogate(new, theta, obs, act, adv, n, m, hidden, tr, tr),
+                kl=mean_kl(new, theta, obs, n, m, hidden, tr, tr))
+
+
 # TRPO line search  (mjrl/algos/trpo.py:100-126)
 def trpo_update(theta, obs, act, adv, n, m, hidden, tr=None, cg_iters=10, damping=1e-4,
                 kl_dist=0.01, min_log_std=-3.0):

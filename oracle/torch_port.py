@@ -15,11 +15,15 @@ from . import npg_oracle as O
 
 
 class TorchPolicy:
-    def __init__(self, theta, n, m, hidden, theta_old=None, tr_new=None, tr_old=None):
+    def __init__(self, theta, n, m, hidden, theta_old=None, tr_new=None, tr_old=None, dtype=np.float32):
+        """dtype float32: the reference's precision (it casts everything with .float()); float64: the same op
+        sequence in double -- the "truth" for tolerance studies of the general (old != new) Hessian."""
         self.n, self.m, self.hidden = n, m, tuple(hidden)
-        self.new = self._split(np.asarray(theta, np.float32), True)
-        self.old = self._split(np.asarray(theta if theta_old is None else theta_old, np.float32), False)
-        f = lambda tr: [torch.from_numpy(np.asarray(a, np.float32)) for a in
+        self.np_dt = np.dtype(dtype).type
+        self.t_dt = torch.float64 if self.np_dt == np.float64 else torch.float32
+        self.new = self._split(np.asarray(theta, self.np_dt), True)
+        self.old = self._split(np.asarray(theta if theta_old is None else theta_old, self.np_dt), False)
+        f = lambda tr: [torch.from_numpy(np.asarray(np.asarray(a, np.float32), self.np_dt)) for a in
                         (tr.in_shift, tr.in_scale, tr.out_shift, tr.out_scale)]
         self.tr_new = f(tr_new or O.Transforms(n, m))
         self.tr_old = f(tr_old or O.Transforms(n, m))
@@ -48,8 +52,8 @@ class TorchPolicy:
 
     def dist(self, obs, act, which):
         ps, tr = (self.new, self.tr_new) if which == "new" else (self.old, self.tr_old)
-        x = torch.from_numpy(obs).float()          # the reference re-casts fp64->fp32 on every call
-        a = torch.from_numpy(act).float()
+        x = torch.from_numpy(obs).to(self.t_dt)    # the reference re-casts fp64->fp32 on every call
+        a = torch.from_numpy(act).to(self.t_dt)
         mean = self._net(ps, tr, x)
         s = ps[-1]
         z = (a - mean) / torch.exp(s)
@@ -59,7 +63,7 @@ class TorchPolicy:
     def surrogate(self, obs, act, adv):
         ll_o, _, _ = self.dist(obs, act, "old")
         ll_n, _, _ = self.dist(obs, act, "new")
-        return torch.mean(torch.exp(ll_n - ll_o) * torch.from_numpy(adv).float())
+        return torch.mean(torch.exp(ll_n - ll_o) * torch.from_numpy(adv).to(self.t_dt))
 
     def kl(self, obs, act):
         _, mo, so = self.dist(obs, act, "old")
@@ -73,14 +77,14 @@ class TorchPolicy:
         return np.concatenate([x.contiguous().view(-1).numpy() for x in g])
 
     def hvp(self, obs, act, v, damping):
-        vec = torch.from_numpy(v).float()
+        vec = torch.from_numpy(np.asarray(v)).to(self.t_dt)
         g = torch.autograd.grad(self.kl(obs, act), self.new, create_graph=True)
         flat = torch.cat([x.contiguous().view(-1) for x in g])
         h = torch.autograd.grad(torch.sum(flat * vec), self.new)
         return np.concatenate([x.contiguous().view(-1).numpy() for x in h]) + damping * v
 
     def set_new(self, theta):
-        for p, q in zip(self.new, self._split(np.asarray(theta, np.float32), True)):
+        for p, q in zip(self.new, self._split(np.asarray(theta, self.np_dt), True)):
             p.data = q.data
 
 

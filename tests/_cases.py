@@ -34,6 +34,7 @@ class NpgCase:
         self.act = np.concatenate([p["actions"] for p in self.paths])
         adv = np.concatenate([p["advantages"] for p in self.paths])
         self.adv_w = O.whiten(adv)
+        self.wide = bool(g.get("wide", False))      # N >= d fixtures of make_golden_big.py (reference + fp64-oracle vectors)
         if self.big:
             th = synth.init_params(self.n, self.m, self.hidden, seed=1, init_log_std=-0.5)
             self.theta0 = synth.perturbed_params(th, scale=0.02)
@@ -66,6 +67,28 @@ class NpgCase:
             err = np.linalg.norm(v - ref) / np.linalg.norm(ref)
         assert err < rtol, (self.name, key, err)
         return err
+
+
+    def check_step(self, key, v, tol):
+        """The north-star bar on a step-direction vector of a `wide` fixture: rel-L2 to the REFERENCE's fp32 result
+        < tol.  Where fp32 round-off puts two correct fp32 implementations of the same CG recurrence farther apart than
+        that -- the reference itself then sits farther than tol from fp64 truth on this problem
+        (err_ref_vs_f64_<key> in the fixture) -- the bar is the distance to truth instead:
+        rel(v, fp64 oracle) <= 1.5 x rel(reference, fp64 oracle).  -> dict of the measured errors."""
+        g = self.g
+        s = int(g["stride"])
+        v = np.asarray(v, np.float64)
+        ref, f64 = g[key + "_sub"].astype(np.float64), g[key + "_f64_sub"].astype(np.float64)
+        e_ref = float(np.linalg.norm(v[::s] - ref) / np.linalg.norm(ref))
+        e_f64 = float(np.linalg.norm(v[::s] - f64) / np.linalg.norm(f64))
+        ref_f64 = float(g["err_ref_vs_f64_" + key])
+        n_ref = abs(np.linalg.norm(v) - float(g[key + "_norm"])) / float(g[key + "_norm"])
+        out = dict(vs_reference=e_ref, vs_fp64=e_f64, reference_vs_fp64=ref_f64, norm_vs_reference=n_ref)
+        if e_ref < tol and n_ref < tol:
+            return out
+        assert ref_f64 > 0.5 * tol, (self.name, key, "reference is within tol/2 of truth, the HIP path is not within tol of it", out)
+        assert e_f64 <= 1.5 * ref_f64, (self.name, key, out)
+        return out
 
 
 NPG_CASES = ["npg_cfg1_linear", "npg_pointmass_32x32", "npg_cfg2_small", "npg_cfg2_ragged_tr"]

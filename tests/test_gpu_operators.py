@@ -1,0 +1,252 @@
+"""GPU tests that EXECUTE the public operator methods the reference exposes on its agents
+(mjrl/algos/batch_reinforce.py:40-58, npg_cg.py:62-88, utils/cg_solve.py) and the less-travelled keyword paths
+(const_learn_rate npg_cg.py:128-130, compute_advantages(normalize=True) process_samples.py:14-19,
+sample_mode='samples' batch_reinforce.py:83-86, DAPG with hvp_sample_frac), against the golden fixtures of the
+unmodified reference and the fp64 oracle; plus the whole-update assertion at the BASELINE size (1M timesteps)."""
+import numpy as np
+import pytest
+
+from oracle import npg_oracle as O
+from oracle import synth
+from tests._cases import NpgCase, load
+
+pytestmark = pytest.mark.gpu
+
+TOL_VPG = 3e-6
+TOL_FVP = 3e-6
+TOL_STEP = 1e-5          # the north-star bar
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def make_agent(c, cls=None, **kw):
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.policies.gaussian_mlp import MLP, LinearPolicy
+    spec = type("Spec", (), dict(observation_dim=c.n, action_dim=c.m, horizon=1000))
+    pol = MLP(spec, hidden_sizes=c.hidden, seed=1, init_log_std=-0.5) if c.hidden else LinearPolicy(spec, seed=1, init_log_std=-0.5)
+    pol.set_param_values(c.theta0)
+    if c.tr is not None:
+        pol.model.set_transformations(*c.tr)
+        pol.old_model.set_transformations(*c.tr)
+    kw.setdefault("FIM_invert_args", {'iters': c.cg_iters, 'damping': 1e-4})
+    return (cls or NPG)(None, pol, None, **kw), pol
+
+
+@pytest.mark.parametrize("name", ["npg_cfg2_small", "npg_cfg2_ragged_tr", "npg_cfg1_linear"])
+def test_agent_operator_methods_vs_reference(name):
+    """CPI_surrogate / flat_vpg / HVP / build_Hvp_eval + cg_solve called the way the reference's own code and its
+    users call them (host ndarrays in; tensors / ndarrays out) == the reference's outputs for the same calls."""
+    import torch
+    from mjrl_amd.utils.cg_solve import cg_solve
+    c = NpgCase(name)
+    agent, pol = make_agent(c)
+    surr = agent.CPI_surrogate(c.obs, c.act, c.adv_w)
+    assert isinstance(surr, torch.Tensor)                                   # the reference returns torch scalars ...
+    assert abs(surr.data.numpy().ravel()[0] - float(c.g["surr_before"])) < 1e-6      # ... unwrapped like batch_reinforce.py:139
+    g = agent.flat_vpg(c.obs, c.act, c.adv_w)
+    assert isinstance(g, np.ndarray) and g.dtype == np.float32 and g.shape == c.g["vpg"].shape
+    assert rel(g, c.g["vpg"]) < TOL_VPG
+    hv = agent.HVP(c.obs, c.act, c.g["vpg"])                                # regu_coef defaults to FIM_invert_args['damping']
+    assert isinstance(hv, np.ndarray) and rel(hv, c.g["hvp_of_vpg"]) < TOL_FVP
+    hv0 = agent.HVP(c.obs, c.act, c.g["vpg"], regu_coef=0.0)
+    assert rel(hv0 + np.float32(1e-4) * c.g["vpg"], c.g["hvp_of_vpg"]) < TOL_FVP
+    hvp = agent.build_Hvp_eval([c.obs, c.act], regu_coef=1e-4)              # npg_cg.py:83-88
+    assert rel(hvp(c.g["vpg"]), c.g["hvp_of_vpg"]) < TOL_FVP
+    x = cg_solve(hvp, c.g["vpg"], x_0=c.g["vpg"].copy(), cg_iters=c.cg_iters)    # the call of npg_cg.py:122-123
+    assert isinstance(x, np.ndarray) and rel(x, c.g["cg_x"]) < TOL_STEP
+    # a plain host callable goes through the reference's host loop (x_0 ignored, residual_tol break)
+    A = np.diag(np.arange(1.0, 9.0)); b = np.arange(8.0)
+    xs = cg_solve(lambda v: A.dot(v), b, x_0=np.ones(8), cg_iters=20)
+    np.testing.assert_allclose(xs, b / np.arange(1.0, 9.0), rtol=1e-8, atol=1e-10)
+    # kl_old_new at theta_new == theta_old: exactly the reference's value (0 up to the 1e-8 of Dr)
+    kl = agent.kl_old_new(c.obs, c.act)
+    assert isinstance(kl, torch.Tensor) and abs(float(kl)) < 1e-6
+    agent.engine.close()
+
+
+def test_agent_operators_with_old_neq_new():
+    """the same public methods in general position (theta_new != theta_old, input transform only on policy.model --
+    the state input_normalization leaves behind, npg_cg.py:101-107) against the reference's values."""
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    g = load("hvp_general_64x64")
+    n, m, hidden = int(g["n"]), int(g["m"]), tuple(int(h) for h in g["hidden"])
+    paths = synth.make_paths(int(g["n_traj"]), int(g["T"]), n, m, seed=int(g["path_seed"]))
+    rng = np.random.RandomState(int(g["adv_seed"]))
+    for p in paths:
+        p["advantages"] = rng.randn(len(p["rewards"])) * 2.0 + 0.3
+    obs = np.concatenate([p["observations"] for p in paths]); act = np.concatenate([p["actions"] for p in paths])
+    adv_w = O.whiten(np.concatenate([p["advantages"] for p in paths]))
+    spec = type("Spec", (), dict(observation_dim=n, action_dim=m, horizon=1000))
+    pol = MLP(spec, hidden_sizes=hidden, seed=1, init_log_std=-0.5)
+    pol.set_param_values(g["theta_old"], set_new=True, set_old=True)
+    pol.set_param_values(g["theta_new"], set_new=True, set_old=False)
+    pol.model.set_transformations(g["in_shift"], g["in_scale"], None, None)
+    agent = NPG(None, pol, None)
+    assert abs(float(agent.CPI_surrogate(obs, act, adv_w)) - float(g["surr"])) < 2e-6
+    assert abs(float(agent.kl_old_new(obs, act)) - float(g["kl"])) < 1e-5 * float(g["kl"]) + 1e-8
+    assert rel(agent.flat_vpg(obs, act, adv_w), g["vpg"]) < TOL_STEP        # (likelihood ratios span 7e-5 .. 1.3e3: the reference itself sits 3.3e-6 from fp64)
+    assert rel(agent.HVP(obs, act, g["v"], regu_coef=1e-4), g["hvp"]) < TOL_STEP
+    agent.engine.close()
+
+
+def test_CG_solve_standalone_equals_cg_solve_and_reference():
+    """the north-star's public name: agent.CG_solve(b) on the bound batch, device tensor or host vector in."""
+    import torch
+    c = NpgCase("npg_cfg2_small")
+    agent, pol = make_agent(c)
+    agent._bind(c.obs, c.act, c.adv_w)
+    x, bx = agent.CG_solve(c.g["vpg"])                                      # host vector
+    assert rel(x.cpu().numpy(), c.g["cg_x"]) < TOL_STEP
+    assert abs(bx - float(np.dot(c.g["vpg"].astype(np.float64), x.cpu().numpy().astype(np.float64)))) < 1e-6 * abs(bx)
+    gdev = torch.from_numpy(c.g["vpg"]).to(agent.engine.device)
+    x2, bx2 = agent.CG_solve(gdev, iters=c.cg_iters, damping=1e-4)          # device tensor, explicit arguments
+    assert np.array_equal(x2.cpu().numpy(), x.cpu().numpy()) and bx2 == bx  # bit-reproducible
+    x3, _ = agent.CG_solve(gdev, iters=3)
+    ref3 = O.cg_solve(lambda p: O.fvp(c.theta0.astype(np.float64), c.obs, p, c.n, c.m, c.hidden, damping=1e-4),
+                      c.g["vpg"].astype(np.float64), 3)
+    assert rel(x3.cpu().numpy(), ref3) < TOL_STEP
+    agent.engine.close()
+
+
+@pytest.mark.parametrize("name", ["npg_cfg2_small", "npg_pointmass_32x32"])
+def test_const_learn_rate_branch(name):
+    """NPG(const_learn_rate=a): new = theta + a * npg_grad, delta logged as a^2 g.x (npg_cg.py:128-130): the step is
+    a times the reference's CG solution of the fixture."""
+    c = NpgCase(name)
+    a = 0.2
+    agent, pol = make_agent(c, const_learn_rate=a, save_logs=True)
+    agent.train_from_paths(c.paths)
+    step = pol.get_param_values().astype(np.float64) - c.theta0
+    assert rel(step, a * c.g["cg_x"].astype(np.float64)) < TOL_STEP
+    lg = agent.logger.get_current_log()
+    gx = float(np.dot(c.g["vpg"].astype(np.float64), c.g["cg_x"].astype(np.float64)))
+    assert lg["alpha"] == a and abs(lg["delta"] - a * a * gx) < 1e-4 * abs(a * a * gx)
+    r = O.npg_update(c.theta0.astype(np.float64), c.obs, c.act, c.adv_w, c.n, c.m, c.hidden, c.transforms(), cg_iters=c.cg_iters,
+                     const_alpha=a)
+    assert abs(lg["kl_dist"] - r["kl"]) < 1e-4 * r["kl"] + 1e-9
+    assert pol.old_equals_new()
+    agent.engine.close()
+
+
+@pytest.mark.parametrize("kind", ["quadratic", "linear"])
+def test_compute_advantages_normalize(kind):
+    """compute_advantages(..., normalize=True): (adv - mean) / (std + 1e-8) over the whole batch, both branches
+    (process_samples.py:14-19, 30-35)."""
+    from mjrl_amd.utils import process_samples
+    g = load("gae_" + kind)
+    n, m = int(g["n"]), int(g["m"])
+    paths = synth.make_paths(int(g["n_traj"]), int(g["T"]), n, m, seed=int(g["path_seed"]), ragged=True)
+    gamma, lam = float(g["gamma"]), float(g["lam"])
+    process_samples.compute_returns(paths, gamma)
+
+    class Frozen:
+        def __init__(self):
+            self.k = 0
+        def predict(self, path):
+            T = len(path["rewards"]); out = g["baseline_pred"][self.k:self.k + T]; self.k += T
+            return np.asarray(out, np.float64)
+    for lam_, key in ((lam, "advantages"), (None, "advantages_nogae")):
+        process_samples.compute_advantages(paths, Frozen(), gamma, lam_, normalize=True)
+        a = g[key]
+        want = (a - a.mean()) / (a.std() + 1e-8)
+        got = np.concatenate([p["advantages"] for p in paths])
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+        assert abs(got.mean()) < 1e-12 and abs(got.std() - 1.0) < 1e-6
+
+
+def test_train_step_sample_mode_samples():
+    """train_step(sample_mode='samples') draws whole trajectories until N timesteps are in (batch_reinforce.py:83-86)
+    and rejects other modes (:73-75)."""
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+    from mjrl_amd.policies.gaussian_mlp import MLP
+
+    class Walk:                            # 1-D random walk to the origin, horizon 20
+        horizon = 20
+        def __init__(self):
+            self.rng = np.random.RandomState(0)
+        def set_seed(self, s):
+            self.rng = np.random.RandomState(s)
+        def reset(self):
+            self.x = self.rng.uniform(-1, 1, 3); return self.x.copy()
+        def step(self, a):
+            self.x = self.x + 0.1 * np.clip(a, -1, 1)[:3]
+            return self.x.copy(), -float(np.abs(self.x).sum()), False, {}
+
+    spec = type("Spec", (), dict(observation_dim=3, action_dim=3, horizon=20))
+    pol = MLP(spec, hidden_sizes=(32, 32), seed=3, init_log_std=-0.5)
+    agent = NPG(Walk(), pol, QuadraticBaseline(spec), normalized_step_size=0.05, seed=5, save_logs=True)
+    stats = agent.train_step(N=330, sample_mode='samples', gamma=0.95, gae_lambda=0.97, num_cpu=1)
+    lg = agent.logger.get_current_log()
+    assert 330 <= lg["num_samples"] < 330 + 20 and stats[-1] == 330 and agent.seed == 5 + 330
+    assert 0 < lg["kl_dist"] < 0.1
+    with pytest.raises(ValueError):
+        agent.train_step(N=10, sample_mode='timesteps')
+    agent.engine.close()
+
+
+def test_dapg_with_hvp_sample_frac_draws_from_the_on_policy_rows():
+    """DAPG + hvp_sample_frac < 0.99: the Fisher rows of every product are drawn with replacement from the
+    ON-POLICY block only (dapg.py:103 hands HVP the on-policy arrays; npg_cg.py:65-69 samples from what it is handed),
+    from NumPy's global RNG, and the [on-policy ; demonstrations] binding is restored afterwards."""
+    from mjrl_amd.algos.dapg import DAPG
+    c = NpgCase("npg_cfg2_small")
+    demos = synth.make_paths(3, 200, c.n, c.m, seed=7)
+    frac, iters = 0.8, 6
+    agent, pol = make_agent(c, cls=DAPG, demo_paths=demos, kl_dist=0.025, lam_0=1e-2, lam_1=0.95, hvp_sample_frac=frac,
+                            FIM_invert_args={'iters': iters, 'damping': 1e-4})
+    np.random.seed(11)
+    agent.train_from_paths(c.paths)
+    th = c.theta0.astype(np.float64)
+    a = (c.n, c.m, c.hidden)
+    d_obs = np.concatenate([p["observations"] for p in demos]); d_act = np.concatenate([p["actions"] for p in demos])
+    N = c.obs.shape[0]
+    all_adv = 1e-2 * np.concatenate([c.adv_w / (np.std(c.adv_w) + 1e-8), 1e-2 * np.ones(d_obs.shape[0])])
+    g = (all_adv.shape[0] / N) * O.vpg(th, th, np.concatenate([c.obs, d_obs]), np.concatenate([c.act, d_act]), all_adv, *a)
+    np.random.seed(11)
+    def hv(p):
+        idx = np.random.choice(N, size=int(frac * N))
+        return O.fvp(th, c.obs[idx], p, *a, damping=1e-4)
+    x = O.cg_solve(hv, g, iters)
+    alpha = np.sqrt(abs(2 * 0.025 / (g.dot(x) + 1e-20)))
+    step = pol.get_param_values().astype(np.float64) - c.theta0
+    assert rel(step, alpha * x) < TOL_STEP, rel(step, alpha * x)
+    new = th + alpha * x
+    assert abs(agent.last_update["kl_dist"] - O.mean_kl(new, th, c.obs, *a)) < 1e-4 * agent.last_update["kl_dist"]
+    eng = agent.engine
+    assert eng.N_bound == N and eng.N_local == N + d_obs.shape[0]      # prefix binding restored over the whole block
+    agent.engine.close()
+
+
+def test_whole_update_at_the_baseline_size():
+    """ONE NPG update on bench.py's own 1M-timestep batch (BASELINE configs[1]): alpha / kl / surr_improvement and the
+    step against the stored fp64-oracle values (tests/golden/bench_cfg2_1m.npz; 84 s of CPU to regenerate)."""
+    import torch
+    import bench
+    from mjrl_amd.engine import UpdateEngine
+    g = load("bench_cfg2_1m")
+    theta0 = bench.initial_params()
+    obs, act, adv = bench.synth_shard(0, 1)
+    adv = (adv - adv.mean()) / (adv.std() + 1e-6)
+    eng = UpdateEngine(bench.N_OBS, bench.N_ACT, bench.HIDDEN)
+    ident = np.concatenate([np.zeros(bench.N_OBS), np.ones(bench.N_OBS), np.zeros(bench.N_ACT), np.ones(bench.N_ACT)]).astype(np.float32)
+    eng.set_policy(theta0, theta0, ident, ident)
+    eng.set_batch(obs, act, adv)
+    assert eng.N_global == int(g["N"])
+    grad, _ = eng.surr_vpg(sync=False)
+    eng.cg_solve(grad, bench.CG_ITERS, bench.DAMPING, sync=False)
+    eng.apply_npg_step(bench.STEP, -3.0)
+    surr_after, kl = eng.eval_surr_kl()
+    late = eng.deferred()
+    assert abs(late["alpha"] - float(g["alpha"])) < 1e-5 * float(g["alpha"])
+    assert abs(kl - float(g["kl"])) < 1e-5 * float(g["kl"])
+    assert abs((surr_after - late["surr_before"]) - float(g["surr_improvement"])) < 1e-5 * float(g["surr_improvement"])
+    step = eng.theta_new.cpu().numpy().astype(np.float64) - theta0
+    s = int(g["stride"])
+    assert rel(step[::s], g["step_sub"]) < TOL_STEP
+    assert abs(np.linalg.norm(step) - float(g["step_norm"])) < 1e-5 * float(g["step_norm"])
+    eng.close()

@@ -45,6 +45,54 @@ def test_trpo_line_search_matches_reference():
     assert abs(r["kl"] - float(c.g["kl"])) < 1e-5
 
 
+def test_dapg_update_matches_reference():
+    """oracle.dapg_update (fp64) against the reference's DAPG.train_from_paths on the small cfg5-shaped fixture
+    (N = 10 000 << d = 297 528: fp32 CG on a rank-deficient Fisher, hence the loose bars; the N >= d fixture
+    dapg_cfg5_wide stores the reference-vs-oracle distance, 1e-6 class, checked below)."""
+    c = NpgCase("dapg_cfg5_small")
+    d_obs = np.concatenate([p["observations"] for p in c.demo_paths]); d_act = np.concatenate([p["actions"] for p in c.demo_paths])
+    r = O.dapg_update(c.theta0.astype(np.float64), c.obs, c.act, c.adv_w, d_obs, d_act, c.n, c.m, c.hidden, cg_iters=c.cg_iters,
+                      damping=1e-4, kl_dist=float(c.g["kl_dist"]), lam_0=float(c.g["lam_0"]), lam_1=float(c.g["lam_1"]))
+    assert abs(r["alpha"] - float(c.g["alpha"])) / float(c.g["alpha"]) < 2e-4
+    c.check("new_params", r["new_params"], 1e-4)
+    assert abs(r["kl"] - float(c.g["kl"])) < 2e-3 * abs(float(c.g["kl"]))
+
+
+@pytest.mark.parametrize("name", ["npg_cfg4_wide", "dapg_cfg5_wide"])
+def test_wide_fixtures_pin_the_oracle(name):
+    """The N >= d fixtures (make_golden_big.py) hold the reference's vectors AND the fp64 oracle's on the same inputs
+    (re-running the oracle takes minutes, so the comparison made at generation time is stored): the oracle must sit
+    within the reference's fp32 round-off of it -- gradient and Fisher product at 1e-6 class, the CG solve and the
+    update step below the 1e-5 north-star bar."""
+    g = load(name)
+    bars = dict(vpg=2e-6, hvp_of_vpg=1e-6, cg_x=1e-5, update_step=1e-5)
+    for key, bar in bars.items():
+        ref, f64 = g[key + "_sub"].astype(np.float64), g[key + "_f64_sub"]
+        sub = np.linalg.norm(ref - f64) / np.linalg.norm(f64)
+        full = float(g["err_ref_vs_f64_" + key])
+        assert full < bar, (name, key, full)
+        assert abs(sub - full) < 0.5 * full + 1e-9, (name, key, sub, full)       # the stored strided samples tell the same story
+    assert abs(float(g["alpha"]) - float(g["alpha_f64"])) < 1e-5 * float(g["alpha_f64"])
+    assert abs(float(g["kl"]) - float(g["kl_f64"])) < 1e-4 * float(g["kl_f64"])
+    assert int(g["N"]) >= O.num_params(int(g["n"]), int(g["m"]), tuple(int(h) for h in g["hidden"]))       # N >= d
+
+
+def test_bench_fixture_is_the_oracles_update_on_the_bench_batch():
+    """bench_cfg2_1m.npz: the fp64 oracle's alpha / kl / surr_improvement of one NPG update on bench.py's 1M-timestep
+    batch (84 s of CPU, stored).  Cheap consistency pin: the same oracle on the first 20 000 timesteps of the same
+    batch lands near those scalars (they are means over i.i.d. samples), and the stored step is a descent step."""
+    import bench
+    g = load("bench_cfg2_1m")
+    assert int(g["N"]) == bench.N_TRAJ * bench.T
+    theta0 = bench.initial_params()
+    obs, act, adv = bench.synth_shard(0, 50)                     # first 20 trajectories
+    adv = (adv - adv.mean()) / (adv.std() + 1e-6)
+    r = O.npg_update(theta0.astype(np.float64), obs.astype(np.float64), act.astype(np.float64), adv, bench.N_OBS, bench.N_ACT,
+                     bench.HIDDEN, cg_iters=bench.CG_ITERS, damping=bench.DAMPING, delta=bench.STEP)
+    assert abs(r["kl"] - float(g["kl"])) < 0.5 * float(g["kl"])
+    assert float(g["surr_improvement"]) > 0 and float(g["alpha"]) > 0 and float(g["step_norm"]) > 0
+
+
 def test_torch_port_general_hvp_matches_reference():
     from oracle.torch_port import TorchPolicy
     g = load("hvp_general_64x64")
