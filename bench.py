@@ -169,10 +169,9 @@ def main():
 
     def one_update():
         # the call sequence of NPG.train_from_paths (mjrl_amd/algos/npg_cg.py): everything is enqueued, one read-back
-        g, _ = eng.surr_vpg(sync=False)
-        eng.cg_solve(g, CG_ITERS, DAMPING, sync=False)
-        eng.apply_npg_step(STEP, -3.0)                  # alpha = sqrt(|delta / (g.x + 1e-20)|) formed on the device
-        surr_after, kl = eng.eval_surr_kl()
+        # ONE call into libmjx (mjx_npg_update): K1, rank sum, CG (10 x [K2, rank sum, vector update]), step length on the
+        # device, step, K3, rank sum -- then one read-back
+        surr_after, kl = eng.npg_update(CG_ITERS, DAMPING, STEP, -3.0)
         late = eng.deferred()
         last.update(alpha=late["alpha"], kl=kl, surr_improvement=surr_after - late["surr_before"])
         # old := new happens here in training; the bench restores theta0 so every step does identical work

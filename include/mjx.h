@@ -123,6 +123,7 @@ typedef int (*mjx_allreduce_fn)(void* user, float* buf, int64_t count, void* str
 /* x_out = CG(A, b) with A p = allreduce(mjx_fvp(p)) + damping*p, x0 = 0 (the
  * reference ignores its x_0 argument), `iters` iterations, early stop once
  * r.r < tol (the remaining launches become no-ops on device: no host sync).
+ * allreduce == NULL: the attached communicator's ncclAllReduce (mjx_comm_init) when there is one, else single rank.
  * Also writes bdotx_out[0] = b . x  (double) for the step-size rule. */
 int mjx_cg_solve(mjx_ctx* ctx, const float* b, int iters, float damping, double tol,
                  float* x_out, double* bdotx_out, mjx_allreduce_fn allreduce, void* user, void* stream);
@@ -131,6 +132,47 @@ int mjx_cg_init(mjx_ctx* ctx, const float* b, void* stream);
 const float* mjx_cg_p(mjx_ctx* ctx);                       /* current search direction (device) */
 int mjx_cg_step(mjx_ctx* ctx, const float* Ap_nodamp, float damping, double tol, void* stream);
 int mjx_cg_finish(mjx_ctx* ctx, const float* b, float* x_out, double* bdotx_out, void* stream);
+
+/* ---- multi-rank: one process per GPU, RCCL over xGMI -------------------------------------------- */
+/* The batch shards by whole trajectories over the ranks; every sample sum is formed locally with N_global and summed
+ * over the ranks: d floats after K1 and after every Fisher-vector product of the solve, 4 doubles after K1 / K3.  With a
+ * communicator attached, mjx_cg_solve (allreduce == NULL) and mjx_npg_update issue those sums as ncclAllReduce calls on
+ * the launch stream between their kernels: no host round trip and no cross-stream event per CG iteration.  The
+ * reference has nothing to replace here (its only parallelism is the sampler pool, mjrl/samplers/core.py:189-210).
+ * librccl is bound at run time (dlopen; the copy the process already mapped -- PyTorch-ROCm's -- is preferred). */
+#define MJX_COMM_ID_BYTES 128
+/* rank 0: a fresh communicator id (ncclGetUniqueId); the caller hands the 128 bytes to the other ranks */
+int mjx_comm_unique_id(char* id_out_host);
+/* every rank: join (ncclCommInitRank on the context's device; collective, blocks until all ranks joined).
+ * world == 1 is allowed: the collectives still run on a 1-rank communicator (rehearsals). */
+int mjx_comm_init(mjx_ctx* ctx, int rank, int world, const char* id_host);
+int mjx_comm_destroy(mjx_ctx* ctx);
+/* A transport hook in place of RCCL (tests that put two ranks on one GPU, which RCCL refuses; other fabrics): called on
+ * the host between the kernel launches of mjx_cg_solve / mjx_npg_update; it must leave the sum over the ranks in buf
+ * (count elements, dtype 0 = fp32 / 1 = fp64) ordered after the work already enqueued on `stream` and before what
+ * follows.  fn == NULL detaches.  Not allowed while an RCCL communicator is attached. */
+typedef int (*mjx_reduce_fn)(void* user, void* buf, int64_t count, int dtype, void* stream);
+int mjx_comm_set_callback(mjx_ctx* ctx, mjx_reduce_fn fn, void* user, int world);
+/* number of ranks of the attached communicator / transport hook, 0 = none */
+int mjx_comm_world(const mjx_ctx* ctx);
+/* in-place sum over the ranks on `stream`; dtype 0 = fp32, 1 = fp64 */
+int mjx_comm_allreduce(mjx_ctx* ctx, void* buf, int64_t count, int dtype, void* stream);
+
+/* ONE device-resident NPG update enqueued without a host round trip -- what NPG.train_from_paths does between
+ * process_paths and the parameter read-back (mjrl/algos/npg_cg.py:108-142):
+ *   K1   grad = flat_vpg, surrogate sums                                   [rank sum: d floats + 4 doubles]
+ *   K4   x = CG(F + damping I, grad): iters x (K2 [rank sum: d floats] + vector update), early stop below tol
+ *        alpha = sqrt(|step_size / (grad.x + 1e-20)|)   (:133), or alpha = const_alpha when const_alpha > 0 (:128-130)
+ *        theta_out = theta_old + alpha x, log_std = max(log_std, min_log_std)   (:137-139, gaussian_mlp.py:73-75)
+ *   K3   surrogate / KL sums of theta_out against theta_old                [rank sum: 4 doubles]
+ * Requires mjx_bind_batch and mjx_bind_policy(old_is_new = 1).  theta_out (d floats) may be the bound theta_new
+ * buffer (it is rewritten in place) but must not alias theta_old.  On return the context's NEW parameters are
+ * theta_out, as after mjx_bind_policy(theta_out, theta_old, tr_new, tr_old, 0).
+ * results (device, 16 doubles): [0] sum LR*adv and [1] sum KL at theta_out (K3); [4] sum LR*adv at theta_old and
+ * [5] local sample count (K1); [8] grad.x; [9] alpha (left untouched under const_alpha).  Sums are over all ranks;
+ * divide by N_global.  grad_out / x_out: d floats each. */
+int mjx_npg_update(mjx_ctx* ctx, int iters, float damping, double tol, double step_size, double const_alpha,
+                   float min_log_std, float* grad_out, float* x_out, float* theta_out, double* results, void* stream);
 
 /* theta_out = theta + alpha * x, then log_std = max(log_std, min_log_std)
  * (npg_cg.py:137-139 + gaussian_mlp.py:73-75). */

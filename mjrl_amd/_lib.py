@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("MJX_LIB") or os.path.join(_HERE, "csrc", "libmjx.so")
 c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_void_p)
+REDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p)      # mjx_reduce_fn
 
 # name -> (restype, argtypes); every symbol include/mjx.h declares
 PROTOTYPES = {
@@ -34,11 +35,19 @@ PROTOTYPES = {
     "mjx_surr_vpg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mjx_fvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mjx_eval_surr_kl": (c_int, [c_void_p, c_void_p, c_void_p]),
-    "mjx_cg_solve": (c_int, [c_void_p, c_void_p, c_int, c_float, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mjx_cg_solve": (c_int, [c_void_p, c_void_p, c_int, c_float, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),   # (the mjx_allreduce_fn argument as a plain pointer: ctypes.cast(ALLREDUCE_FN(f), c_void_p) or None)
     "mjx_cg_init": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mjx_cg_p": (c_void_p, [c_void_p]),
     "mjx_cg_step": (c_int, [c_void_p, c_void_p, c_float, c_double, c_void_p]),
     "mjx_cg_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mjx_comm_unique_id": (c_int, [ctypes.c_char_p]),
+    "mjx_comm_init": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p]),
+    "mjx_comm_destroy": (c_int, [c_void_p]),
+    "mjx_comm_world": (c_int, [c_void_p]),
+    "mjx_comm_set_callback": (c_int, [c_void_p, REDUCE_FN, c_void_p, c_int]),
+    "mjx_comm_allreduce": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mjx_npg_update": (c_int, [c_void_p, c_int, c_float, c_double, c_double, c_double, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p]),
     "mjx_apply_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "mjx_apply_npg_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_float, c_void_p, c_void_p, c_void_p]),
     "mjx_discount_scan": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p]),

@@ -129,33 +129,38 @@ class NPG(BatchREINFORCE):
             self.log_rollout_statistics(paths)
         eng = self.engine
 
-        # The whole update is enqueued without reading anything back: the normalised step length is formed on the device
-        # from g.x; surrogate-before, g.x and alpha are fetched once, after the evaluation kernel (t_gLL / t_FIM are
-        # therefore enqueue times unless the constant-alpha branch needs g.x on the host).
         const_alpha = self.alpha is not None
         subsampled = self.hvp_subsample is not None and self.hvp_subsample < 0.99
-        t0 = timer.time()
-        g, surr_before = eng.surr_vpg(sync=False)             # npg_cg.py:111-115
-        t_gLL = timer.time() - t0
-
-        t0 = timer.time()
-        _, gdotx = self.CG_solve(g, sync=const_alpha or subsampled)   # npg_cg.py:120-123
-        t_FIM = timer.time() - t0
-
-        if const_alpha:                                       # npg_cg.py:128-133
-            if gdotx is None:
-                gdotx = eng.deferred()["gdotx"]
-            alpha = self.alpha
-            n_step_size = (alpha ** 2) * gdotx
-            eng.apply_step(alpha, self.policy.min_log_std)    # npg_cg.py:137-139
+        iters, damping = self.FIM_invert_args['iters'], self.FIM_invert_args['damping']
+        if not subsampled and eng.old_is_new:
+            # The whole update in ONE call into libmjx (mjx_npg_update): K1, CG, step length formed on the device from g.x,
+            # step, K3 -- rank sums included -- and one read-back.  (t_gLL / t_FIM cannot be told apart any more: the
+            # gradient time is logged as 0, the solve time is the whole call.)
+            t0 = timer.time()
+            surr_after, kl_dist = eng.npg_update(iters, damping, self.n_step_size, self.policy.min_log_std,
+                                                 const_alpha=self.alpha if const_alpha else None)   # npg_cg.py:108-141
+            t_gLL, t_FIM = 0.0, timer.time() - t0
         else:
-            n_step_size = self.n_step_size
-            eng.apply_npg_step(self.n_step_size, self.policy.min_log_std)   # alpha = sqrt(|delta / (g.x + 1e-20)|), on the device
-        surr_after, kl_dist = eng.eval_surr_kl()              # npg_cg.py:140-141
+            # row-subsampled Fisher products (a fresh host-drawn sample per product, npg_cg.py:65-69) and the general
+            # position theta_new != theta_old (input_normalization, :101-107): call by call
+            t0 = timer.time()
+            g, _ = eng.surr_vpg(sync=False)                   # npg_cg.py:111-115
+            t_gLL = timer.time() - t0
+            t0 = timer.time()
+            self.CG_solve(g, sync=const_alpha or subsampled)  # npg_cg.py:120-123
+            t_FIM = timer.time() - t0
+            if const_alpha:
+                eng.apply_step(self.alpha, self.policy.min_log_std)    # npg_cg.py:137-139
+            else:
+                eng.apply_npg_step(self.n_step_size, self.policy.min_log_std)   # alpha = sqrt(|delta / (g.x + 1e-20)|), on the device
+            surr_after, kl_dist = eng.eval_surr_kl()          # npg_cg.py:140-141
         late = eng.deferred()
         surr_before, gdotx = late["surr_before"], late["gdotx"]
-        if not const_alpha:
-            alpha = late["alpha"]
+        if const_alpha:                                       # npg_cg.py:128-130
+            alpha = self.alpha
+            n_step_size = (alpha ** 2) * gdotx
+        else:
+            alpha, n_step_size = late["alpha"], self.n_step_size
         self.policy.set_param_values(eng.theta_new.cpu().numpy(), set_new=True, set_old=True)
 
         if self.save_logs:

@@ -810,7 +810,8 @@ struct LayerwiseWS {
       if (splits > maxs) splits = maxs;
       if (splits < 1) splits = 1;
       const int csplits = 256;
-      if (ensure_part((int64_t)splits * ho * hi_ + (int64_t)csplits * ho + (int64_t)rowblocks * hi_)) return 2;
+      const int rsplits = 64;                      // second-stage split of the per-row-block column sums
+      if (ensure_part((int64_t)splits * ho * hi_ + (int64_t)csplits * ho + (int64_t)rowblocks * hi_ + (int64_t)rsplits * hi_)) return 2;
       GemmArgs g{};
       g.npairs = 1; g.K[0] = (int)N;
       if (narrow) {
@@ -851,7 +852,14 @@ struct LayerwiseWS {
         b.epi = EPI_BACK;
         b.colsum = (rowblocks == 1) ? grad + ob[l - 1] : cpart;
         launch_gemm(b, 1, st);
-        if (rowblocks > 1)
+        if (rowblocks > 1024) {
+          // thousands of row blocks (3 907 at 500 k samples): 16..32 workgroups walking them took 100-200 us per layer;
+          // sum them in 64 row ranges first (k_colsum: 64 x hi/64 workgroups), then the 64 partial rows -- fixed order
+          float* rpart = cpart + (int64_t)rowblocks * hi_;
+          hipLaunchKernelGGL(k_colsum, dim3((hi_ + 63) / 64, rsplits), dim3(256), 0, st, cpart, (int64_t)rowblocks, hi_, (int64_t)hi_, rpart);
+          hipLaunchKernelGGL(k_reduce_partials, dim3((hi_ + 15) / 16), dim3(256), 0, st, rpart, rsplits, hi_, grad + ob[l - 1],
+                             (const float*)nullptr, (const float*)nullptr, 0, 0.f);
+        } else if (rowblocks > 1)
           hipLaunchKernelGGL(k_reduce_partials, dim3((hi_ + 15) / 16), dim3(256), 0, st, cpart, rowblocks, hi_, grad + ob[l - 1],
                              (const float*)nullptr, (const float*)nullptr, 0, 0.f);
         bias_done = true;

@@ -16,6 +16,7 @@
 #include "baseline.h"
 #include "fused_policy.h"
 #include "policy_fit.h"
+#include "rccl_dyn.h"
 #include "layerwise.h"
 #include "mlp_fit.h"
 #include "vecops.h"
@@ -78,6 +79,8 @@ struct mjx_ctx {
   size_t prof_used = 0;
   int prof_stride = 1;               // bracket every prof_stride-th launch
   size_t prof_seen = 0;
+  void* comm = nullptr; int comm_world = 0, comm_rank = 0;   // RCCL communicator (one process per GPU)
+  mjx_reduce_fn reduce_cb = nullptr; void* reduce_user = nullptr;   // transport hook in its place (tests)
   mjx::LayerwiseWS lw;             // layer-wise path workspace
   mjx::LayerwiseWS lwmb;           // minibatch trainer workspace (mjx_policy_minibatch_adam)
   float *mb_x = nullptr, *mb_a = nullptr, *mb_adv = nullptr, *mb_grad = nullptr; int mb_cap = 0;
@@ -239,6 +242,7 @@ int mjx_create(mjx_ctx** out, int device, int n, int m, const int* hidden, int n
 void mjx_destroy(mjx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  (void)mjx_comm_destroy(c);
   c->lw.release();
   c->lwmb.release();
   hipFree(c->mb_x); hipFree(c->mb_a); hipFree(c->mb_adv); hipFree(c->mb_grad);
@@ -657,10 +661,99 @@ int mjx_cg_solve(mjx_ctx* c, const float* b, int iters, float damping, double to
   if (int rc = mjx_cg_init(c, b, stream)) return rc;
   for (int i = 0; i < iters; ++i) {
     if (int rc = mjx_fvp(c, c->cg_p, c->cg_Ap, stream)) return rc;
-    if (allreduce) if (int rc = allreduce(user, c->cg_Ap, c->d, stream)) return fail(rc, "allreduce callback failed (%d)", rc);
+    if (allreduce) { if (int rc = allreduce(user, c->cg_Ap, c->d, stream)) return fail(rc, "allreduce callback failed (%d)", rc); }
+    else if (c->comm || c->reduce_cb) { if (int rc = mjx_comm_allreduce(c, c->cg_Ap, c->d, 0, stream)) return rc; }
     if (int rc = mjx_cg_step(c, c->cg_Ap, damping, tol, stream)) return rc;
   }
   return mjx_cg_finish(c, b, x_out, bdotx_out, stream);
+}
+
+// ---------------------------------------------------------------------------- multi-rank (RCCL, bound at run time)
+int mjx_comm_unique_id(char* id_out) {
+  if (!id_out) return fail(MJX_ERR_ARG, "null id buffer");
+  RcclApi& r = rccl();
+  if (!r.load()) return fail(MJX_ERR_UNSUPPORTED, "%s", r.error.c_str());
+  RcclApi::UniqueId id;
+  if (int rc = r.GetUniqueId(&id)) return fail(1000 + rc, "ncclGetUniqueId: %s", r.GetErrorString(rc));
+  memcpy(id_out, id.internal, MJX_COMM_ID_BYTES);
+  return MJX_OK;
+}
+
+int mjx_comm_init(mjx_ctx* c, int rank, int world, const char* id_host) {
+  if (!c || !id_host || world < 1 || rank < 0 || rank >= world) return fail(MJX_ERR_ARG, "bad arguments");
+  if (c->comm) return fail(MJX_ERR_STATE, "a communicator is already attached");
+  RcclApi& r = rccl();
+  if (!r.load()) return fail(MJX_ERR_UNSUPPORTED, "%s", r.error.c_str());
+  HIPCHK(hipSetDevice(c->device));
+  RcclApi::UniqueId id;
+  memcpy(id.internal, id_host, MJX_COMM_ID_BYTES);
+  RcclApi::Comm comm = nullptr;
+  if (int rc = r.CommInitRank(&comm, world, id, rank)) return fail(1000 + rc, "ncclCommInitRank: %s", r.GetErrorString(rc));
+  c->comm = comm; c->comm_world = world; c->comm_rank = rank;
+  return MJX_OK;
+}
+
+int mjx_comm_destroy(mjx_ctx* c) {
+  if (!c) return fail(MJX_ERR_ARG, "null context");
+  if (c->comm) {
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    (void)rccl().CommDestroy(c->comm);
+    c->comm = nullptr; c->comm_world = 0;
+  }
+  return MJX_OK;
+}
+
+int mjx_comm_world(const mjx_ctx* c) { return (c && (c->comm || c->reduce_cb)) ? c->comm_world : 0; }
+
+int mjx_comm_set_callback(mjx_ctx* c, mjx_reduce_fn fn, void* user, int world) {
+  if (!c || (fn && world < 1)) return fail(MJX_ERR_ARG, "bad arguments");
+  if (c->comm) return fail(MJX_ERR_STATE, "an RCCL communicator is attached");
+  c->reduce_cb = fn; c->reduce_user = user; c->comm_world = fn ? world : 0;
+  return MJX_OK;
+}
+
+int mjx_comm_allreduce(mjx_ctx* c, void* buf, int64_t count, int dtype, void* stream) {
+  if (!c || !buf || count < 0 || (dtype != 0 && dtype != 1)) return fail(MJX_ERR_ARG, "bad arguments");
+  if (count == 0) return MJX_OK;
+  if (!c->comm) {
+    if (!c->reduce_cb) return fail(MJX_ERR_STATE, "no communicator attached (mjx_comm_init)");
+    if (int rc = c->reduce_cb(c->reduce_user, buf, count, dtype, stream)) return fail(rc, "transport hook failed (%d)", rc);
+    return MJX_OK;
+  }
+  RcclApi& r = rccl();
+  if (int rc = r.AllReduce(buf, buf, (size_t)count, dtype ? RcclApi::kFloat64 : RcclApi::kFloat32, RcclApi::kSum, c->comm, stream))
+    return fail(1000 + rc, "ncclAllReduce: %s", r.GetErrorString(rc));
+  return MJX_OK;
+}
+
+int mjx_npg_update(mjx_ctx* c, int iters, float damping, double tol, double step_size, double const_alpha, float min_log_std,
+                   float* grad_out, float* x_out, float* theta_out, double* results, void* stream) {
+  if (int rc = check_bound(c, true)) return rc;
+  if (!grad_out || !x_out || !theta_out || !results || iters < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (!c->old_is_new) return fail(MJX_ERR_STATE, "mjx_npg_update starts from theta_new == theta_old (mjx_bind_policy with old_is_new)");
+  if (theta_out == c->theta_old) return fail(MJX_ERR_ARG, "theta_out must not alias theta_old");
+  if (int rc = mjx_surr_vpg(c, grad_out, results + 4, stream)) return rc;
+  if (c->comm) {
+    RcclApi& r = rccl();
+    (void)r.GroupStart();                       // one launch for the gradient and its scalars
+    int rc = mjx_comm_allreduce(c, grad_out, c->d, 0, stream);
+    if (!rc) rc = mjx_comm_allreduce(c, results + 4, 4, 1, stream);
+    const int ge = r.GroupEnd();
+    if (rc) return rc;
+    if (ge) return fail(1000 + ge, "ncclGroupEnd: %s", r.GetErrorString(ge));
+  } else if (c->reduce_cb) {
+    if (int rc = mjx_comm_allreduce(c, grad_out, c->d, 0, stream)) return rc;
+    if (int rc = mjx_comm_allreduce(c, results + 4, 4, 1, stream)) return rc;
+  }
+  if (int rc = mjx_cg_solve(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream)) return rc;
+  const float* base = c->theta_old;               // == theta_new in value; theta_out may be the theta_new buffer itself
+  if (const_alpha > 0.0) { if (int rc = mjx_apply_step(c, base, x_out, (float)const_alpha, min_log_std, theta_out, stream)) return rc; }
+  else if (int rc = mjx_apply_npg_step(c, base, x_out, results + 8, step_size, min_log_std, theta_out, results + 9, stream)) return rc;
+  if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc;
+  if (int rc = mjx_eval_surr_kl(c, results, stream)) return rc;
+  if (c->comm || c->reduce_cb) if (int rc = mjx_comm_allreduce(c, results, 4, 1, stream)) return rc;
+  return MJX_OK;
 }
 
 int mjx_apply_step(mjx_ctx* c, const float* theta, const float* x, float alpha, float min_log_std, float* theta_out, void* stream) {

@@ -29,6 +29,25 @@ def _dist():
     return None
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """file descriptor 1 -> 2 for the duration (native libraries that print banners to stdout; a caller's stdout may be a
+    machine-readable stream, e.g. bench.py's single JSON line)"""
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class HipBackend:
     """Local (this-rank) compute: thin ctypes shim over libmjx.so.  All arguments are torch tensors
     living on ``self.device``; nothing here communicates or synchronises."""
@@ -105,6 +124,50 @@ class HipBackend:
     def cg_finish(self, b, x_out, bdotx_out):
         check(self.lib.mjx_cg_finish(self.ctx, ptr(b), ptr(x_out), ptr(bdotx_out), self.stream()))
 
+    # ---- multi-rank (RCCL inside libmjx, include/mjx.h "multi-rank")
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        check(self.lib.mjx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, world, uid):
+        check(self.lib.mjx_comm_init(self.ctx, int(rank), int(world), ctypes.create_string_buffer(bytes(uid), 128)))
+
+    def comm_world(self):
+        return int(self.lib.mjx_comm_world(self.ctx))
+
+    def comm_set_callback(self, dist, world):
+        """rank sums through `dist.all_reduce` (any torch.distributed backend) as libmjx's transport hook: the C loops
+        of mjx_cg_solve / mjx_npg_update call back between their launches.  For process groups that are not RCCL (the
+        tests put two gloo ranks on one GPU); every call costs a stream synchronisation."""
+        torch, dev = self.torch, self.device
+
+        class _View:                                  # zero-copy tensor over a device pointer
+            def __init__(self, p, count, typestr):
+                self.__cuda_array_interface__ = dict(shape=(int(count),), typestr=typestr, data=(int(p), False), version=2)
+
+        def hook(user, buf, count, dtype, stream):
+            try:
+                torch.cuda.current_stream(dev).synchronize()
+                t = torch.as_tensor(_View(buf, count, "<f8" if dtype else "<f4"), device=dev)
+                dist.all_reduce(t)
+                torch.cuda.current_stream(dev).synchronize()
+                return 0
+            except Exception:                         # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return -5
+        self._hook = _lib.REDUCE_FN(hook)             # keep the trampoline alive as long as the context
+        check(self.lib.mjx_comm_set_callback(self.ctx, self._hook, None, int(world)))
+
+    def allreduce(self, t):
+        """in-place sum over the ranks on the launch stream (fp32 / fp64 tensors)"""
+        check(self.lib.mjx_comm_allreduce(self.ctx, ptr(t), t.numel(), 1 if t.dtype == self.torch.float64 else 0, self.stream()))
+
+    def npg_update(self, iters, damping, tol, step_size, const_alpha, min_log_std, grad_out, x_out, theta_out, results):
+        check(self.lib.mjx_npg_update(self.ctx, int(iters), float(damping), float(tol), float(step_size), float(const_alpha or 0.0),
+                                      float(min_log_std), ptr(grad_out), ptr(x_out), ptr(theta_out), ptr(results), self.stream()))
+
     def apply_step(self, base, x, alpha, min_log_std, out):
         check(self.lib.mjx_apply_step(self.ctx, ptr(base), ptr(x), float(alpha), float(min_log_std), ptr(out), self.stream()))
 
@@ -145,6 +208,7 @@ class UpdateEngine:
         self._block = self._prefix = None
         self.old_is_new = True
         self._dbg = None
+        self._comm_state = None                     # None: not tried yet; True: libmjx holds an RCCL communicator; False: torch collectives
 
     # convenience handles used by bench / tests
     @property
@@ -238,16 +302,52 @@ class UpdateEngine:
         if self._prefix is not None:
             self.backend.bind_rows(*self._prefix)
 
+    # ------------------------------------------------------------------ collectives
+    def _native_comm(self):
+        """True when the rank sums run inside libmjx (ncclAllReduce on the launch stream, include/mjx.h): tried once, when
+        torch.distributed runs on the nccl (= RCCL) backend -- every rank then owns its GPU.  The communicator id is made
+        by rank 0 and broadcast through the process group.  Any failure leaves the torch.distributed collectives in
+        place (MJX_NATIVE_COMM=0 forces that)."""
+        if self._comm_state is not None:
+            return self._comm_state
+        d = _dist()
+        ok = False
+        if d is not None and hasattr(self.backend, "comm_init") and os.environ.get("MJX_NATIVE_COMM", "1") != "0":
+            try:
+                if d.get_backend() == "nccl":
+                    box = [self.backend.comm_unique_id() if d.get_rank() == 0 else None]
+                    if d.get_world_size() > 1:
+                        d.broadcast_object_list(box, src=0)
+                    with _stdout_to_stderr():         # RCCL prints a version banner to stdout when a communicator is created
+                        self.backend.comm_init(d.get_rank(), d.get_world_size(), box[0])
+                else:                                # e.g. gloo ranks sharing one GPU (tests): same C loops, hooked transport
+                    self.backend.comm_set_callback(d, d.get_world_size())
+                ok = True
+            except Exception as e:                   # pragma: no cover - depends on the host's RCCL
+                import warnings
+                warnings.warn("mjrl_amd: rank sums inside libmjx unavailable (%s); using torch.distributed collectives" % (e,))
+        self._comm_state = ok
+        return ok
+
+    def _rank_sum(self, *tensors):
+        """sum device tensors over the ranks in place (no-op for a single process)"""
+        d = _dist()
+        if d is None:
+            return
+        if self._native_comm():
+            for t in tensors:
+                self.backend.allreduce(t)
+        else:
+            for t in tensors:
+                d.all_reduce(t)
+
     # ------------------------------------------------------------------ kernels + collectives
     def surr_vpg(self, sync=True):
         """K1 -> (grad device tensor, surrogate float).  flat_vpg + CPI_surrogate
         (batch_reinforce.py:40-58).  sync=False: nothing is read back (see deferred())."""
         self._host_results = None
         self.backend.surr_vpg(self.grad, self.scal_vpg)
-        d = _dist()
-        if d is not None:
-            d.all_reduce(self.grad)
-            d.all_reduce(self.scal_vpg)
+        self._rank_sum(self.grad, self.scal_vpg)
         if not sync:
             return self.grad, None                   # the surrogate stays on the device: read it with deferred()
         s = self.scal_vpg.cpu().numpy()
@@ -257,9 +357,7 @@ class UpdateEngine:
         """K2: (H v) without damping, reduced over ranks (npg_cg.py:62-81)."""
         out = self.Ap if out is None else out
         self.backend.fvp(v, out)
-        d = _dist()
-        if d is not None:
-            d.all_reduce(out)
+        self._rank_sum(out)
         return out
 
     def cg_solve(self, b, iters, damping, tol=1e-10, sync=True):
@@ -269,7 +367,8 @@ class UpdateEngine:
         d = _dist()
         be = self.backend
         self._host_results = None
-        if d is None:
+        if d is None or self._native_comm():
+            # one C call: iters x (K2, [ncclAllReduce on the launch stream,] vector update), nothing in between
             be.cg_solve_local(b, iters, damping, tol, self.x, self.bdotx)
         else:
             be.cg_init(b)
@@ -296,6 +395,27 @@ class UpdateEngine:
         self.old_is_new = False
         self._bind_policy()
 
+    def npg_update(self, iters, damping, step_size, min_log_std, const_alpha=None, tol=1e-10):
+        """The whole NPG update (npg_cg.py:108-142: K1, CG, step length, step, K3) enqueued by ONE call into libmjx
+        (mjx_npg_update), rank sums included -> (surr_after, kl); deferred() has surr_before / g.x / alpha.
+        Needs theta_new == theta_old at entry; the torch.distributed fallback path (no RCCL inside libmjx) issues the same
+        sequence call by call."""
+        assert self.old_is_new, "npg_update starts from theta_new == theta_old"
+        d = _dist()
+        if (d is None or self._native_comm()) and hasattr(self.backend, "npg_update"):
+            self._host_results = None
+            self.backend.npg_update(iters, damping, tol, step_size, const_alpha, min_log_std, self.grad, self.x, self.theta_new, self.results)
+            self.old_is_new = False
+            s = self._host_results = self.results.cpu().numpy()
+            return float(s[0] / self.N_global), float(s[1] / self.N_global)
+        g, _ = self.surr_vpg(sync=False)
+        self.cg_solve(g, iters, damping, tol, sync=const_alpha is not None)
+        if const_alpha is not None:
+            self.apply_step(const_alpha, min_log_std)
+        else:
+            self.apply_npg_step(step_size, min_log_std)
+        return self.eval_surr_kl()
+
     def deferred(self):
         """-> dict(surr_before, gdotx, alpha) of the calls made with sync=False / apply_npg_step (one read-back after the update)"""
         r = self._host_results                       # eval_surr_kl() already fetched the block: no further round trip
@@ -306,9 +426,7 @@ class UpdateEngine:
     def eval_surr_kl(self):
         """K3 -> (surrogate, mean KL) (batch_reinforce.py:40-52)."""
         self.backend.eval_surr_kl(self.scal)
-        d = _dist()
-        if d is not None:
-            d.all_reduce(self.scal)
+        self._rank_sum(self.scal)
         s = self._host_results = self.results.cpu().numpy()      # the whole block: deferred() needs no second read-back
         return float(s[0] / self.N_global), float(s[1] / self.N_global)
 

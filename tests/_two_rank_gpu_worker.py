@@ -37,6 +37,14 @@ def main():
     late = eng.deferred()
     res = dict(grad=g.cpu().numpy(), x=eng.x.cpu().numpy(), theta=eng.theta_new.cpu().numpy(),
                scal=np.array([late["surr_before"], late["gdotx"], late["alpha"], surr_after, kl]))
+    # the rank sums ran inside libmjx's C loops (transport hook over gloo; over RCCL on a real multi-GPU node) ...
+    res["native_comm"] = np.array([bool(eng._native_comm()), eng.backend.comm_world() == world])
+    # ... and the whole update as ONE call (mjx_npg_update) gives the same bits as the call-by-call sequence
+    eng.set_policy(th, th, ident, ident)
+    sa2, kl2 = eng.npg_update(10, 1e-4, 0.05, -3.0)
+    late2 = eng.deferred()
+    res["one_call_equal"] = np.array([np.array_equal(eng.x.cpu().numpy(), res["x"]) and np.array_equal(eng.theta_new.cpu().numpy(), res["theta"])
+                                      and sa2 == surr_after and kl2 == kl and late2 == late])
     # every rank must hold identical results (the CG scalars are recomputed redundantly from the reduced vectors)
     t = torch.from_numpy(np.concatenate([res["x"], res["theta"], res["scal"].astype(np.float32)])).cuda()
     lo_t, hi_t = t.clone(), t.clone()

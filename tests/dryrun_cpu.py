@@ -29,6 +29,7 @@ DEFAULT = [
     ("test_const_learn_rate_branch", ("npg_pointmass_32x32",)),
     ("test_dapg_with_hvp_sample_frac_draws_from_the_on_policy_rows", ()),
 ]
+# (test_one_call_update_equals_call_sequence needs the real library: the oracle stand-in has no mjx_npg_update)
 
 if __name__ == "__main__":
     want = sys.argv[1:]

@@ -250,3 +250,71 @@ def test_whole_update_at_the_baseline_size():
     assert rel(step[::s], g["step_sub"]) < TOL_STEP
     assert abs(np.linalg.norm(step) - float(g["step_norm"])) < 1e-5 * float(g["step_norm"])
     eng.close()
+
+
+@pytest.mark.parametrize("name,layerwise", [("npg_cfg2_small", False), ("npg_cfg2_ragged_tr", False), ("npg_pointmass_32x32", True)])
+def test_one_call_update_equals_call_sequence(name, layerwise, monkeypatch):
+    """mjx_npg_update (K1, CG, device-side step length, step, K3 enqueued by one C call) == the same kernels driven call
+    by call from Python, bit for bit; and == the reference's update."""
+    from mjrl_amd.engine import UpdateEngine
+    c = NpgCase(name)
+    if layerwise:
+        monkeypatch.setenv("MJX_FORCE_LAYERWISE", "1")
+    tr = np.concatenate([np.float32(x).ravel() for x in c.tr]) if c.tr is not None else \
+        np.concatenate([np.zeros(c.n), np.ones(c.n), np.zeros(c.m), np.ones(c.m)]).astype(np.float32)
+    step = float(c.g["step"])
+    out = []
+    for one_call in (False, True):
+        eng = UpdateEngine(c.n, c.m, c.hidden)
+        eng.set_policy(c.theta0, c.theta0, tr, tr)
+        eng.set_batch(c.obs, c.act, c.adv_w)
+        if one_call:
+            sa, kl = eng.npg_update(c.cg_iters, 1e-4, step, -3.0)
+        else:
+            g, _ = eng.surr_vpg(sync=False)
+            eng.cg_solve(g, c.cg_iters, 1e-4, sync=False)
+            eng.apply_npg_step(step, -3.0)
+            sa, kl = eng.eval_surr_kl()
+        out.append((eng.theta_new.cpu().numpy().copy(), eng.x.cpu().numpy().copy(), eng.grad.cpu().numpy().copy(), sa, kl, eng.deferred()))
+        assert not eng.old_is_new
+        eng.close()
+    a, b = out
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3:] == b[3:]
+    stp = b[0].astype(np.float64) - c.theta0
+    assert rel(stp, c.g["new_params"].astype(np.float64) - c.theta0) < TOL_STEP
+    assert abs(b[5]["alpha"] - float(c.g["alpha"])) < 1e-5 * float(c.g["alpha"])
+    # the constant-step-size branch of the same entry point (npg_cg.py:128-130)
+    eng = UpdateEngine(c.n, c.m, c.hidden)
+    eng.set_policy(c.theta0, c.theta0, tr, tr)
+    eng.set_batch(c.obs, c.act, c.adv_w)
+    eng.npg_update(c.cg_iters, 1e-4, step, -3.0, const_alpha=0.2)
+    assert rel(eng.theta_new.cpu().numpy().astype(np.float64) - c.theta0, 0.2 * c.g["cg_x"].astype(np.float64)) < TOL_STEP
+    eng.close()
+
+
+def test_rccl_inside_libmjx_one_rank_group():
+    """the RCCL binding of libmjx (dlopen, ncclCommInitRank, ncclAllReduce on the launch stream) on a 1-rank
+    communicator: sums are identities, the C loops with the collectives in place give the single-process bits."""
+    import ctypes
+    import torch
+    from mjrl_amd._lib import check
+    from mjrl_amd.engine import UpdateEngine
+    c = NpgCase("npg_cfg2_small")
+    tr = np.concatenate([np.zeros(c.n), np.ones(c.n), np.zeros(c.m), np.ones(c.m)]).astype(np.float32)
+    res = []
+    for with_comm in (False, True):
+        eng = UpdateEngine(c.n, c.m, c.hidden)
+        if with_comm:
+            eng.backend.comm_init(0, 1, eng.backend.comm_unique_id())
+            assert eng.backend.comm_world() == 1
+            t = torch.arange(7, dtype=torch.float32, device=eng.device) + 0.5
+            t64 = torch.arange(5, dtype=torch.float64, device=eng.device) - 2.25
+            eng.backend.allreduce(t); eng.backend.allreduce(t64)
+            torch.cuda.synchronize()
+            assert torch.equal(t.cpu(), torch.arange(7, dtype=torch.float32) + 0.5) and torch.equal(t64.cpu(), torch.arange(5, dtype=torch.float64) - 2.25)
+        eng.set_policy(c.theta0, c.theta0, tr, tr)
+        eng.set_batch(c.obs, c.act, c.adv_w)
+        sa, kl = eng.npg_update(c.cg_iters, 1e-4, float(c.g["step"]), -3.0)
+        res.append((eng.theta_new.cpu().numpy().copy(), sa, kl))
+        eng.close()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1:] == res[1][1:]
