@@ -95,12 +95,102 @@ def cpu_baseline(theta0, sample_traj):
     torch.set_num_threads(default_threads)
     n = obs.shape[0]
     ups = (n / float(N_TRAJ * T)) / dt                            # linear-in-N extrapolation to 1M
-    return dict(value=ups, unit="updates/s", cores=int(best), kind="port",
+    kind, validation = "port", None
+    vf = os.path.join(ROOT, "tests", "golden", "cpu_port_vs_reference.json")
+    if os.path.exists(vf):
+        validation = json.load(open(vf))
+        kind = "port (validated vs reference: %.2f)" % validation["port_over_reference"]
+    return dict(value=ups, unit="updates/s", cores=int(best), kind=kind,
+                validation=None if validation is None else dict(
+                    what="wall time of this port / wall time of the unmodified reference's NPG.train_from_paths on the same "
+                         "%d-timestep batch, best of 3 each, %d threads, build container (tests/golden/make_cpu_port_validation.py)"
+                         % (validation["timesteps"], validation["threads"]),
+                    port_over_reference=validation["port_over_reference"], step_rel_difference=validation["step_rel_difference"]),
+                reference_probe=dict(value=0.0576, unit="updates/s", cores=8,
+                                     what="the unmodified reference, one NPG update on the full 1M-timestep batch, 8-vCPU build container "
+                                          "(BASELINE.md section 2 / SURVEY section 6: 17.4 s)"),
                 sample="%d-timestep slice (%d traj) of the 1M batch, one NPG update in %.2f s on torch-CPU "
                        "(autograd double-backward HVP, as the reference) with %d intra-op threads (best of %s on a "
                        "%d-sample calibration), scaled linearly to 1M" % (n, sample_traj, dt, best,
                                                                           {k: round(v, 2) for k, v in cal.items()}, ncal),
                 seconds=dt, nproc=os.cpu_count())
+
+
+def secondary_measurements(eng, theta0, theta0_dev):
+    """Measured AFTER the primary timed region, on the same GPU (N = 1):
+    * BASELINE configs[2]: one TRPO update (KL line search, mjrl/algos/trpo.py:100-126) on the same 1M batch -- K1, CG,
+      then backtracking evaluations of K3 until KL < kl_dist (kl_dist = 0.025: the first step length is rejected);
+    * the layer-wise path at the per-GPU shard sizes of configs[3] / [4] (the 8-GPU configs this 1-GPU run cannot time
+      as a whole): HIP-event time of the Fisher-vector-product chain and its rate against the fp32-MFMA peak."""
+    import torch
+    from mjrl_amd._lib import check
+    from mjrl_amd.engine import UpdateEngine
+    out = {}
+    # ---- TRPO
+    kl_dist, trials_log = 0.025, []
+
+    def trpo_update():
+        g, _ = eng.surr_vpg(sync=False)
+        _, gx = eng.cg_solve(g, CG_ITERS, DAMPING)
+        alpha = np.sqrt(np.abs(2.0 * kl_dist / (gx + 1e-20)))
+        trials = 0
+        for k in range(100):
+            eng.apply_step(alpha, -3.0)
+            _, kl = eng.eval_surr_kl()
+            trials += 1
+            if kl < kl_dist:
+                break
+            alpha = 0.9 * alpha
+        eng.apply_step(alpha, -3.0)
+        eng.eval_surr_kl()
+        trials_log.append(trials)
+        eng.theta_new.copy_(theta0_dev); eng.old_is_new = True; eng._bind_policy()
+    trpo_update()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5):
+        trpo_update()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / 5
+    out["trpo_configs2"] = {"updates_per_s": 1e3 / ms, "ms_per_update": ms, "kl_dist": kl_dist, "line_search_trials": trials_log[-1],
+                            "workload": "BASELINE configs[2]: the same 1M-timestep batch and 64x64 policy, TRPO with KL line search"}
+    # ---- layer-wise FVP at the shard sizes of the 8-GPU configs
+    lw = {}
+    for name, n, m, hid, N in (("configs3_humanoid_256x256", 376, 17, (256, 256), 500000), ("configs4_adroit_512x512", 39, 28, (512, 512), 1000000)):
+        gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+        e = UpdateEngine(n, m, hid)
+        rng = np.random.RandomState(1)
+        sizes = (n,) + tuple(hid) + (m,)
+        flat = []
+        for i in range(len(sizes) - 1):
+            k = 1.0 / np.sqrt(sizes[i])
+            flat += [rng.uniform(-k, k, (sizes[i + 1], sizes[i])).ravel() * (1e-2 if i == len(sizes) - 2 else 1.0), rng.uniform(-k, k, sizes[i + 1])]
+        flat.append(np.full(m, -0.5))
+        th = np.concatenate(flat).astype(np.float32)
+        th = (th + 0.02 * np.random.RandomState(1).randn(th.size)).astype(np.float32)
+        ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+        e.set_policy(th, th, ident, ident)
+        e.set_batch(torch.randn((N, n), generator=gen, device="cuda"), torch.randn((N, m), generator=gen, device="cuda"),
+                    torch.randn((N,), generator=gen, device="cuda"))
+        grad = e.surr_vpg()[0].clone()
+        e.fvp(grad)
+        torch.cuda.synchronize()
+        check(e.lib.mjx_profile_enable(e.ctx, 1))
+        for _ in range(4):
+            e.fvp(grad)
+        prof = (ctypes.c_double * 2)()
+        check(e.lib.mjx_profile_read(e.ctx, prof))
+        check(e.lib.mjx_profile_enable(e.ctx, 0))
+        P = sum(sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1))
+        flop = 2 * (4 * P - 2 * n * hid[0]) * N
+        ms = prof[0] / prof[1]
+        lw[name] = {"rows": N, "fvp_ms": ms, "TFLOPs": flop / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+                    "flop_per_fvp": flop, "kernels": "k_gemm<128,256> / <128,128> / <128,32> chain with fused epilogues (csrc/layerwise.h)",
+                    "timed": "4 products, HIP events around the whole chain of one product"}
+        e.close()
+        del e
+        torch.cuda.empty_cache()
+    out["roofline_lw"] = lw
+    return out
 
 
 def main():
@@ -112,6 +202,12 @@ def main():
     ap.add_argument("--fvp-event-stride", type=int, default=11,
                     help="bracket every k-th Fisher-vector-product launch with HIP events (k coprime to the CG iteration count: every CG position is sampled equally); 0: none")
     ap.add_argument("--cpu-sample-traj", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="the timed region (barrier + synchronize, EXACTLY --steps updates, barrier + synchronize) is run this many "
+                         "times; `value` is the median repeat, all repeats are reported")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (TRPO line-search update = BASELINE configs[2]; layer-wise FVP at the "
+                         "per-GPU shard sizes of configs[3] / [4]); they run after the primary timed region, N = 1 only")
     ap.add_argument("--rehearse-world", type=int, default=0,
                     help="diagnostic, 1 GPU: run rank 0's share of an R-rank job (1/R of the batch, global N, "
                          "RCCL collectives on a 1-rank group); the line is tagged 'rehearsal' and is not the metric")
@@ -188,19 +284,24 @@ def main():
         one_update()
     fence()
     check(eng.lib.mjx_profile_enable(eng.ctx, args.fvp_event_stride))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_update()
-    fence()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(max(1, args.repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_update()
+        fence()
+        dts.append(time.perf_counter() - t0)
     prof = (ctypes.c_double * 2)()
     check(eng.lib.mjx_profile_read(eng.ctx, prof))
     check(eng.lib.mjx_profile_enable(eng.ctx, 0))
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor(dts, dtype=torch.float64, device="cuda")
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)          # per repeat: the slowest rank
+    dts = sorted(float(x) for x in tmax.cpu())
+    dt = dts[len(dts) // 2] if len(dts) % 2 else 0.5 * (dts[len(dts) // 2 - 1] + dts[len(dts) // 2])     # the median repeat
 
+    failed = False
     if rank == 0:
         fvp_ms = prof[0] / prof[1] if prof[1] > 0 else float("nan")      # (--fvp-event-stride 0: no roofline figures)
         P = N_OBS * 64 + 64 * 64 + 64 * N_ACT
@@ -214,11 +315,15 @@ def main():
         flop_recompute = 2 * (5 * P - 2 * N_OBS * 64)                # 51 328 @cfg2
         n_loc = eng.N_local
         achieved_tf = flop_per_sample * n_loc / (fvp_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_fvp_pmc.json")
-        if os.path.exists(pmc) and world == 1:
+        traffic, traffic_source = None, None
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fvp_pmc.json")))
+        if pmcs and world == 1:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmcs[-1])).get("hbm_bytes_per_launch")
+                traffic_source = ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over an EARLIER run of this command "
+                                  "(tools/profile_bench.sh); a constant read from the file, not measured by this run"
+                                  % os.path.relpath(pmcs[-1], ROOT))
             except Exception:
                 traffic = None
         out = {
@@ -238,26 +343,44 @@ def main():
                        "cg_iters": CG_ITERS, "damping": DAMPING},
             "roofline": {"bound": "mfma", "kernel": "k_fused<64,64,1,8,MODE_FVP,NP=20,CACHED>",
                          "achieved": achieved_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP32_MFMA_PEAK_TF, "traffic": traffic,
+                         "frac": achieved_tf / FP32_MFMA_PEAK_TF, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": fvp_ms, "launches": int(prof[1]),
-                         "launches_timed": "every %d-th of %d (HIP events on the launch stream, inside the timed region)" % (max(args.fvp_event_stride, 1), args.steps * CG_ITERS),
+                         "launches_timed": "every %d-th of %d (HIP events on the launch stream, inside the timed regions)" % (max(args.fvp_event_stride, 1), args.steps * CG_ITERS * len(dts)),
                          "flop_per_launch": flop_per_sample * n_loc,
                          "algorithmic_bytes_per_launch": bytes_per_sample * n_loc,
                          "hbm_GBps_algorithmic": bytes_per_sample * n_loc / (fvp_ms * 1e-3) / 1e9,
                          "hbm_frac_algorithmic": bytes_per_sample * n_loc / (fvp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "fvp_equivalent_TFLOPs_if_recomputed": flop_recompute * n_loc / (fvp_ms * 1e-3) / 1e12},
+            "timing": {"repeats": len(dts), "ms_per_step_each_repeat_sorted": [1e3 * x / args.steps for x in dts],
+                       "ms_per_step_min": 1e3 * dts[0] / args.steps, "ms_per_step_median": 1e3 * dt / args.steps,
+                       "value_is": "steps / median repeat (each repeat: barrier + synchronize, exactly `steps` updates, barrier + synchronize; max over ranks)"},
             "check": last,
         }
+        # the update's scalars against the fp64 oracle on this very batch (tests/golden/bench_cfg2_1m.npz, 125 s of CPU to
+        # regenerate: tests/golden/make_golden_big.py): a drift beyond the 1e-5 parity bar fails the run loudly
+        fx = os.path.join(ROOT, "tests", "golden", "bench_cfg2_1m.npz")
+        if os.path.exists(fx) and args.rehearse_world <= 1:
+            g = np.load(fx)
+            drift = {k: abs(last[k] - float(g[k])) / abs(float(g[k])) for k in ("alpha", "kl", "surr_improvement")}
+            out["check_vs_fp64_oracle"] = {"rel_error": drift, "bar": 1e-5, "fixture": "tests/golden/bench_cfg2_1m.npz"}
+            if max(drift.values()) > 1e-5:
+                print(json.dumps({"error": "update drifted from the fp64 oracle beyond 1e-5", "drift": drift, "check": last}), file=sys.stderr, flush=True)
+                failed = True
         if args.rehearse_world > 1:
             out["rehearsal"] = "rank 0 of %d on one GPU, 1-rank RCCL group: NOT the metric" % args.rehearse_world
             out["roofline"]["traffic"] = None
+        if world == 1 and not args.no_secondary and args.rehearse_world <= 1:
+            out["secondary"] = secondary_measurements(eng, theta0, theta0_dev)
         if world == 1 and not args.no_cpu_baseline and args.rehearse_world <= 1:
             out["cpu_baseline"] = cpu_baseline(theta0, args.cpu_sample_traj)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        if not failed:
+            print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -75,7 +75,7 @@ class BatchREINFORCE:
     def flat_vpg(self, observations, actions, advantages):
         """flattened gradient of the CPI surrogate as a float32 ndarray -- batch_reinforce.py:54-58."""
         self._bind(observations, actions, advantages)
-        return self.engine.surr_vpg()[0].cpu().numpy()
+        return self.engine.to_host(self.engine.surr_vpg()[0])
 
     # ------------------------------------------------------------------ main loop step
     def train_step(self, N, env=None, sample_mode='trajectories', horizon=1e6, gamma=0.995, gae_lambda=0.97,
@@ -134,7 +134,7 @@ class BatchREINFORCE:
                 alpha = alpha / 2.0
                 eng.apply_step(alpha, self.policy.min_log_std)
         surr_after, kl_dist = eng.eval_surr_kl()
-        self.policy.set_param_values(eng.theta_new.cpu().numpy(), set_new=True, set_old=True)
+        self.policy.set_param_values(eng.to_host(eng.theta_new), set_new=True, set_old=True)
         if self.save_logs:
             self.logger.log_kv('alpha', self.alpha)
             self.logger.log_kv('time_vpg', t_gLL)
@@ -154,19 +154,38 @@ class BatchREINFORCE:
         advantages, base_stats, running_score = self._advantages_and_statistics(paths)
         return observations, actions, advantages, base_stats, running_score
 
-    def _advantages_and_statistics(self, paths):
-        advantages = np.concatenate([path["advantages"] for path in paths])
-        path_returns = np.array([float(np.sum(p["rewards"])) for p in paths])
+    def _path_statistics(self, paths):
+        """[mean, std, min, max] of the path returns over all ranks and the running score (batch_reinforce.py:187-196)"""
+        path_returns = None
+        eng = self._engine_obj
+        if eng is not None and eng.device.type == "cuda" and len(paths) > 64:
+            # the rewards were staged back to back in a page-locked block by compute_returns: one vectorised segmented sum
+            # instead of a NumPy call per path (4 ms per 1 000 paths)
+            from ..utils import ingest
+            blk = ingest.host_block(eng.backend, paths, "rewards")
+            if blk is not None:
+                lens = np.fromiter((len(p["rewards"]) for p in paths), dtype=np.int64, count=len(paths))
+                if lens.min() > 0:
+                    starts = np.zeros(len(paths), np.int64)
+                    np.cumsum(lens[:-1], out=starts[1:])
+                    path_returns = np.add.reduceat(blk.reshape(-1), starts)
+        if path_returns is None:
+            path_returns = np.fromiter((float(np.sum(p["rewards"])) for p in paths), dtype=np.float64, count=len(paths))
         d = _dist()
         if d is not None:
             gathered = [None] * d.get_world_size()
             d.all_gather_object(gathered, path_returns)
             path_returns = np.concatenate(gathered)
-        mean, std = self._global_mean_std(advantages)
-        advantages = (advantages - mean) / (std + 1e-6)
         mean_return = np.mean(path_returns)
         base_stats = [mean_return, np.std(path_returns), np.amin(path_returns), np.amax(path_returns)]
         running_score = mean_return if self.running_score is None else 0.9 * self.running_score + 0.1 * mean_return
+        return base_stats, running_score
+
+    def _advantages_and_statistics(self, paths):
+        advantages = np.concatenate([path["advantages"] for path in paths])
+        mean, std = self._global_mean_std(advantages)
+        advantages = (advantages - mean) / (std + 1e-6)
+        base_stats, running_score = self._path_statistics(paths)
         return advantages, base_stats, running_score
 
     def _staging_pool(self):
@@ -198,9 +217,18 @@ class BatchREINFORCE:
         # the gather / upload of observations and actions runs on a helper thread (native memcpy threads + asynchronous
         # copies, no GIL) while this thread assembles the advantage vector and the path statistics
         eng = self.engine
+        from ..utils import ingest
+        # (asked before the staging job starts: the helper thread holds the registry lock while it stages)
+        adv64 = ingest.lookup(eng.backend, paths, "advantages") if eng.device.type == "cuda" else None
         fut = self._staging_pool().submit(self._stage_on_callers_stream(), paths, ("observations", "actions"))
         try:
-            advantages, base_stats, self.running_score = self._advantages_and_statistics(paths)
+            if adv64 is not None:
+                # the advantages never left the device (utils/process_samples.compute_advantages): whitening statistics
+                # and the fp32 cast happen there; only the per-path return statistics are host work
+                advantages = eng.whitened_advantages(adv64)
+                base_stats, self.running_score = self._path_statistics(paths)
+            else:
+                advantages, base_stats, self.running_score = self._advantages_and_statistics(paths)
         finally:
             staged = fut.result()
         self._push_policy()

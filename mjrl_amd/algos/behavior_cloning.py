@@ -12,6 +12,7 @@ import numpy as np
 
 from .._lib import check, ptr
 from ..engine import UpdateEngine
+from ..utils.ingest import upload
 from ..utils.logger import DataLog
 
 LOSS_IDS = {"MSE": 0, "MLE": 1}
@@ -94,12 +95,12 @@ class BC:
             act = eng.to_device_f32(data["expert_actions"])
             if self._adam is None:
                 self._adam = [torch.zeros_like(theta), torch.zeros_like(theta), 0]
-            didx = torch.from_numpy(idx).to(eng.device)
+            didx = upload(eng.backend, idx)
             check(eng.lib.mjx_policy_minibatch_adam(eng.ctx, LOSS_IDS[self.loss_type], ptr(obs), ptr(act), None, ptr(didx), steps,
                                                     self.mb_size, ptr(theta), ptr(tr), None, None, 0, ptr(self._adam[0]),
                                                     ptr(self._adam[1]), self._adam[2], self.lr, 0.0, None, eng.stream()))
             self._adam[2] += steps
-            p.set_param_values(theta.cpu().numpy(), set_new=True, set_old=True)
+            p.set_param_values(eng.to_host(theta), set_new=True, set_old=True)
         else:
             p = self.policy
             p.set_param_values(p.get_param_values(), set_new=True, set_old=True)

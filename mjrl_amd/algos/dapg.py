@@ -82,7 +82,7 @@ class DAPG(NPG):
         alpha = np.sqrt(np.abs(n_step_size / (gdotx + 1e-20)))
         eng.apply_step(alpha, self.policy.min_log_std)
         surr_after, kl_dist = eng.eval_surr_kl()
-        self.policy.set_param_values(eng.theta_new.cpu().numpy(), set_new=True, set_old=True)
+        self.policy.set_param_values(eng.to_host(eng.theta_new), set_new=True, set_old=True)
 
         if self.save_logs:
             self._log_update(paths, alpha, n_step_size, t_gLL, t_FIM, kl_dist, surr_before, surr_after)

@@ -64,7 +64,7 @@ class NPG(BatchREINFORCE):
         a host vector; returns (x device tensor, b.x).  sync=False leaves b.x on the device (engine.deferred())."""
         eng = self.engine
         if not hasattr(b, "data_ptr"):
-            b = eng.torch.from_numpy(np.asarray(b, np.float32)).to(eng.device)
+            b = eng.to_device_f32(np.asarray(b, np.float32))
         iters = self.FIM_invert_args['iters'] if iters is None else iters
         damping = self.FIM_invert_args['damping'] if damping is None else damping
         if self.hvp_subsample is not None and self.hvp_subsample < 0.99:
@@ -80,12 +80,13 @@ class NPG(BatchREINFORCE):
         Nb = eng.N_bound
         k = int(self.hvp_subsample * Nb)
         from ..engine import _dist
+        from ..utils.ingest import upload
         d = _dist()
         kg = eng.global_count(k)
         be.cg_init(b)
         try:
             for _ in range(int(iters)):
-                idx = torch.from_numpy(np.random.choice(Nb, size=k)).to(eng.device)
+                idx = upload(be, np.random.choice(Nb, size=k))
                 sub = eng.obs.index_select(0, idx)
                 be.bind_batch(sub, None, None, k, kg)
                 be.fvp_of_cg_direction(eng.Ap)
@@ -161,7 +162,7 @@ class NPG(BatchREINFORCE):
             n_step_size = (alpha ** 2) * gdotx
         else:
             alpha, n_step_size = late["alpha"], self.n_step_size
-        self.policy.set_param_values(eng.theta_new.cpu().numpy(), set_new=True, set_old=True)
+        self.policy.set_param_values(eng.to_host(eng.theta_new), set_new=True, set_old=True)
 
         if self.save_logs:
             self._log_update(paths, alpha, n_step_size, t_gLL, t_FIM, kl_dist, surr_before, surr_after)

@@ -17,6 +17,7 @@ import time as timer
 import numpy as np
 
 from .._lib import check, ptr
+from ..utils.ingest import upload
 from ..utils.logger import DataLog
 from .batch_reinforce import BatchREINFORCE
 
@@ -69,7 +70,7 @@ class PPO(BatchREINFORCE):
             idx = np.stack([np.random.choice(num_samples, size=self.mb_size) for _ in range(steps)]).astype(np.int32)
             if self._adam is None:
                 self._adam = [torch.zeros_like(eng.theta_new), torch.zeros_like(eng.theta_new), 0]
-            didx = torch.from_numpy(idx).to(eng.device)
+            didx = upload(eng.backend, idx)
             # reference_aliasing: reproduce what the reference computes once its new / old network tensors share memory
             # (policies/gaussian_mlp.py set_param_values); False = the old policy stays fixed during the epochs
             track = int(bool(self.reference_aliasing and getattr(self.policy, "reference_new_old_alias", False)))
@@ -81,7 +82,7 @@ class PPO(BatchREINFORCE):
             eng.old_is_new = False
             eng._bind_policy()
         surr_after, kl_dist = eng.eval_surr_kl()
-        self.policy.set_param_values(eng.theta_new.cpu().numpy(), set_new=True, set_old=True)
+        self.policy.set_param_values(eng.to_host(eng.theta_new), set_new=True, set_old=True)
         t_opt = timer.time() - ts
         if self.save_logs:
             self.logger.log_kv('t_opt', t_opt)

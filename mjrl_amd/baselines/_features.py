@@ -7,6 +7,7 @@ import numpy as np
 
 from .. import _lib
 from .._lib import check, ptr
+from ..utils import ingest
 
 FEAT_MLP, FEAT_LINEAR, FEAT_QUADRATIC = 0, 1, 2
 
@@ -35,11 +36,12 @@ def path_inputs(paths, inp):
     return np.ascontiguousarray(o, dtype=np.float64), tpos
 
 
-class _StagerBackend:
-    """what utils/ingest.PathStager needs from a backend"""
-
-    def __init__(self, torch, device, lib):
-        self.torch, self.device, self.lib = torch, device, lib
+def _time_index(paths):
+    """tpos[s] = position of sample s inside its trajectory (the reference's np.arange(l) per path), vectorised"""
+    lens = np.fromiter((len(p["rewards"]) for p in paths), dtype=np.int64, count=len(paths))
+    starts = np.zeros(len(paths), np.int64)
+    np.cumsum(lens[:-1], out=starts[1:])
+    return (np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(starts, lens)).astype(np.int32)
 
 
 class DeviceBlock:
@@ -48,35 +50,50 @@ class DeviceBlock:
         shared batch registered."""
         self.torch, self.dev = torch_dev()
         self.lib = _lib.load()
+        self.handle = ingest.DeviceHandle(self.torch, self.dev, self.lib)
+        self.paths, self.shared = paths, False
         first = paths[0]["observations"] if inp != 'env_features' else None
         if shared and first is not None and first.ndim == 2 and first.dtype == np.float64:
             # the fp64 observation block of this batch: uploaded once per process (page-locked staging), shared with
-            # the policy update and the other baseline call of the iteration (utils/ingest.stage_shared)
-            from ..utils.ingest import stage_shared
-            self.obs = stage_shared(_StagerBackend(self.torch, self.dev, self.lib), paths, ("observations",))["observations"]["raw"]
+            # the policy update and the other baseline call of the iteration (utils/ingest.stage_shared); the time index
+            # is built once per batch as well
+            self.shared = True
+            self.obs = ingest.stage_shared(self.handle, paths, ("observations",))["observations"]["raw"]
             self.N, self.n = int(self.obs.shape[0]), int(self.obs.shape[1])
-            tpos = np.concatenate([np.arange(len(p["rewards"]), dtype=np.int32) for p in paths])
+            self.tpos = ingest.derived(self.handle, paths, "observations", "tpos",
+                                       lambda: ingest.upload(self.handle, _time_index(paths)))
         else:
             o, tpos = path_inputs(paths, inp)
             self.N, self.n = o.shape
-            self.obs = self.torch.from_numpy(o).to(self.dev)
-        self.tpos = self.torch.from_numpy(tpos).to(self.dev)
+            self.obs = ingest.upload(self.handle, o)
+            self.tpos = ingest.upload(self.handle, tpos)
 
     def st(self):
         return stream(self.torch, self.dev)
 
+    def returns_dev(self):
+        """the concatenated fp64 returns on the device: the block compute_returns left there (utils/process_samples.py)
+        when these are the paths it handed them to, else one upload"""
+        y = ingest.lookup(self.handle, self.paths, "returns") if self.shared else None
+        if y is None:
+            y = ingest.upload(self.handle, np.concatenate([np.asarray(p["returns"], np.float64) for p in self.paths]))
+        return y
+
     def gram(self, kind, y):
         F = self.lib.mjx_bl_num_features(kind, self.n)
-        yt = self.torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).to(self.dev)
+        yt = y if hasattr(y, "data_ptr") else ingest.upload(self.handle, y, np.float64)
         G = self.torch.empty((F + 1, F + 1), dtype=self.torch.float64, device=self.dev)
         check(self.lib.mjx_bl_gram(kind, ptr(self.obs), ptr(self.tpos), ptr(yt), self.N, self.n, ptr(G), self.st()))
-        return G.cpu().numpy()
+        return ingest.download(self.handle, G)
 
-    def predict_linear(self, kind, coef):
+    def predict_linear_dev(self, kind, coef):
         ct = self.torch.from_numpy(np.ascontiguousarray(coef, dtype=np.float64)).to(self.dev)
         out = self.torch.empty(self.N, dtype=self.torch.float64, device=self.dev)
         check(self.lib.mjx_bl_predict(kind, ptr(self.obs), ptr(self.tpos), self.N, self.n, ptr(ct), ptr(out), self.st()))
-        return out.cpu().numpy()
+        return out
+
+    def predict_linear(self, kind, coef):
+        return ingest.download(self.handle, self.predict_linear_dev(kind, coef))
 
     def mlp_features(self):
         out = self.torch.empty((self.N, self.n + 4), dtype=self.torch.float32, device=self.dev)

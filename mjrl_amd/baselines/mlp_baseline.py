@@ -11,6 +11,7 @@ import ctypes
 import numpy as np
 
 from .._lib import check, ptr
+from ..utils import ingest
 from ._features import DeviceBlock
 
 
@@ -49,34 +50,43 @@ class MLPBaseline:
         blk = DeviceBlock(paths, self.inp)
         torch = blk.torch
         feat = blk.mlp_features()
-        returns = np.concatenate([path["returns"] for path in paths]).astype('float32')
-        num_samples = returns.shape[0]
-        y = torch.from_numpy(returns).to(blk.dev)
+        y64 = blk.returns_dev()                                # fp64, left on the device by compute_returns when possible
+        num_samples = int(y64.shape[0])
+        y = torch.empty(num_samples, dtype=torch.float32, device=blk.dev)
+        check(blk.lib.mjx_cast_f64_f32(ptr(y64), num_samples, ptr(y), blk.st()))     # == astype('float32') (mlp_baseline.py:66)
+        if return_errors:
+            returns = ingest.download(blk.handle, y)
         p = torch.from_numpy(self.params).to(blk.dev)
         if return_errors:
-            errors = returns - self._forward(blk, feat, p).cpu().numpy()
+            errors = returns - ingest.download(blk.handle, self._forward(blk, feat, p))
             error_before = np.sum(errors ** 2) / (np.sum(returns ** 2) + 1e-8)
         m, v = torch.from_numpy(self.adam_m).to(blk.dev), torch.from_numpy(self.adam_v).to(blk.dev)
         perm = np.concatenate([np.random.permutation(num_samples) for _ in range(self.epochs)]).astype(np.int32) \
             if self.epochs > 0 else np.zeros(1, np.int32)
-        perm_t = torch.from_numpy(perm).to(blk.dev)
+        perm_t = ingest.upload(blk.handle, perm)
         losses = torch.zeros(max(self.epochs, 1), dtype=torch.float64, device=blk.dev)
         check(blk.lib.mjx_mlp_fit_adam(ptr(feat), ptr(y), num_samples, self.n + 4, self._hid(), len(self.hidden_sizes), ptr(p), ptr(m),
                                        ptr(v), self.adam_steps, ptr(perm_t), int(self.epochs), int(self.batch_size),
                                        float(self.learn_rate), float(self.reg_coef), ptr(losses), blk.st()))
         steps = max(int(num_samples / self.batch_size) - 1, 0)
         self.adam_steps += steps * self.epochs
-        self.params, self.adam_m, self.adam_v = p.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()
+        self.params, self.adam_m, self.adam_v = (ingest.download(blk.handle, t) for t in (p, m, v))
         self.epoch_losses = list(losses.cpu().numpy()[:self.epochs] / max(steps, 1))
         if return_errors:
-            errors = returns - self._forward(blk, feat, p).cpu().numpy()
+            errors = returns - ingest.download(blk.handle, self._forward(blk, feat, p))
             error_after = np.sum(errors ** 2) / (np.sum(returns ** 2) + 1e-8)
             return error_before, error_after
 
-    def predict_batch(self, paths, shared=True):
+    def predict_batch_device(self, paths, shared=True):
+        """fp32 predictions of all timesteps as a device block (the GAE chain of utils/process_samples stays there)"""
         blk = DeviceBlock(paths, self.inp, shared)
         p = blk.torch.from_numpy(self.params).to(blk.dev)
-        return self._forward(blk, blk.mlp_features(), p).cpu().numpy()
+        return self._forward(blk, blk.mlp_features(), p)
+
+    def predict_batch(self, paths, shared=True):
+        out = self.predict_batch_device(paths, shared)
+        import torch
+        return ingest.download(ingest.DeviceHandle(torch, out.device, None), out)
 
     def predict(self, path):
         return self.predict_batch([path], shared=False)

@@ -14,6 +14,16 @@ import numpy as np
 from ._features import FEAT_LINEAR, FEAT_QUADRATIC, DeviceBlock
 
 
+def _few_blas_threads(limit=8):
+    """context manager capping the BLAS / LAPACK thread pools (threadpoolctl when importable, else a no-op)"""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=limit)
+    except Exception:                                   # pragma: no cover
+        import contextlib
+        return contextlib.nullcontext()
+
+
 class _RidgeBaseline:
     _kind = None
 
@@ -24,28 +34,39 @@ class _RidgeBaseline:
         self._coeffs = None
 
     def _solve(self, G, b):
-        """quadratic_baseline.py:54-63 / linear_baseline.py:45-54"""
+        """quadratic_baseline.py:54-63 / linear_baseline.py:45-54.  The F x F solve (F <= a few hundred) is a job for a
+        handful of cores: with the BLAS pool at its default of one thread per core, LAPACK's SVD spent 10-50 ms (erratic)
+        on the 128-core hosts of the GPU boxes -- the unexplained stall of round 1's iteration timings."""
         reg_coeff = copy.deepcopy(self._reg_coeff)
-        for _ in range(10):
-            coeffs = np.linalg.lstsq(G + reg_coeff * np.identity(G.shape[0]), b, rcond=-1)[0]
-            if not np.any(np.isnan(coeffs)):
-                break
-            reg_coeff *= 10
+        with _few_blas_threads():
+            for _ in range(10):
+                coeffs = np.linalg.lstsq(G + reg_coeff * np.identity(G.shape[0]), b, rcond=-1)[0]
+                if not np.any(np.isnan(coeffs)):
+                    break
+                reg_coeff *= 10
         return coeffs
 
     def fit(self, paths, return_errors=False):
         blk = DeviceBlock(paths, self.inp)
-        returns = np.concatenate([path["returns"] for path in paths])
+        y = blk.returns_dev()                                  # stays on the device when compute_returns put it there
         if return_errors:
+            returns = np.concatenate([path["returns"] for path in paths])
             predictions = blk.predict_linear(self._kind, self._coeffs) if self._coeffs is not None else np.zeros(returns.shape)
             error_before = np.sum((returns - predictions) ** 2) / np.sum(returns ** 2)
-        Gaug = blk.gram(self._kind, returns)
+        Gaug = blk.gram(self._kind, y)
         F = Gaug.shape[0] - 1
         self._coeffs = self._solve(Gaug[:F, :F], Gaug[:F, F])
         if return_errors:
             predictions = blk.predict_linear(self._kind, self._coeffs)
             error_after = np.sum((returns - predictions) ** 2) / np.sum(returns ** 2)
             return error_before, error_after
+
+    def predict_batch_device(self, paths, shared=True):
+        """concatenated predictions as an fp64 device block (utils/process_samples keeps the GAE chain on the device);
+        None before the first fit (the caller falls back to predict_batch's zeros)"""
+        if self._coeffs is None:
+            return None
+        return DeviceBlock(paths, self.inp, shared).predict_linear_dev(self._kind, self._coeffs)
 
     def predict_batch(self, paths, shared=True):
         """concatenated predictions for a list of paths in one device pass"""

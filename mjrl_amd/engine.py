@@ -83,7 +83,8 @@ class HipBackend:
         torch = self.torch
         if isinstance(a, torch.Tensor):
             return a.to(device=self.device, dtype=torch.float32).contiguous()
-        t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        from .utils.ingest import upload
+        t = upload(self, a)                          # page-locked bounce buffer: pageable uploads crawl on this stack
         if t.dtype == torch.float64:
             out = torch.empty(t.shape, dtype=torch.float32, device=self.device)
             check(self.lib.mjx_cast_f64_f32(ptr(t), t.numel(), ptr(out), self.stream()))
@@ -238,6 +239,11 @@ class UpdateEngine:
     def to_device_f32(self, a):
         return self.backend.upload_f32(a)
 
+    def to_host(self, t):
+        """device tensor -> fresh ndarray through a page-locked bounce buffer (utils/ingest.download: no pageable hipMemcpy)"""
+        from .utils.ingest import download
+        return download(self.backend, t)
+
     # ------------------------------------------------------------------ binding
     def set_policy(self, theta_new, theta_old, tr_new, tr_old):
         """flat fp32 parameter vectors + packed transforms (host ndarrays)."""
@@ -273,6 +279,25 @@ class UpdateEngine:
         self._block = (self.obs, self.act, self.adv, self.N_local, int(self.N_global))
         self._prefix = None
         self.backend.bind_batch(self.obs, self.act, self.adv, self.N_local, int(self.N_global))
+
+    def whitened_advantages(self, adv64):
+        """(adv - mean) / (std + 1e-6) of process_paths (batch_reinforce.py:185) for an fp64 advantage block that is
+        already on the device (utils/process_samples left it there): population mean / std over ALL ranks by two
+        reduction passes (mean, then squared deviations about it -- NumPy's algorithm), cast to fp32 on the way out."""
+        torch, lib = self.torch, self.lib
+        N = int(adv64.numel())
+        st = torch.zeros(3, dtype=torch.float64, device=self.device)
+        check(lib.mjx_sum_stats(ptr(adv64), N, 0.0, ptr(st), self.stream()))
+        self._rank_sum(st)
+        s = st.cpu().numpy()
+        mean = float(s[0] / s[2])
+        check(lib.mjx_sum_stats(ptr(adv64), N, mean, ptr(st), self.stream()))
+        self._rank_sum(st)
+        s = st.cpu().numpy()
+        std = float(np.sqrt(s[1] / s[2]))
+        out = torch.empty(N, dtype=torch.float32, device=self.device)
+        check(lib.mjx_whiten_cast(ptr(adv64), N, mean, std, 1e-6, ptr(out), self.stream()))
+        return out
 
     def stage_paths(self, paths, keys=("observations", "actions")):
         """per-path host arrays -> fp32 device blocks through the page-locked stager (utils/ingest.py): no

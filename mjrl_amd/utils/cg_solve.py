@@ -19,17 +19,17 @@ class DeviceFisher:
 
     def __call__(self, v):
         torch = self.engine.torch
-        vt = torch.from_numpy(np.asarray(v, np.float32)).to(self.engine.device)
-        out = self.engine.fvp(vt).cpu().numpy()
+        vt = self.engine.to_device_f32(np.asarray(v, np.float32))
+        out = self.engine.to_host(self.engine.fvp(vt))
         return out + np.float32(self.damping) * np.asarray(v, np.float32)
 
 
 def cg_solve(f_Ax, b, x_0=None, cg_iters=10, residual_tol=1e-10):
     if isinstance(f_Ax, DeviceFisher):
         eng = f_Ax.engine
-        bt = eng.torch.from_numpy(np.asarray(b, np.float32)).to(eng.device)
+        bt = eng.to_device_f32(np.asarray(b, np.float32))
         x, _ = eng.cg_solve(bt, cg_iters, f_Ax.damping, residual_tol)
-        return x.cpu().numpy()
+        return eng.to_host(x)
     sol = np.zeros_like(b)
     resid = np.array(b, copy=True)
     direction = np.array(b, copy=True)

@@ -200,6 +200,76 @@ class PathStager:
             self.pool = None
 
 
+# ---------------------------------------------------------------------- host <-> device, never through pageable memory
+# hipMemcpy between the device and PAGEABLE host memory pins the host range on the fly for transfers of about a megabyte
+# and more (a userptr registration that ROCm keeps cached).  When the process later maps or unmaps memory over such a
+# range -- NumPy allocating / freeing multi-megabyte temporaries is enough -- the driver's MMU notifier evicts the
+# process's GPU queues and the NEXT submission, whatever it is, waits 10-35 ms for them to be restored: the
+# "host-runtime stall" of round 1's iteration timings (tools/probe_stall2.py --pageable reproduces it, tools/
+# probe_stall3.py localises it).  So every transfer of this package goes through page-locked memory: the PathStager's
+# staging blocks for the rollouts, the bounce buffers below for everything else.
+_BOUNCE = {}
+_BOUNCE_LOCK = threading.Lock()
+_BOUNCE_MIN = 1 << 16          # below 64 KB the runtime stages the copy itself (no on-the-fly pinning)
+
+
+def _bounce_acquire(torch, dev, n):
+    with _BOUNCE_LOCK:
+        pool = _BOUNCE.setdefault((dev.type, dev.index), [])
+        slot = None
+        for s_ in pool:
+            if s_["cap"] >= n and not s_["busy"] and s_["event"].query():
+                slot = s_
+                break
+        if slot is None:
+            cap = max(1 << 20, 1 << int(n - 1).bit_length())
+            slot = dict(cap=cap, pin=torch.empty(cap, dtype=torch.uint8, pin_memory=True), event=torch.cuda.Event(), busy=False)
+            slot["np"] = slot["pin"].numpy()
+            slot["event"].record(torch.cuda.current_stream(dev))
+            pool.append(slot)
+            if len(pool) > 8:                           # keep the page-locked footprint bounded: drop idle buffers
+                pool[:] = [q for q in pool if q is slot or q["busy"] or not q["event"].query()][-8:] or [slot]
+        slot["busy"] = True
+    return slot
+
+
+def upload(backend, a, dtype=None):
+    """host ndarray -> device tensor of the same shape (dtype: optional NumPy dtype to convert to on the host first).
+    The copy is asynchronous on the current stream; the bounce buffer is recycled once its transfer has completed."""
+    torch, dev = backend.torch, backend.device
+    a = np.ascontiguousarray(a if dtype is None else np.asarray(a, dtype=dtype))
+    if dev.type != "cuda" or a.nbytes < _BOUNCE_MIN:
+        return torch.from_numpy(a).to(dev)
+    n = a.nbytes
+    slot = _bounce_acquire(torch, dev, n)
+    try:
+        slot["np"][:n] = a.reshape(-1).view(np.uint8)
+        out = torch.empty(a.shape, dtype=torch.from_numpy(np.empty(0, a.dtype)).dtype, device=dev)
+        out.view(torch.uint8).reshape(-1).copy_(slot["pin"][:n], non_blocking=True)
+        slot["event"].record(torch.cuda.current_stream(dev))
+    finally:
+        slot["busy"] = False
+    return out
+
+
+def download(backend, t):
+    """device tensor -> fresh host ndarray of the same shape / dtype (synchronises the current stream)"""
+    torch, dev = backend.torch, backend.device
+    n = t.numel() * t.element_size()
+    if dev.type != "cuda" or not t.is_cuda or n < _BOUNCE_MIN:
+        return t.cpu().numpy()
+    t = t.contiguous()
+    slot = _bounce_acquire(torch, dev, n)
+    try:
+        slot["pin"][:n].copy_(t.view(-1).view(torch.uint8))            # device -> page-locked host, blocking
+        out = np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
+        out.reshape(-1).view(np.uint8)[:] = slot["np"][:n]
+        slot["event"].record(torch.cuda.current_stream(dev))
+    finally:
+        slot["busy"] = False
+    return out
+
+
 # ---------------------------------------------------------------------- one upload per batch and process
 # A training iteration touches the same trajectories three times -- baseline.predict (advantages), the policy
 # update, baseline.fit (mjrl/algos/batch_reinforce.py:61-114) -- and the reference rebuilds / re-casts the
@@ -216,15 +286,28 @@ def _probe(a):
     return (float(f[0]), float(f[k // 3]), float(f[(2 * k) // 3]), float(f[-1])) if k else ()
 
 
+def _probed(n):
+    """indices of the per-path arrays whose values are probed (all of them up to 32 paths, 32 evenly spaced ones beyond:
+    a lookup happens ~10 times per iteration and must stay far below a millisecond for 1 000 paths)"""
+    return range(n) if n <= 32 else range(0, n, (n + 31) // 32)
+
+
+def _probes(arrays):
+    return [_probe(arrays[i]) for i in _probed(len(arrays))]
+
+
 def _same_batch(ent, paths, key):
     """is `paths` the very batch `ent` uploaded?  Identity of the list AND of every per-path array, against STRONG
     references the entry holds (an id() can be recycled once the objects are freed; a held object's cannot), plus a
-    few probe values per array against in-place edits."""
-    if ent["paths"] is not paths or len(ent["arrays"]) != len(paths):
+    few probe values of a sample of the arrays against in-place edits."""
+    arrays = ent["arrays"]
+    if ent["paths"] is not paths or len(arrays) != len(paths):
         return False
-    for a, p, pr in zip(ent["arrays"], paths, ent["probes"]):
-        b = p[key]
-        if a is not b or _probe(b) != pr:
+    for a, p in zip(arrays, paths):
+        if a is not p[key]:
+            return False
+    for i, pr in zip(_probed(len(arrays)), ent["probes"]):
+        if _probe(arrays[i]) != pr:
             return False
     return True
 
@@ -240,13 +323,75 @@ def stage_shared(backend, paths, keys):
         for k in keys:
             ent = reg.get(k)
             if ent is None or ent.get("paths") is None or not _same_batch(ent, paths, k):
-                st = ent["stager"] if ent is not None else PathStager(backend)
+                st = ent.get("stager") if ent is not None else None
+                if st is None:
+                    st = PathStager(backend)
                 f32 = st.stage(paths, (k,))[k]
                 arrays = [p[k] for p in paths]
                 ent = reg[k] = dict(stager=st, f32=f32, raw=st.raw(k), paths=paths, arrays=arrays,
-                                    probes=[_probe(a) for a in arrays])
+                                    probes=_probes(arrays))
             out[k] = dict(f32=ent["f32"], raw=ent["raw"])
     return out
+
+
+class DeviceHandle:
+    """what the registry needs from a backend: torch, the device, libmjx (the update engine's HipBackend has them too)"""
+
+    def __init__(self, torch, device, lib):
+        self.torch, self.device, self.lib = torch, device, lib
+
+
+def publish(backend, paths, key, raw, arrays):
+    """Register a per-timestep block that was COMPUTED on the device (returns, baseline values, advantages:
+    utils/process_samples.py) under paths[i][key] = arrays[i] -- the host copies just handed to the paths.  Whoever
+    needs that block on the device later in the iteration (the advantage whitening of process_paths, the baseline fit)
+    finds it with lookup() instead of concatenating and uploading the host arrays again; the identity / probe check of
+    _same_batch protects against paths whose arrays were replaced or edited in between."""
+    dev = backend.device
+    with _SHARED_LOCK:
+        reg = _SHARED.setdefault((dev.type, dev.index), {})
+        old = reg.get(key)
+        reg[key] = dict(stager=old.get("stager") if old else None, f32=None, raw=raw, paths=paths, arrays=list(arrays),
+                        probes=_probes(arrays))
+
+
+def lookup(backend, paths, key):
+    """the device tensor registered for paths[.][key] (stage_shared upload or publish), or None"""
+    dev = backend.device
+    with _SHARED_LOCK:
+        ent = _SHARED.get((dev.type, dev.index), {}).get(key)
+        if ent is None or ent.get("paths") is None or not _same_batch(ent, paths, key):
+            return None
+        return ent["raw"]
+
+
+def host_block(backend, paths, key):
+    """the page-locked HOST copy of a block staged by stage_shared -- the per-path arrays back to back, (N, w) in the
+    paths' dtype -- or None when `paths` is not the staged batch.  Valid until the next batch is staged under `key`;
+    lets host-side reductions run vectorised over one contiguous block instead of path by path."""
+    dev = backend.device
+    with _SHARED_LOCK:
+        ent = _SHARED.get((dev.type, dev.index), {}).get(key)
+        if ent is None or ent.get("paths") is None or ent.get("stager") is None or ent.get("f32") is None or not _same_batch(ent, paths, key):
+            return None
+        st = ent["stager"]
+        return st._slots[key]["pin_np"][:st._rows]
+
+
+def derived(backend, paths, anchor_key, name, build):
+    """a block derived from the batch (e.g. the within-trajectory time index, the trajectory offsets) cached next to
+    the staged / published block `anchor_key` of the same batch: build() runs once per batch"""
+    dev = backend.device
+    with _SHARED_LOCK:
+        ent = _SHARED.get((dev.type, dev.index), {}).get(anchor_key)
+        hit = ent is not None and ent.get("paths") is not None and _same_batch(ent, paths, anchor_key)
+        if hit and name in ent.setdefault("derived", {}):
+            return ent["derived"][name]
+    val = build()
+    if hit:
+        with _SHARED_LOCK:
+            ent.setdefault("derived", {})[name] = val
+    return val
 
 
 def drop_shared_batch():
@@ -257,6 +402,7 @@ def drop_shared_batch():
             for ent in reg.values():
                 ent["paths"] = ent["arrays"] = ent["probes"] = None
                 ent["f32"] = ent["raw"] = None
+                ent.pop("derived", None)
 
 
 def drop_shared():
@@ -264,5 +410,6 @@ def drop_shared():
     with _SHARED_LOCK:
         for reg in _SHARED.values():
             for ent in reg.values():
-                ent["stager"].close()
+                if ent.get("stager") is not None:
+                    ent["stager"].close()
         _SHARED.clear()

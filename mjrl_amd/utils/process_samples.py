@@ -4,7 +4,15 @@ Same entry points and in-place path mutation as the reference
 (mjrl/utils/process_samples.py:3-44); the per-timestep Python loops (``discount_sum``) and
 the per-path baseline forward passes become one segmented reverse scan over the concatenated
 fp64 reward block (``mjx_discount_scan`` / ``mjx_gae``, csrc/vecops.h k_traj_scan) plus one
-batched baseline prediction when the baseline offers ``predict_batch``.
+batched baseline prediction when the baseline offers ``predict_batch_device`` / ``predict_batch``.
+
+The chain stays on the device: the rewards are uploaded once (page-locked stager, shared with the
+rest of the iteration), returns, baseline values and advantages are computed there and REGISTERED
+(utils/ingest.publish), so that the advantage whitening of ``process_paths`` and the baseline fit
+later in the same ``train_step`` read the device blocks instead of concatenating and uploading the
+host arrays again.  The paths still receive ``returns`` / ``baseline`` / ``advantages`` as NumPy arrays
+(one read-back per block; per-path views of it), as every consumer of the reference's path format
+expects.
 """
 import ctypes
 
@@ -12,36 +20,60 @@ import numpy as np
 
 from .. import _lib
 from .._lib import check, ptr
+from . import ingest
 
 
-def _torch_dev():
+def _handle():
     import torch
     if not torch.cuda.is_available():
         raise _lib.MjxError("mjrl_amd.utils.process_samples needs a GPU (no CPU fallback)")
-    return torch, torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    return ingest.DeviceHandle(torch, dev, _lib.load())
 
 
 def _offsets(paths):
-    lens = np.array([len(p["rewards"]) for p in paths], dtype=np.int64)
+    lens = np.fromiter((len(p["rewards"]) for p in paths), dtype=np.int64, count=len(paths))
     off = np.zeros(len(paths) + 1, dtype=np.int64)
     np.cumsum(lens, out=off[1:])
     return off
 
 
-def _stream(torch, dev):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+def _stream(h):
+    return ctypes.c_void_p(h.torch.cuda.current_stream(h.device).cuda_stream)
+
+
+def _rewards_block(h, paths):
+    """the concatenated fp64 reward block on the device: one upload per batch (shared registry)"""
+    first = paths[0]["rewards"]
+    if isinstance(first, np.ndarray) and first.dtype == np.float64 and first.ndim == 1:
+        return ingest.stage_shared(h, paths, ("rewards",))["rewards"]["raw"].view(-1)
+    r = np.concatenate([np.asarray(p["rewards"], np.float64).ravel() for p in paths])
+    return ingest.upload(h, r)
+
+
+def _offsets_dev(h, paths, off):
+    return ingest.derived(h, paths, "rewards", "offsets_dev", lambda: h.torch.from_numpy(off).to(h.device))
+
+
+def _hand_out(h, paths, key, block, off):
+    """one read-back of a device block; the paths get per-path views of the host copy -> the list of views"""
+    host = ingest.download(h, block)
+    views = [host[off[i]:off[i + 1]] for i in range(len(paths))]
+    for p, v in zip(paths, views):
+        p[key] = v
+    return views
 
 
 def discount_sum(x, gamma, terminal=0.0):
     """Single-sequence form (process_samples.py:37-44) on the device scan; `terminal` folds in
     as an extra trailing element."""
-    torch, dev = _torch_dev()
-    lib = _lib.load()
+    h = _handle()
+    torch, dev = h.torch, h.device
     xs = np.append(np.asarray(x, np.float64), float(terminal)) if terminal != 0.0 else np.asarray(x, np.float64)
     xt = torch.from_numpy(np.ascontiguousarray(xs)).to(dev)
     off = torch.tensor([0, xs.shape[0]], dtype=torch.int64, device=dev)
     y = torch.empty_like(xt)
-    check(lib.mjx_discount_scan(ptr(xt), ptr(off), 1, float(gamma), ptr(y), _stream(torch, dev)))
+    check(h.lib.mjx_discount_scan(ptr(xt), ptr(off), 1, float(gamma), ptr(y), _stream(h)))
     out = y.cpu().numpy()
     return out[:len(x)]
 
@@ -50,28 +82,35 @@ def compute_returns(paths, gamma):
     """process_samples.py:3-5"""
     if not paths:
         return
-    torch, dev = _torch_dev()
-    lib = _lib.load()
+    h = _handle()
     off = _offsets(paths)
-    r = torch.from_numpy(np.concatenate([np.asarray(p["rewards"], np.float64) for p in paths])).to(dev)
-    offt = torch.from_numpy(off).to(dev)
-    y = torch.empty_like(r)
-    check(lib.mjx_discount_scan(ptr(r), ptr(offt), len(paths), float(gamma), ptr(y), _stream(torch, dev)))
-    out = y.cpu().numpy()
-    for i, p in enumerate(paths):
-        p["returns"] = out[off[i]:off[i + 1]].copy()
+    r = _rewards_block(h, paths)
+    y = h.torch.empty_like(r)
+    check(h.lib.mjx_discount_scan(ptr(r), ptr(_offsets_dev(h, paths, off)), len(paths), float(gamma), ptr(y), _stream(h)))
+    ingest.publish(h, paths, "returns", y, _hand_out(h, paths, "returns", y, off))
 
 
-def _predict_all(paths, baseline):
+def _baseline_block(h, paths, baseline, off):
+    """baseline values of every timestep as an fp64 device block (N,), paths[i]["baseline"] set"""
+    torch = h.torch
+    if hasattr(baseline, "predict_batch_device"):
+        b = baseline.predict_batch_device(paths)
+        if b is not None:
+            if b.dtype != torch.float64:
+                b = b.to(torch.float64)                 # (the reference's fp32 predictions are promoted by NumPy the same way)
+            ingest.publish(h, paths, "baseline", b, _hand_out(h, paths, "baseline", b, off))
+            return b
     if hasattr(baseline, "predict_batch"):
         flat = np.asarray(baseline.predict_batch(paths), np.float64)
-        off = _offsets(paths)
         for i, p in enumerate(paths):
             p["baseline"] = flat[off[i]:off[i + 1]].copy()
-        return flat
-    for p in paths:
-        p["baseline"] = baseline.predict(p)
-    return np.concatenate([np.asarray(p["baseline"], np.float64) for p in paths])
+    else:
+        for p in paths:
+            p["baseline"] = baseline.predict(p)
+        flat = np.concatenate([np.asarray(p["baseline"], np.float64) for p in paths])
+    if flat.ndim != 1:
+        raise NotImplementedError("vector-valued baselines (process_samples.py:26-27) are not supported on the device path")
+    return ingest.upload(h, flat)
 
 
 def compute_advantages(paths, baseline, gamma, gae_lambda=None, normalize=False):
@@ -79,23 +118,26 @@ def compute_advantages(paths, baseline, gamma, gae_lambda=None, normalize=False)
     advantages = returns - baseline."""
     if not paths:
         return
-    torch, dev = _torch_dev()
-    lib = _lib.load()
+    h = _handle()
+    torch, dev = h.torch, h.device
     off = _offsets(paths)
-    b = _predict_all(paths, baseline)
-    if b.ndim != 1:
-        raise NotImplementedError("vector-valued baselines (process_samples.py:26-27) are not supported on the device path")
+    b = _baseline_block(h, paths, baseline, off)
     use_gae = not (gae_lambda is None or gae_lambda < 0.0 or gae_lambda > 1.0)
-    src = "rewards" if use_gae else "returns"
-    x = torch.from_numpy(np.concatenate([np.asarray(p[src], np.float64) for p in paths])).to(dev)
-    bt = torch.from_numpy(np.ascontiguousarray(b)).to(dev)
-    offt = torch.from_numpy(off).to(dev)
-    term = torch.from_numpy(np.array([1 if p.get("terminated", False) else 0 for p in paths], dtype=np.uint8)).to(dev)
+    if use_gae:
+        x = _rewards_block(h, paths)
+    else:
+        x = ingest.lookup(h, paths, "returns")           # what compute_returns left on the device
+        if x is None:
+            x = ingest.upload(h, np.concatenate([np.asarray(p["returns"], np.float64) for p in paths]))
+    term = ingest.derived(h, paths, "rewards", "terminated_dev", lambda: torch.from_numpy(
+        np.fromiter((1 if p.get("terminated", False) else 0 for p in paths), dtype=np.uint8, count=len(paths))).to(dev))
     adv = torch.empty_like(x)
     lam = float(gae_lambda) if use_gae else -1.0
-    check(lib.mjx_gae(ptr(x), ptr(bt), ptr(offt), ptr(term), len(paths), float(gamma), lam, ptr(adv), _stream(torch, dev)))
-    out = adv.cpu().numpy()
-    if normalize:
+    check(h.lib.mjx_gae(ptr(x), ptr(b), ptr(_offsets_dev(h, paths, off)), ptr(term), len(paths), float(gamma), lam, ptr(adv), _stream(h)))
+    if normalize:                                        # process_samples.py:14-19 / 30-35: over the whole batch
+        out = ingest.download(h, adv)
         out = (out - out.mean()) / (out.std() + 1e-8)
-    for i, p in enumerate(paths):
-        p["advantages"] = out[off[i]:off[i + 1]].copy()
+        for i, p in enumerate(paths):
+            p["advantages"] = out[off[i]:off[i + 1]]
+        return
+    ingest.publish(h, paths, "advantages", adv, _hand_out(h, paths, "advantages", adv, off))

@@ -157,3 +157,49 @@ def test_path_stager_matches_concatenate_cpu():
             st.add_paths(paths)
             st.finish()
         st.close()
+
+
+def test_staged_batch_registry_identity_rules():
+    """utils/ingest: a batch is recognised by the IDENTITY of the path list and of every per-path array, held by
+    strong references (ids of freed objects are recycled), plus probe values against in-place edits; device-computed
+    blocks are published / looked up under the same rules (the id()-based fingerprint could hit falsely)."""
+    import torch
+    from mjrl_amd.utils import ingest
+    ingest.drop_shared()
+    h = ingest.DeviceHandle(torch, torch.device("cpu"), None)
+    rng = np.random.RandomState(0)
+    paths = [dict(observations=rng.randn(T, 5), rewards=rng.randn(T)) for T in (7, 3, 11)]
+    a = ingest.stage_shared(h, paths, ("observations",))["observations"]
+    b = ingest.stage_shared(h, paths, ("observations",))["observations"]
+    assert a["f32"] is b["f32"] and a["raw"] is b["raw"]                       # same batch: one upload
+    np.testing.assert_array_equal(a["raw"].numpy(), np.concatenate([p["observations"] for p in paths]))
+    # a NEW list holding the same arrays is another batch (the temporary lists of baseline.predict(path))
+    c = ingest.stage_shared(h, list(paths), ("observations",))["observations"]
+    assert c["raw"] is not a["raw"]
+    a = ingest.stage_shared(h, paths, ("observations",))["observations"]
+    # one array replaced by an equal-valued copy: not the same batch
+    paths[1]["observations"] = paths[1]["observations"].copy()
+    d = ingest.stage_shared(h, paths, ("observations",))["observations"]
+    assert d["raw"] is not a["raw"]
+    # in-place edit of an array that is still the same object: caught by the probes
+    paths[0]["observations"][0, 0] += 1.0
+    e = ingest.stage_shared(h, paths, ("observations",))["observations"]
+    assert e["raw"] is not d["raw"] and e["raw"][0, 0].item() == paths[0]["observations"][0, 0]
+    # published device blocks
+    blk = torch.arange(21, dtype=torch.float64)
+    views = [blk.numpy()[0:7], blk.numpy()[7:10], blk.numpy()[10:21]]
+    for p, v in zip(paths, views):
+        p["returns"] = v
+    assert ingest.lookup(h, paths, "returns") is None
+    ingest.publish(h, paths, "returns", blk, views)
+    assert ingest.lookup(h, paths, "returns") is blk
+    calls = []
+    assert ingest.derived(h, paths, "returns", "x", lambda: calls.append(1) or 42) == 42
+    assert ingest.derived(h, paths, "returns", "x", lambda: calls.append(1) or 43) == 42 and len(calls) == 1
+    paths[2]["returns"] = paths[2]["returns"].copy()
+    assert ingest.lookup(h, paths, "returns") is None
+    ingest.drop_shared_batch()
+    assert ingest.lookup(h, paths, "observations") is None
+    f = ingest.stage_shared(h, paths, ("observations",))["observations"]       # after the drop everything is staged afresh
+    np.testing.assert_array_equal(f["raw"].numpy(), np.concatenate([p["observations"] for p in paths]))
+    ingest.drop_shared()
