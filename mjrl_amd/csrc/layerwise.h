@@ -62,11 +62,12 @@ constexpr int GBN = 128, GBK = 32, GLD = GBK + 4;
 //                                 the activation operand is read ONCE per 256 columns -- these GEMMs sit at the ridge of
 //                                 the roofline when their operands stream from HBM, so halving the re-reads
 //                                 is worth more than occupancy
+//   128 x 128   64 x 64    64     in 256-thread workgroups (4 waves), two workgroups per CU: one workgroup's epilogue
+//                                 (activation loads, stores) and pipeline fill run under the other's matrix-core loop
 template <int BN> constexpr int gemm_threads() { return BN >= 128 ? 512 : 256; }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(gemm_threads<BN>(), 2) void k_gemm(GemmArgs g) {      // (second argument: waves per SIMD; 4 would need <= 128 VGPRs: spills, measured slower)
-  constexpr int NTH = gemm_threads<BN>();
+template <int BM, int BN, int NTH = gemm_threads<BN>()>
+__global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second argument: waves per SIMD; 4 would need <= 128 VGPRs: spills, measured slower)
   constexpr int WN = BN / 64 > 0 ? BN / 64 : 1;   // waves along N
   constexpr int WMc = (NTH / 64) / WN;            // waves along M
   constexpr int TM = BM / WMc, TN = BN / WN;     // per-wave tile
@@ -696,11 +697,13 @@ struct LayerwiseWS {
   static constexpr size_t gemm_lds_bytes() {
     return 2 * sizeof(float) * (size_t)(((BM * GLD > GBK * (BM + 4)) ? BM * GLD : GBK * (BM + 4)) + ((BN * GLD > GBK * (BN + 4)) ? BN * GLD : GBK * (BN + 4)));
   }
-  // MJX_LW_TILES=0: the round-1 tile shapes only (128 x 128 / 128 x 32) -- A/B measurements; default: wide tiles
-  static bool wide_tiles() {
-    static const bool w = [] { const char* e = getenv("MJX_LW_TILES"); return !(e && e[0] == '0'); }();
-    return w;
+  // MJX_LW_TILES (A/B measurements): 0 = the round-1 shapes only (128 x 128 in 512-thread workgroups / 128 x 32),
+  // 1 = 128 x 256 tiles (one workgroup per CU), 2 = 128 x 128 tiles in 256-thread workgroups, two per CU
+  static int tile_mode() {
+    static const int m = [] { const char* e = getenv("MJX_LW_TILES"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
+    return m;
   }
+  static bool wide_tiles() { return tile_mode() == 1; }
   // rows per workgroup tile (256-row tiles were tried for the weight gradients: 256 x 256 needs 128 accumulator + 80 operand
   // registers per lane and spills 874 VGPRs at two waves per SIMD; 256 x 128 buys nothing over 128 x 256)
   static int bm_of(int, bool) { return 128; }
@@ -711,9 +714,9 @@ struct LayerwiseWS {
     const int rem = N % 256;
     return N / 256 + (rem ? 1 : 0);
   }
-  template <int BM, int BN>
+  template <int BM, int BN, int NTH = gemm_threads<BN>()>
   static void launch_tile(const GemmArgs& g, int splits, hipStream_t st) {
-    void (*const kern)(GemmArgs) = k_gemm<BM, BN>;
+    void (*const kern)(GemmArgs) = k_gemm<BM, BN, NTH>;
     static const bool attr_set = [kern] {             // double-buffered operand tiles: dynamic LDS beyond the 64 KB default
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<BM, BN>());
       return true;
@@ -721,8 +724,7 @@ struct LayerwiseWS {
     (void)attr_set;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
     constexpr size_t lds = gemm_lds_bytes<BM, BN>();
-    constexpr int nth = gemm_threads<BN>();
-    hipLaunchKernelGGL(kern, grid, dim3(nth), lds, st, g);
+    hipLaunchKernelGGL(kern, grid, dim3(NTH), lds, st, g);
   }
   // the launch restricted to columns [j0, j0 + ncols)
   static GemmArgs col_slice(const GemmArgs& g, int j0, int ncols) {
@@ -745,6 +747,7 @@ struct LayerwiseWS {
   static void launch_gemm(const GemmArgs& g, int splits, hipStream_t st, bool wgrad = false) {
     (void)wgrad;
     if (g.N <= 32) { launch_tile<128, 32>(g, splits, st); return; }
+    if (tile_mode() == 2) { launch_tile<128, 128, 256>(g, splits, st); return; }
     if (!wide_tiles()) { launch_tile<128, 128>(g, splits, st); return; }
     // 256-column blocks; a remainder of up to 128 columns gets its own 128-column launch (a half-empty 256-column
     // block would spend matrix-core time on padding), a larger one rides in one more 256-column block
@@ -756,7 +759,7 @@ struct LayerwiseWS {
   }
   // sum of `splits` partial slabs of cnt floats (fixed order, fp64 accumulation)
   static void reduce_split(const float* part, int splits, int64_t cnt, float* out, hipStream_t st) {
-    if ((cnt & 3) == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0 && wide_tiles())
+    if ((cnt & 3) == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0 && tile_mode() != 0)
       hipLaunchKernelGGL(k_reduce_split4, dim3((unsigned)((cnt / 4 + 63) / 64)), dim3(256), 0, st, part, splits, cnt / 4, out);
     else
       hipLaunchKernelGGL(k_reduce_split, dim3(ew_grid(cnt)), dim3(256), 0, st, part, splits, cnt, out);

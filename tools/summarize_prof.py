@@ -4,7 +4,7 @@
 usage: python tools/summarize_prof.py <tag> <profiles-subdir>
   reads  gpurun_out/prof_<tag>/{trace,pmc_*}/bench_*.csv
   writes profiles/<subdir>/kernel_stats.csv, profiles/<subdir>/pmc_per_launch_avg.json and
-         profiles/r01_fvp_pmc.json (HBM bytes per FVP launch, read by bench.py for roofline.traffic)
+         profiles/<round>_fvp_pmc.json (HBM bytes per FVP launch; bench.py reads the newest one for roofline.traffic)
 """
 import collections
 import csv
@@ -59,9 +59,9 @@ def main():
         "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
         "algorithmic_bytes_per_launch": algo,
         "round": tag,
-    }, open(os.path.join(ROOT, "profiles", "r01_fvp_pmc.json"), "w"), indent=1)
+    }, open(os.path.join(ROOT, "profiles", tag[:3] + "_fvp_pmc.json"), "w"), indent=1)
     print(json.dumps(out[fvp], indent=1))
-    print(open(os.path.join(ROOT, "profiles", "r01_fvp_pmc.json")).read())
+    print(open(os.path.join(ROOT, "profiles", tag[:3] + "_fvp_pmc.json")).read())
 
 
 if __name__ == "__main__":
