@@ -201,12 +201,18 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second a
 #pragma unroll
             for (int b = 0; b < NT; ++b) bn[b] = frag(RB, Bc, LB, wn * TN + 32 * b, q + 1);
           }
+#ifdef MJX_GEMM_SETPRIO
+          __builtin_amdgcn_s_setprio(1);       // (experiment) the wave that is issuing matrix-core work wins arbitration over its SIMD partner's loads / LDS traffic
+#endif
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
               for (int b = 0; b < NT; ++b) acc[a][b] = MJX_MFMA(a4[a][t], b4[b][t], acc[a][b]);
+#ifdef MJX_GEMM_SETPRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
           for (int a = 0; a < MT; ++a) a4[a] = an[a];
 #pragma unroll

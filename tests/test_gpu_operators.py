@@ -318,3 +318,71 @@ def test_rccl_inside_libmjx_one_rank_group():
         res.append((eng.theta_new.cpu().numpy().copy(), sa, kl))
         eng.close()
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1:] == res[1][1:]
+
+
+def test_upload_download_never_touch_pageable_memory_and_round_trip():
+    """utils/ingest.upload / download: host <-> device through page-locked bounce buffers (pageable
+    hipMemcpy of ~1 MB and more leaves userptr registrations behind that later stall the GPU queues), bit-exact for the
+    dtypes the package moves, any shape, non-contiguous inputs, sizes around the bounce threshold."""
+    import torch
+    from mjrl_amd import _lib
+    from mjrl_amd.utils import ingest
+    h = ingest.DeviceHandle(torch, torch.device("cuda", torch.cuda.current_device()), _lib.load())
+    rng = np.random.RandomState(0)
+    for shape, dt in (((1_000_003,), np.float64), ((70_001, 17), np.float32), ((5,), np.float64), ((16384,), np.int32),
+                      ((16385,), np.int32), ((300_000,), np.int64), ((3, 1000, 7), np.float32), ((2_000_000,), np.uint8)):
+        a = (rng.randn(*shape) * 100).astype(dt)
+        t = ingest.upload(h, a)
+        assert t.is_cuda and tuple(t.shape) == shape
+        back = ingest.download(h, t)
+        assert back.dtype == a.dtype and np.array_equal(back, a)
+        assert np.array_equal(t.cpu().numpy(), a)
+    nc = rng.randn(4000, 60)[:, ::3]                                       # non-contiguous view
+    assert np.array_equal(ingest.download(h, ingest.upload(h, nc)), nc)
+    assert np.array_equal(ingest.download(h, ingest.upload(h, nc, np.float32)), nc.astype(np.float32))
+    big = torch.arange(3_000_000, dtype=torch.float32, device=h.device).reshape(1000, 3000)
+    assert np.array_equal(ingest.download(h, big[:, ::2]), big[:, ::2].cpu().numpy())     # non-contiguous device tensor
+    many = [ingest.upload(h, rng.randn(200_000)) for _ in range(12)]       # more uploads in flight than bounce buffers kept
+    torch.cuda.synchronize()
+    assert all(m.shape == (200_000,) for m in many)
+
+
+def test_device_resident_chain_equals_host_chain():
+    """returns -> baseline values -> GAE -> whitening -> NPG update -> baseline fit with the blocks left on the device
+    (utils/process_samples + the registry of utils/ingest) == the same iteration with every hand-over through the host
+    arrays of the paths (registry dropped after each step: the reference's data flow)."""
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    from mjrl_amd.utils import ingest, process_samples
+    n, m = 11, 3
+    spec = type("Spec", (), dict(observation_dim=n, action_dim=m, horizon=300))
+
+    def run(device_chain):
+        ingest.drop_shared()
+        paths = synth.make_paths(40, 300, n, m, seed=3, ragged=True)
+        pol = MLP(spec, hidden_sizes=(32, 32), seed=1, init_log_std=-0.5)
+        bl = QuadraticBaseline(spec)
+        agent = NPG(None, pol, bl, normalized_step_size=0.05)
+        drop = (lambda: None) if device_chain else ingest.drop_shared_batch
+        process_samples.compute_returns(paths, 0.99); drop()
+        bl.fit(paths); drop()                                              # a fitted baseline, so that predictions are not zeros
+        process_samples.compute_advantages(paths, bl, 0.99, 0.95); drop()
+        hit = ingest.lookup(agent.engine.backend, paths, "advantages") is not None
+        stats = agent.train_from_paths(paths); drop()
+        errs = bl.fit(paths, return_errors=True)
+        out = dict(theta=pol.get_param_values().copy(), coeffs=bl._coeffs.copy(), stats=np.array(stats), errs=np.array(errs), hit=hit,
+                   adv=np.concatenate([p["advantages"] for p in paths]), ret=np.concatenate([p["returns"] for p in paths]),
+                   bas=np.concatenate([p["baseline"] for p in paths]), kl=agent.last_update["kl_dist"])
+        agent.engine.close()
+        return out
+    dev, host = run(True), run(False)
+    assert dev["hit"] and not host["hit"]                                  # the two runs really took the two routes
+    assert np.array_equal(dev["ret"], host["ret"]) and np.array_equal(dev["bas"], host["bas"]) and np.array_equal(dev["adv"], host["adv"])
+    np.testing.assert_allclose(dev["stats"], host["stats"], rtol=1e-13)
+    np.testing.assert_allclose(dev["coeffs"], host["coeffs"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(dev["errs"], host["errs"], rtol=1e-9)
+    # whitening statistics formed on the device (two fp64 reduction passes) vs NumPy's: the fp32 advantages may differ in
+    # the last bit, the update by fp32 round-off
+    assert rel(dev["theta"], host["theta"]) < 1e-6 and abs(dev["kl"] - host["kl"]) < 1e-5 * host["kl"]
+    ingest.drop_shared()
