@@ -39,6 +39,7 @@ struct GemmArgs {
   const float* aux2; const float* aux3;           // EPI_RBACK: tangent activation t and the pre-activation cotangent
   const float* osc; const float* osh;             // per-column affine (EPI_BIAS_AFFINE)
   const float* ls; float inv_N;                   // EPI_FVP_HEAD: log_std per column, 1 / N_global
+  int fast;                                       // set by launch_tile: the interior fast path of the 256-column tiles may be used
   int epi;
 };
 
@@ -221,10 +222,98 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second a
         __syncthreads();
       }
     };
+    // Fast path of the 256-column tiles: every tile of this operand pair is interior (whole 128 x 256 block inside the
+    // matrices, K range a multiple of 32, 16-byte granules) -- the steady state of the big products.  Per-thread operand
+    // pointers are formed once and bumped by a constant per k-tile, and the LDS stores of tile k + 1 / the global loads of
+    // tile k + 2 sit BETWEEN the MFMA groups of tile k instead of in front of them: in the general loop above all eight
+    // waves leave the barrier together, do their stores / address arithmetic / load issue together (~700 cycles per
+    // k-tile during which no matrix-core instruction runs on the CU) and only then start multiplying.  (Measured before
+    // building this: with the activation operand served from cache -- MJX_LW_DEBUG_ALIAS_A -- the big products run 1-3 %
+    // faster, so the loop is not waiting for memory; it loses its ~12 % in that phase-locked overhead.)
+    auto kloop_fast = [&](auto ta, auto tb) {
+      constexpr int LA = decltype(ta)::value, LB = decltype(tb)::value;
+      constexpr int QA = BM / 4, QB = BN / 4;
+      const int ntile = (kend - kbeg) / GBK;
+      const float* pa[CA];
+      const float* pb[CB];
+#pragma unroll
+      for (int c = 0; c < CA; ++c) {
+        const int idx = tid + NTH * c;
+        pa[c] = LA ? Ap + (int64_t)(kbeg + idx / QA) * aks + m0 + 4 * (idx % QA) : Ap + (int64_t)(m0 + (idx >> 3)) * ars + kbeg + 4 * (idx & 7);
+      }
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const int idx = tid + NTH * c;
+        pb[c] = LB ? Bp + (int64_t)(kbeg + idx / QB) * bks + n0 + 4 * (idx % QB) : Bp + (int64_t)(n0 + (idx >> 3)) * bcs + kbeg + 4 * (idx & 7);
+      }
+      const int64_t sa = LA ? (int64_t)GBK * aks : GBK, sb = LB ? (int64_t)GBK * bks : GBK;
+      auto gloadf = [&]() {
+#pragma unroll
+        for (int c = 0; c < CA; ++c) { ra[c] = *(const f32x4*)pa[c]; pa[c] += sa; }
+#pragma unroll
+        for (int c = 0; c < CB; ++c) { rb[c] = *(const f32x4*)pb[c]; pb[c] += sb; }
+      };
+      gloadf();
+      __syncthreads();                                 // (a previous operand pair is fully consumed)
+      lstore1(RA, As, ra, LA);
+      lstore1(RB, Bs, rb, LB);
+      if (ntile > 1) gloadf();
+      __syncthreads();
+      auto body = [&](int kt, auto st_tag, auto ld_tag) {
+        constexpr bool ST = decltype(st_tag)::value, LD = decltype(ld_tag)::value;
+        const float* Ac = As + (kt & 1) * ASZ;
+        const float* Bc = Bs + (kt & 1) * BSZ;
+        f32x4 a4[MT], b4[NT], an[MT], bn[NT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) a4[a] = frag(RA, Ac, LA, wm * TM + 32 * a, 0);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) b4[b] = frag(RB, Bc, LB, wn * TN + 32 * b, 0);
+#pragma unroll
+        for (int q = 0; q < GBK / 8; ++q) {
+          if (q + 1 < GBK / 8) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) an[a] = frag(RA, Ac, LA, wm * TM + 32 * a, q + 1);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) bn[b] = frag(RB, Bc, LB, wn * TN + 32 * b, q + 1);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+              for (int b = 0; b < NT; ++b) acc[a][b] = MJX_MFMA(a4[a][t], b4[b][t], acc[a][b]);
+          if (q == 0 && ST) {                            // tile kt + 1 -> the other buffer, under this tile's MFMAs
+            lstore1(RA, As + ((kt + 1) & 1) * ASZ, ra, LA);
+            lstore1(RB, Bs + ((kt + 1) & 1) * BSZ, rb, LB);
+          }
+          if (q == 1 && LD) gloadf();                    // tile kt + 2 -> registers
+#pragma unroll
+          for (int a = 0; a < MT; ++a) a4[a] = an[a];
+#pragma unroll
+          for (int b = 0; b < NT; ++b) b4[b] = bn[b];
+        }
+        __syncthreads();
+      };
+      using T = std::true_type;
+      using F = std::false_type;
+      int kt = 0;
+      for (; kt + 2 < ntile; ++kt) body(kt, T{}, T{});
+      if (kt + 1 < ntile) { body(kt, T{}, F{}); ++kt; }
+      body(kt, F{}, F{});
+    };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    if (amode == 1) { if (bmode == 1) kloop(I1{}, I1{}); else kloop(I1{}, I0{}); }
-    else { if (bmode == 1) kloop(I0{}, I1{}); else kloop(I0{}, I0{}); }
+    bool fast = false;
+    if (BN == 256 && g.fast && amode != 2 && bmode != 2 && m0 + BM <= g.M && n0 + BN <= g.N && ((kend - kbeg) % GBK) == 0) fast = true;
+    if (fast) {
+      if constexpr (BN == 256) {
+        if (amode == 1) { if (bmode == 1) kloop_fast(I1{}, I1{}); else kloop_fast(I1{}, I0{}); }
+        else { if (bmode == 1) kloop_fast(I0{}, I1{}); else kloop_fast(I0{}, I0{}); }
+      }
+    } else {
+      if (amode == 1) { if (bmode == 1) kloop(I1{}, I1{}); else kloop(I1{}, I0{}); }
+      else { if (bmode == 1) kloop(I0{}, I1{}); else kloop(I0{}, I0{}); }
+    }
   }
   // Epilogue, specialised once per launch (not per element): per-column constants are fetched once per 32-column
   // block, the activation operands of a 32x32 block as one batch of independent loads.
@@ -730,6 +819,19 @@ struct LayerwiseWS {
     (void)attr_set;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
     constexpr size_t lds = gemm_lds_bytes<BM, BN>();
+    static const bool fast_on = [] { const char* e = getenv("MJX_LW_FAST"); return !(e && e[0] == '0'); }();   // MJX_LW_FAST=0: A/B
+    if (g.fast != (fast_on ? 1 : 0)) { GemmArgs h = g; h.fast = fast_on ? 1 : 0; launch_tile<BM, BN, NTH>(h, splits, st); return; }
+#ifdef MJX_GEMM_EXPERIMENTS
+    // timing experiment (results are WRONG): every row of a K-contiguous A operand reads the same 128-byte line, so the
+    // k-loop's activation stream comes from cache -- separates memory stalls from issue / LDS limits
+    static const bool alias_a = [] { const char* e = getenv("MJX_LW_DEBUG_ALIAS_A"); return e && e[0] == '1'; }();
+    if (alias_a) {
+      GemmArgs h = g;
+      for (int p = 0; p < h.npairs; ++p) if (h.a_ks[p] == 1) h.a_rs[p] = 0;
+      hipLaunchKernelGGL(kern, grid, dim3(NTH), lds, st, h);
+      return;
+    }
+#endif
     hipLaunchKernelGGL(kern, grid, dim3(NTH), lds, st, g);
   }
   // the launch restricted to columns [j0, j0 + ncols)
