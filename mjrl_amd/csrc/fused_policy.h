@@ -126,7 +126,10 @@ struct FusedLayout {
   int oXS, oXT, oD3, oBA, oBB, WAVE;            // per-wave scratch
   int oTR, oCST, oWAVES, TOTAL;
   static constexpr int NCST = 11;               // osc, osh, sigma, log_std (new) ; the same for old ; Dk = 2/(2 sigma^2 + 1e-8) ; {c3, osc^2 Dk / N} pairs
-  __host__ __device__ explicit FusedLayout(int n) {
+  // eval_only: the layout of MODE_EVAL launches -- no backward pass, so a wave's scratch is just the raw image of its
+  // observation tile (3.2 KB instead of 25 KB at HalfCheetah shapes); the workgroup then needs ~64 KB and TWO of them
+  // share a CU, i.e. two waves per SIMD: one wave's tanh / likelihood VALU work runs under the other's MFMAs
+  __host__ __device__ explicit FusedLayout(int n, bool eval_only = false) {
     NP = (n + 1 + 3) & ~3;
     S1 = NP + 2;
     oW1 = 0;
@@ -140,7 +143,7 @@ struct FusedLayout {
     oD3 = oXT + NP * ST;                        // [MP][ST]
     oBA = oD3 + MP * ST;                        // [HM][ST]
     oBB = oBA + HM * ST;                        // [HM][ST]
-    WAVE = ((oBB + HM * ST + 3) / 4) * 4;
+    WAVE = eval_only ? ((oXT + 3) / 4) * 4 : ((oBB + HM * ST + 3) / 4) * 4;
     oTR = 2 * SLOT;                             // in_shift / in_scale of A and B: 4 * NP
     oCST = oTR + 4 * NP;                        // per-action constants [NCST][MP]
     oWAVES = oCST + NCST * MP;
@@ -159,7 +162,7 @@ struct FlatOff {
 };
 
 template <int H1, int H2, int NT1, int MP, int MODE, bool DBG = false, int NPC = 0, bool CACHED = false>
-__global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
+__global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1) void k_fused(FusedArgs A) {
   using LT = FusedLayout<H1, H2, NT1, MP>;
   constexpr int MT1 = LT::MT1, MT2 = LT::MT2, S2 = LT::S2, S3 = LT::S3, ST = LT::ST;
   constexpr int RA = MP / 2;                      // accumulator rows per lane that map to actions: a = unit_of(r, hi), r < RA
@@ -167,7 +170,9 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
   const uint32_t himask = hi ? 0xffffffffu : 0u;
   const int n = A.n, m = A.m;
-  const LT L(n);
+  // small per-wave scratch, two workgroups per CU (up to 8 actions: the 16- / 32-action instances do not fit 256 registers)
+  constexpr bool EV2 = (MODE == MODE_EVAL) && !DBG && MP <= 8;
+  const LT L(n, EV2);
   const int NP = NPC ? NPC : L.NP;                // compile-time when the variant is specialised for the obs dim
   const int S1 = NP + 2;
   const FlatOff fo(n, m, H1, H2);
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
     f32x4* z4 = (f32x4*)lds;
     for (int i = tid; i < L.oWAVES / 4; i += 256) z4[i] = (f32x4)(0.f);
     f32x4* w4 = (f32x4*)ws;
-    for (int i = lane; i < L.oBA / 4; i += 64) w4[i] = (f32x4)(0.f);
+    for (int i = lane; i < (EV2 ? L.WAVE : L.oBA) / 4; i += 64) w4[i] = (f32x4)(0.f);
   }
   __syncthreads();
 #pragma unroll
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
   }
   if (tid < n) { trs[tid] = trr[0]; trs[NP + tid] = trr[1]; trs[2 * NP + tid] = trr[2]; trs[3 * NP + tid] = trr[3]; }
   // constant "ones" feature (bias column) of every wave's staging buffers
-  if (lane < 32) xT[n * ST + lane] = 1.0f;
+  if (!EV2 && lane < 32) xT[n * ST + lane] = 1.0f;
 
   // ---------------- per-action constants (LDS, broadcast reads) ----------------
   float* cst = lds + L.oCST;
@@ -1144,7 +1149,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs A) {
       s_cnt += __shfl_xor(s_cnt, off);
     }
     __syncthreads();
-    double* sred = (double*)(lds + 4 * fo.d + 4);
+    double* sred = (double*)(lds + (EV2 ? 0 : 4 * fo.d + 4));     // (EV2: the weight slots are dead by now)
     sred = (double*)(((uintptr_t)sred + 7) & ~(uintptr_t)7);
     if (lane == 0) { sred[wave * 3 + 0] = s_surr; sred[wave * 3 + 1] = s_kl; sred[wave * 3 + 2] = s_cnt; }
     __syncthreads();

@@ -92,7 +92,8 @@ using namespace mjx;
 
 template <int H1, int H2, int NT1, int MP, bool DBG = false, int NPC = 0>
 int launch_fused(mjx_ctx* c, int mode, const FusedArgs& a, hipStream_t st) {
-  FusedLayout<H1, H2, NT1, MP> L(c->n);
+  const bool ev2 = (mode == MODE_EVAL) && MP <= 8;   // MODE_EVAL (always the non-debug instance): small layout, two workgroups per CU (fused_policy.h)
+  FusedLayout<H1, H2, NT1, MP> L(c->n, ev2);
   size_t bytes = L.bytes();
   void (*k)(FusedArgs) = nullptr;
   const bool cached = (mode == MODE_FVP) && a.hcache != nullptr && !DBG;
@@ -113,7 +114,7 @@ int launch_fused(mjx_ctx* c, int mode, const FusedArgs& a, hipStream_t st) {
       *have = bytes;
     }
   }
-  hipLaunchKernelGGL(k, dim3(c->grid), dim3(256), bytes, st, a);
+  hipLaunchKernelGGL(k, dim3(ev2 ? 2 * c->grid : c->grid), dim3(256), bytes, st, a);
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }
@@ -223,7 +224,7 @@ int mjx_create(mjx_ctx** out, int device, int n, int m, const int* hidden, int n
   if (const char* e = getenv("MJX_FORCE_LAYERWISE")) if (e[0] == '1') c->fused = 0;
   if (const char* e = getenv("MJX_NO_HCACHE")) if (e[0] == '1') c->use_hcache = 0;
   HIPCHK(hipMalloc(&c->partials, (size_t)c->grid * d * sizeof(float)));
-  HIPCHK(hipMalloc(&c->spartials, (size_t)c->grid * 4 * sizeof(double)));
+  HIPCHK(hipMalloc(&c->spartials, (size_t)2 * c->grid * 4 * sizeof(double)));       // (MODE_EVAL launches 2 workgroups per CU)
   HIPCHK(hipMalloc(&c->cg_x, d * 4)); HIPCHK(hipMalloc(&c->cg_r, d * 4)); HIPCHK(hipMalloc(&c->cg_p, d * 4));
   HIPCHK(hipMalloc(&c->cg_z, d * 4)); HIPCHK(hipMalloc(&c->cg_Ap, d * 4));
   HIPCHK(hipMalloc(&c->cg_scal, 8 * sizeof(double)));
@@ -232,7 +233,7 @@ int mjx_create(mjx_ctx** out, int device, int n, int m, const int* hidden, int n
   for (int i = 0; i < m; ++i) id[2 * n + m + i] = 1.f;
   HIPCHK(hipMalloc(&c->ident_tr, id.size() * 4));
   HIPCHK(hipMemcpy(c->ident_tr, id.data(), id.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(c->spartials, 0, (size_t)c->grid * 4 * sizeof(double)));
+  HIPCHK(hipMemset(c->spartials, 0, (size_t)2 * c->grid * 4 * sizeof(double)));
   c->lw.init(n, m, c->hidden);
   c->lwmb.init(n, m, c->hidden);
   *out = c;
@@ -625,7 +626,7 @@ int mjx_eval_surr_kl(mjx_ctx* c, double* scal_out, void* stream) {
   FusedArgs a = make_args(c, c->theta_old);
   if (c->ocache_valid && c->N_local <= c->ocache_rows) { a.ocache = c->ocache; a.snap = c->snap; }
   if (int rc = dispatch_fused(c, MODE_EVAL, a, st)) return rc;
-  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, c->grid, scal_out);
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, 2 * c->grid, scal_out);
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }
