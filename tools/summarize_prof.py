@@ -49,7 +49,7 @@ def main():
     algo = 4 * (((N_OBS + 4) & ~3) + H1 + H2) * N_SAMPLES if cached else 4 * N_OBS * N_SAMPLES
     fetch, write = out[fvp]["FETCH_SIZE"], out[fvp]["WRITE_SIZE"]
     json.dump({
-        "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
+        "command": "python bench.py --steps 5 --warmup 1 --repeats 1 --no-cpu-baseline --no-secondary (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
                    "separate passes; tools/profile_bench.sh %s)" % tag,
         "kernel": fvp,
         "FETCH_SIZE_KB_raw": fetch,
