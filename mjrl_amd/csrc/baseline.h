@@ -184,6 +184,123 @@ __global__ __launch_bounds__(256, 2) void k_bl_gram_mfma(const FeatDesc* __restr
   }
 }
 
+// More than 176 augmented features (the quadratic baseline of BASELINE configs[4]: obs 39 -> 824 features, whose N x F
+// feature matrix would be 52.7 GB per 8M timesteps): the (F+1) x (F+1) matrix is cut into 128 x 128 feature blocks and
+// one workgroup owns one upper-triangle block PAIR (bi <= bj) over one sample range.  Per 32-sample chunk it generates the
+// 2 x 128 features it needs into LDS once ([sample][feature], row stride 144 doubles == 16 mod 32), then its 4 waves run
+// the 8 x 8 tiles of v_mfma_f64_16x16x4_f64 (wave w: tile rows 2w, 2w+1 x all 8 tile columns: 16 accumulator tiles = 128
+// VGPRs for the whole run; per 4-sample step 2 + 8 operand reads for 16 MFMAs).  Same operand / result mapping as above.
+// Diagonal pairs compute their whole block (the reduction reads block (bi, bj) with bi <= bj and mirrors).
+constexpr int GB_F = 128, GB_FS = GB_F + 16;
+// Feature generation is branch-free: every column is a product e[p] * e[q] of two entries of the sample's EXTENDED vector
+// e = [o_0 .. o_{n-1}, 1, tau, tau^2, tau^3, tau^4, y, 0] (o_p * 1 for a linear column, 1 * 1 for the constant, y * 1 for
+// the augmented column, 0 * 1 beyond it) -- bit-identical to feat_value(), and the two index pairs of a thread's two
+// columns are formed once: per value two LDS reads, one multiply, one LDS write (the first version looked the descriptor
+// up and branched per value and spent more time generating features than multiplying them).
+__device__ __forceinline__ void gb_pair(FeatDesc fd, int c, int F, int n, int& p, int& q) {
+  const int one = n, zero = n + 6;
+  if (c > F) { p = zero; q = one; return; }
+  if (c == F) { p = n + 5; q = one; return; }
+  if (fd.p >= 0) { p = fd.p; q = fd.q >= 0 ? fd.q : one; return; }
+  if (fd.p == -1) { p = one; q = one; return; }
+  p = n + fd.q; q = one;                                   // tau^q sits at n + q
+}
+__global__ __launch_bounds__(256, 1) void k_bl_gram_mfma_blk(int nb, const FeatDesc* __restrict__ table, int F, int n,
+                                                             const double* __restrict__ obs, const int32_t* __restrict__ tpos,
+                                                             const double* __restrict__ y, int64_t N, double* __restrict__ part) {
+  extern __shared__ double sm[];
+  const int NE = n + 7;
+  double* so = sm;                       // [32][NE] extended vectors
+  double* fi = so + 32 * NE;             // [32][GB_FS] features of block bi
+  double* fj = fi + 32 * GB_FS;          // [32][GB_FS] features of block bj (unused on the diagonal)
+  int pid = blockIdx.x, bi = 0;          // row-major upper triangle of block pairs
+  while (pid >= nb - bi) { pid -= nb - bi; ++bi; }
+  const int bj = bi + pid;
+  const bool diag = bi == bj;
+  const double* fjr = diag ? fi : fj;
+  const int FA = F + 1;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
+  f64x4 acc[2][8];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[e][t] = (f64x4)(0.0);
+  const int cl = tid & (GB_F - 1), kh = tid >> 7;
+  const int ci = GB_F * bi + cl, cj = GB_F * bj + cl;
+  int pi, qi, pj, qj;
+  gb_pair(table[ci < F ? ci : 0], ci, F, n, pi, qi);
+  gb_pair(table[cj < F ? cj : 0], cj, F, n, pj, qj);
+  int64_t chunk = (N + gridDim.y - 1) / gridDim.y;
+  chunk = (chunk + 31) & ~(int64_t)31;
+  const int64_t lo = blockIdx.y * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
+  // the next chunk's observations / time index / targets are requested before the current chunk's MFMA loop and land in
+  // registers under it (one wave per SIMD: a global-load round trip per chunk would otherwise sit in the open)
+  constexpr int OPT = 8;                                       // 32 * n <= 256 * OPT, i.e. n <= 64 (checked by the launcher)
+  double ro[OPT], rtau = 0.0, ry = 0.0;
+  auto prefetch = [&](int64_t s0) {
+    const int ks = (int)((hi - s0 < 32) ? hi - s0 : 32);
+#pragma unroll
+    for (int c = 0; c < OPT; ++c) {
+      const int i = tid + 256 * c, k = i / n;
+      ro[c] = (i < 32 * n && k < ks) ? obs[s0 * n + i] : 0.0;
+    }
+    if (tid < 32) { rtau = tid < ks ? (double)tpos[s0 + tid] / 1000.0 : 0.0; ry = tid < ks ? y[s0 + tid] : 0.0; }
+  };
+  if (lo < hi) prefetch(lo);
+  for (int64_t s0 = lo; s0 < hi; s0 += 32) {
+    const int ks = (int)((hi - s0 < 32) ? hi - s0 : 32);
+#pragma unroll
+    for (int c = 0; c < OPT; ++c) {
+      const int i = tid + 256 * c;
+      if (i < 32 * n) { const int k = i / n, f = i - k * n; so[k * NE + f] = fmin(fmax(ro[c], -10.0), 10.0) / 10.0; }
+    }
+    if (tid < 32) {
+      const bool in = tid < ks;
+      double* e = so + tid * NE + n;
+      e[0] = in ? 1.0 : 0.0;                                  // (rows past the range end contribute zeros)
+      double t = rtau;
+      e[1] = t; t *= rtau; e[2] = t; t *= rtau; e[3] = t; t *= rtau; e[4] = t;  // tau^k by repeated product, like feat_value()
+      e[5] = ry;
+      e[6] = 0.0;
+    }
+    __syncthreads();
+    if (s0 + 32 < hi) prefetch(s0 + 32);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = 2 * kk + kh;
+      const double* e = so + k * NE;
+      fi[k * GB_FS + cl] = e[pi] * e[qi];
+      if (!diag) fj[k * GB_FS + cl] = e[pj] * e[qj];
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int k0 = 0; k0 < 32; k0 += 4) {
+      const double* ra = fi + (k0 + q) * GB_FS + r16;
+      const double* rb = fjr + (k0 + q) * GB_FS + r16;
+      const double a0 = ra[16 * (2 * wave)], a1 = ra[16 * (2 * wave + 1)];
+      double b[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) b[t] = rb[16 * t];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[t], acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[t], acc[1][t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  double* out = part + (size_t)blockIdx.y * FA * FA;
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int c = GB_F * bj + 16 * t + r16;
+      const int r0 = GB_F * bi + 16 * (2 * wave + e) + q;        // register r holds row 4 r + (lane >> 4) of the tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (r0 + 4 * r < FA && c < FA) out[(size_t)(r0 + 4 * r) * FA + c] = acc[e][t][r];
+    }
+}
+
 // G[r][c] = sum_z part[z][min][max]  (upper-triangle tiles of TS x TS were computed; mirror)
 __global__ void k_bl_gram_reduce(const double* __restrict__ part, int Z, int FA, double* __restrict__ G, int TS) {
   const int64_t tot = (int64_t)FA * FA;

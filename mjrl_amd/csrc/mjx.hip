@@ -362,6 +362,22 @@ int mjx_bl_gram(int kind, const double* obs, const int32_t* tpos, const double* 
     HIPCHK(hipGetLastError());
     return MJX_OK;
   }
+  if (!(no_mfma && no_mfma[0] == '1') && n <= 64) {
+    // fp64 matrix cores, 128 x 128 feature blocks: one workgroup per (block pair, sample range)
+    const int nb = (FA + GB_F - 1) / GB_F, nbp = nb * (nb + 1) / 2;
+    int Z = (int)((N + 2047) / 2048);
+    int maxz = (768 + nbp - 1) / nbp;                  // ~3 rounds of workgroups on the chip
+    if (Z > maxz) Z = maxz;
+    if (Z < 1) Z = 1;
+    if (int rc = get_scratch(part, (size_t)Z * FA * FA * sizeof(double))) return rc;
+    const size_t lds = (size_t)(32 * (n + 7) + 2 * 32 * GB_FS) * sizeof(double);
+    static thread_local bool attr_blk = false;
+    if (!attr_blk) { HIPCHK(hipFuncSetAttribute((const void*)k_bl_gram_mfma_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_blk = true; }
+    hipLaunchKernelGGL(k_bl_gram_mfma_blk, dim3(nbp, Z), dim3(256), lds, (hipStream_t)stream, nb, ft->dev, F, n, obs, tpos, y, N, (double*)part.p);
+    hipLaunchKernelGGL(k_bl_gram_reduce, dim3(LayerwiseWS::ew_grid((int64_t)FA * FA)), dim3(256), 0, (hipStream_t)stream, (const double*)part.p, Z, FA, G, GB_F);
+    HIPCHK(hipGetLastError());
+    return MJX_OK;
+  }
   int Z = (int)((N + 4095) / 4096);
   int maxz = (2048 + npairs - 1) / npairs;
   if (Z > maxz) Z = maxz;

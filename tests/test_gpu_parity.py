@@ -368,9 +368,11 @@ def test_whole_update_other_variants_vs_oracle(n, m, hid, N):
     eng.close()
 
 
-@pytest.mark.parametrize("kind,n,N", [(2, 17, 100003), (2, 6, 777), (1, 39, 5000), (2, 11, 31), (2, 16, 4096), (1, 3, 1)])
+@pytest.mark.parametrize("kind,n,N", [(2, 17, 100003), (2, 6, 777), (1, 39, 5000), (2, 11, 31), (2, 16, 4096), (1, 3, 1),
+                                      (2, 39, 20011), (2, 24, 777), (2, 18, 33), (2, 45, 5)])      # > 176 features: 128 x 128 feature blocks
 def test_gram_on_matrix_cores_equals_fma_gram(kind, n, N, monkeypatch):
-    """mjx_bl_gram has two kernels: fp64 MFMA tiles for up to 176 augmented features, fp64 FMA register tiles beyond.
+    """mjx_bl_gram runs on the fp64 matrix cores (one workgroup holds all tiles up to 176 augmented features; 128 x 128 feature
+    blocks beyond) and has an fp64 FMA register-tile kernel as the cross-check (MJX_GRAM_FMA=1).
     Same normal equations (to fp64 summation-order noise), symmetric, for ragged sample counts and partial tiles."""
     import torch
     from mjrl_amd import _lib
