@@ -125,22 +125,33 @@ __global__ __launch_bounds__(256) void k_bl_gram(int nbt, const FeatDesc* __rest
 // <= 17 accumulator tiles per wave, registers for the whole run).  The FMA kernel above re-generates a 64-column block
 // per tile pair and is bound by LDS operand bandwidth (8 x 8 bytes per 16 FMAs): 5.0 ms at 1M x 175; this one ~0.7 ms.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+// (p, q) with column c == e[p] * e[q] for the sample's extended vector e = [o_0 .. o_{n-1}, 1, tau, tau^2, tau^3, tau^4, y, 0]
+__device__ __forceinline__ void gb_pair(FeatDesc fd, int c, int F, int n, int& p, int& q) {
+  const int one = n, zero = n + 6;
+  if (c > F) { p = zero; q = one; return; }
+  if (c == F) { p = n + 5; q = one; return; }
+  if (fd.p >= 0) { p = fd.p; q = fd.q >= 0 ? fd.q : one; return; }
+  if (fd.p == -1) { p = one; q = one; return; }
+  p = n + fd.q; q = one;                                   // tau^q sits at n + q
+}
+
 constexpr int GM_TMAX = 11, GM_TPW = (GM_TMAX * (GM_TMAX + 1) / 2 + 3) / 4;      // 66 tiles / 4 waves -> 17
 __global__ __launch_bounds__(256, 2) void k_bl_gram_mfma(const FeatDesc* __restrict__ table, int F, int n,
                                                          const double* __restrict__ obs, const int32_t* __restrict__ tpos,
                                                          const double* __restrict__ y, int64_t N, double* __restrict__ part) {
   extern __shared__ double sm[];
-  const int FA = F + 1, T = (FA + 15) >> 4, FS = 16 * (T | 1), NTILE = T * (T + 1) / 2;
-  double* so = sm;                       // [32][n] clipped obs
-  double* ft = so + 32 * n;              // [32][FS] features (+ y in column F, zeros beyond)
-  __shared__ double stau[32];
+  const int FA = F + 1, T = (FA + 15) >> 4, FS = 16 * (T | 1), NTILE = T * (T + 1) / 2, NE = n + 7;
+  double* so = sm;                       // [32][NE] extended vectors [o, 1, tau..tau^4, y, 0]
+  double* ft = so + 32 * NE;             // [32][FS] features (+ y in column F, zeros beyond)
   __shared__ int16_t tile_i[GM_TMAX * (GM_TMAX + 1) / 2], tile_j[GM_TMAX * (GM_TMAX + 1) / 2];
+  __shared__ int16_t spq[16 * GM_TMAX][2];   // column c == e[spq[c][0]] * e[spq[c][1]]: branch-free generation (see gb_pair)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
   if (tid < NTILE) {                     // row-major upper triangle
     int t = tid, i = 0;
     while (t >= T - i) { t -= T - i; ++i; }
     tile_i[tid] = (int16_t)i; tile_j[tid] = (int16_t)(i + t);
   }
+  if (tid < 16 * T) { int p_, q_; gb_pair(table[tid < F ? tid : 0], tid, F, n, p_, q_); spq[tid][0] = (int16_t)p_; spq[tid][1] = (int16_t)q_; }
   __syncthreads();
   int ai[GM_TPW], bj[GM_TPW];            // this wave's tiles: LDS column offsets of the A / B operand of tile slot e
   f64x4 acc[GM_TPW];
@@ -154,16 +165,42 @@ __global__ __launch_bounds__(256, 2) void k_bl_gram_mfma(const FeatDesc* __restr
   int64_t chunk = (N + gridDim.x - 1) / gridDim.x;
   chunk = (chunk + 31) & ~(int64_t)31;
   const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
+  // the next chunk's observations / time index / targets travel to registers under the current chunk's MFMAs
+  constexpr int OPT = 3;                                       // 32 * n <= 256 * OPT: n <= 24 (T <= 11 means n <= 17 quadratic; linear: checked by the launcher)
+  double ro[OPT], rtau = 0.0, ry = 0.0;
+  auto prefetch = [&](int64_t s0) {
+    const int ks = (int)((hi - s0 < 32) ? hi - s0 : 32);
+#pragma unroll
+    for (int c = 0; c < OPT; ++c) {
+      const int i = tid + 256 * c, k = i / n;
+      ro[c] = (i < 32 * n && k < ks) ? obs[s0 * n + i] : 0.0;
+    }
+    if (tid < 32) { rtau = tid < ks ? (double)tpos[s0 + tid] / 1000.0 : 0.0; ry = tid < ks ? y[s0 + tid] : 0.0; }
+  };
+  if (lo < hi) prefetch(lo);
+  const int FC = 16 * T;
   for (int64_t s0 = lo; s0 < hi; s0 += 32) {
     const int ks = (int)((hi - s0 < 32) ? hi - s0 : 32);
-    for (int i = tid; i < ks * n; i += 256) so[i] = fmin(fmax(obs[s0 * n + i], -10.0), 10.0) / 10.0;
-    if (tid < 32) stau[tid] = tid < ks ? (double)tpos[s0 + tid] / 1000.0 : 0.0;
+#pragma unroll
+    for (int c = 0; c < OPT; ++c) {
+      const int i = tid + 256 * c;
+      if (i < 32 * n) { const int k = i / n, f = i - k * n; so[k * NE + f] = fmin(fmax(ro[c], -10.0), 10.0) / 10.0; }
+    }
+    if (tid < 32) {
+      const bool in = tid < ks;
+      double* e = so + tid * NE + n;
+      e[0] = in ? 1.0 : 0.0;
+      double t = rtau;
+      e[1] = t; t *= rtau; e[2] = t; t *= rtau; e[3] = t; t *= rtau; e[4] = t;
+      e[5] = ry;
+      e[6] = 0.0;
+    }
     __syncthreads();
-    for (int i = tid; i < 32 * 16 * T; i += 256) {
-      const int k = i / (16 * T), c = i - k * 16 * T;
-      double v = 0.0;
-      if (k < ks) { if (c < F) v = feat_value(table[c], so + k * n, stau[k]); else if (c == F) v = y[s0 + k]; }
-      ft[k * FS + c] = v;
+    if (s0 + 32 < hi) prefetch(s0 + 32);
+    for (int i = tid; i < 32 * FC; i += 256) {
+      const int k = i / FC, c = i - k * FC;
+      const double* e = so + k * NE;
+      ft[k * FS + c] = e[spq[c][0]] * e[spq[c][1]];
     }
     __syncthreads();
     for (int k0 = 0; k0 < 32; k0 += 4) {
@@ -197,14 +234,6 @@ constexpr int GB_F = 128, GB_FS = GB_F + 16;
 // the augmented column, 0 * 1 beyond it) -- bit-identical to feat_value(), and the two index pairs of a thread's two
 // columns are formed once: per value two LDS reads, one multiply, one LDS write (the first version looked the descriptor
 // up and branched per value and spent more time generating features than multiplying them).
-__device__ __forceinline__ void gb_pair(FeatDesc fd, int c, int F, int n, int& p, int& q) {
-  const int one = n, zero = n + 6;
-  if (c > F) { p = zero; q = one; return; }
-  if (c == F) { p = n + 5; q = one; return; }
-  if (fd.p >= 0) { p = fd.p; q = fd.q >= 0 ? fd.q : one; return; }
-  if (fd.p == -1) { p = one; q = one; return; }
-  p = n + fd.q; q = one;                                   // tau^q sits at n + q
-}
 __global__ __launch_bounds__(256, 1) void k_bl_gram_mfma_blk(int nb, const FeatDesc* __restrict__ table, int F, int n,
                                                              const double* __restrict__ obs, const int32_t* __restrict__ tpos,
                                                              const double* __restrict__ y, int64_t N, double* __restrict__ part) {

@@ -346,14 +346,14 @@ int mjx_bl_gram(int kind, const double* obs, const int32_t* tpos, const double* 
   static thread_local Scratch part;
   const int T16 = (FA + 15) / 16;
   const char* no_mfma = getenv("MJX_GRAM_FMA");
-  if (T16 <= GM_TMAX && !(no_mfma && no_mfma[0] == '1')) {
+  if (T16 <= GM_TMAX && n <= 24 && !(no_mfma && no_mfma[0] == '1')) {
     // fp64 matrix cores: one persistent workgroup per sample range, all features generated once per chunk
     int Z = (int)((N + 2047) / 2048);
     if (Z > 512) Z = 512;
     if (Z < 1) Z = 1;
     if (int rc = get_scratch(part, (size_t)Z * FA * FA * sizeof(double))) return rc;
     HIPCHK(hipMemsetAsync(part.p, 0, (size_t)Z * FA * FA * sizeof(double), (hipStream_t)stream));
-    const size_t lds = ((size_t)32 * n + (size_t)32 * 16 * (T16 | 1)) * sizeof(double);
+    const size_t lds = ((size_t)32 * (n + 7) + (size_t)32 * 16 * (T16 | 1)) * sizeof(double);
     static thread_local bool attr_set = false;
     if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_bl_gram_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_set = true; }
     if (lds > 64 * 1024) return fail(MJX_ERR_UNSUPPORTED, "Gram kernel LDS staging");
