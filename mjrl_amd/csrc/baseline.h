@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_bl_predict(const FeatDesc* __restrict__
                                                     const double* __restrict__ coef, int64_t N, double* __restrict__ out) {
   extern __shared__ double sm[];
   double* o = sm + (size_t)threadIdx.x * n;
-  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < N; s += (int64_t)gridDim.x * 256) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < N; s += (int64_t)gridDim.x * blockDim.x) {
     for (int i = 0; i < n; ++i) o[i] = fmin(fmax(obs[s * n + i], -10.0), 10.0) / 10.0;
     const double tau = (double)tpos[s] / 1000.0;
     double a = 0.0;

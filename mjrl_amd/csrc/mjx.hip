@@ -397,10 +397,12 @@ int mjx_bl_predict(int kind, const double* obs, const int32_t* tpos, int64_t N, 
   if (N == 0) return MJX_OK;
   FeatTableCache* ft;
   if (int rc = get_feat_table(kind, n, &ft)) return rc;
-  size_t lds = (size_t)256 * n * sizeof(double);
+  int nth = 256;                                          // one observation row per thread in LDS: fewer threads for wide observations
+  while (nth > 64 && (size_t)nth * n * sizeof(double) > 64 * 1024) nth >>= 1;
+  size_t lds = (size_t)nth * n * sizeof(double);
   if (lds > 64 * 1024) return fail(MJX_ERR_UNSUPPORTED, "obs dim too large for the predict kernel's LDS staging");
-  int grid = (int)((N + 255) / 256); if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_bl_predict, dim3(grid), dim3(256), lds, (hipStream_t)stream, ft->dev, ft->F, n, obs, tpos, coef, N, out);
+  int grid = (int)((N + nth - 1) / nth); if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_bl_predict, dim3(grid), dim3(nth), lds, (hipStream_t)stream, ft->dev, ft->F, n, obs, tpos, coef, N, out);
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }

@@ -386,3 +386,32 @@ def test_device_resident_chain_equals_host_chain():
     # the last bit, the update by fp32 round-off
     assert rel(dev["theta"], host["theta"]) < 1e-6 and abs(dev["kl"] - host["kl"]) < 1e-5 * host["kl"]
     ingest.drop_shared()
+
+
+@pytest.mark.parametrize("n", [39, 46])
+def test_wide_quadratic_baseline_block_gram_and_cholesky_route(monkeypatch, n):
+    """obs 39 -> 824 quadratic features (BASELINE configs[4]; 46 = the widest hand_dapg observation): normal equations from the 128 x 128-block fp64-MFMA kernel,
+    solved by Cholesky (>= 256 features) == the same fit through the reference's lstsq call, == the fp64 oracle's
+    ridge fit on the explicit feature matrix."""
+    from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+    spec = type("Spec", (), dict(observation_dim=n, action_dim=3, horizon=100))
+    paths = synth.make_paths(60, 100, n, 3, seed=4, ragged=True)
+    rng = np.random.RandomState(1)
+    for p in paths:
+        p["returns"] = rng.randn(len(p["rewards"])) + p["observations"][:, 0] * p["observations"][:, 1]
+    preds = {}
+    for route in ("cholesky", "lstsq"):
+        if route == "lstsq":
+            monkeypatch.setenv("MJX_RIDGE_LSTSQ", "1")
+        bl = QuadraticBaseline(spec)
+        e0, e1 = bl.fit(paths, return_errors=True)
+        assert e0 == 1.0 and 0.0 < e1 < 1.0
+        preds[route] = (bl.predict_batch(paths), bl._coeffs.copy(), e1)
+    a, b = preds["cholesky"], preds["lstsq"]
+    assert a[1].shape == (n + n * (n + 1) // 2 + 5,)
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-7, atol=1e-8)
+    assert abs(a[2] - b[2]) < 1e-9
+    F = O.quadratic_baseline_features([p["observations"] for p in paths])
+    ret = np.concatenate([p["returns"] for p in paths])
+    coef = O.ridge_fit(F, ret, 1e-3)
+    np.testing.assert_allclose(a[0], F.dot(coef), rtol=1e-6, atol=1e-7)
