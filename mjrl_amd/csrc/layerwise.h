@@ -41,7 +41,23 @@ struct GemmArgs {
   const float* ls; float inv_N;                   // EPI_FVP_HEAD: log_std per column, 1 / N_global
   int fast;                                       // set by launch_tile: the interior fast path of the 256-column tiles may be used
   int epi;
+#ifdef MJX_PHASE_CLOCK
+  long long* clk;                                 // timing build: 8 int64 per workgroup (tools/lw_clock.py)
+#endif
 };
+
+#ifdef MJX_PHASE_CLOCK
+// timing build (-DMJX_PHASE_CLOCK): every workgroup of a k_gemm launch leaves its entry / first-MFMA / loop-end / exit
+// times (s_memrealtime, 100 MHz) and the CU it ran on; mjx_set_debug_buffer hands the buffer over and resets the slot
+// counter, each launch_tile call takes the next slot of LW_CLK_SLOT int64
+constexpr int LW_CLK_SLOT = 8 + 8 * 16384, LW_CLK_SLOTS = 24;
+inline long long*& lw_clk_buf() { static long long* p = nullptr; return p; }
+inline int& lw_clk_slot() { static int s = 0; return s; }
+#define LW_STAMP(k) do { if (g.clk && tid == 0 && blockIdx.z == 0) { __builtin_amdgcn_sched_barrier(0); \
+  g.clk[8 + 8 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define LW_STAMP(k) do {} while (0)
+#endif
 
 constexpr int GBN = 128, GBK = 32, GLD = GBK + 4;
 
@@ -82,6 +98,18 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second a
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  LW_STAMP(0);
+#ifdef MJX_PHASE_CLOCK
+  if (g.clk && tid == 0 && blockIdx.z == 0) {
+    long long* q = g.clk + 8 + 8 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+    q[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+    q[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+      g.clk[0] = g.M; g.clk[1] = g.N; g.clk[2] = g.K[0]; g.clk[3] = g.npairs > 1 ? g.K[1] : 0; g.clk[4] = g.epi; g.clk[5] = BN;
+      g.clk[6] = gridDim.x * gridDim.y; g.clk[7] = gridDim.z;
+    }
+  }
+#endif
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -176,6 +204,7 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second a
         gload1(RB, rb, Bp, bmode, bcs, bks, n0, g.N, kbeg + GBK);
       }
       __syncthreads();
+      if (p == 0) LW_STAMP(1);
       for (int kt = 0; kt < ntile; ++kt) {
         const float* Ac = As + (kt & 1) * ASZ;
         const float* Bc = Bs + (kt & 1) * BSZ;
@@ -259,6 +288,7 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second a
       lstore1(RB, Bs, rb, LB);
       if (ntile > 1) gloadf();
       __syncthreads();
+      if (p == 0) LW_STAMP(1);
       auto body = [&](int kt, auto st_tag, auto ld_tag) {
         constexpr bool ST = decltype(st_tag)::value, LD = decltype(ld_tag)::value;
         const float* Ac = As + (kt & 1) * ASZ;
@@ -317,6 +347,7 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second a
   }
   // Epilogue, specialised once per launch (not per element): per-column constants are fetched once per 32-column
   // block, the activation operands of a 32x32 block as one batch of independent loads.
+  LW_STAMP(2);
   float* Cz = g.C + (int64_t)blockIdx.z * g.c_zs;
   auto epilogue = [&](auto tag) {
     constexpr int EPI = decltype(tag)::value;
@@ -328,6 +359,69 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second a
     float csum[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) csum[nt] = 0.f;
+    // Interior blocks (the whole BM x BN block inside C, unit column stride): addresses are a wave-uniform base per 32 x 32
+    // block (SGPRs) + sixteen 32-bit lane offsets formed once; the element-wise path below pays a 64-bit multiply, bounds
+    // tests and selects PER ELEMENT -- measured with the per-workgroup clocks (tools/lw_clock.py) at ~10 us per workgroup,
+    // 13-23 % of a 256-wide product and more than half of the K <= 39 ones.  The activation operand of all the wave's blocks
+    // is requested as one batch.
+    if (m0 + BM <= g.M && n0 + BN <= g.N && ccs == 1 && g.ldc < (1 << 24) && g.ld_aux < (1 << 24)) {
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      const int um = m0 + (wv / WN) * TM, un = n0 + (wv % WN) * TN;        // wave-uniform origin of this wave's sub-tile
+      uint32_t offC[16], offA[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        offC[r] = (uint32_t)(4 * hi) * (uint32_t)g.ldc + (uint32_t)j + (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)g.ldc;
+        offA[r] = (uint32_t)(4 * hi) * (uint32_t)g.ld_aux + (uint32_t)j + (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)g.ld_aux;
+      }
+      constexpr bool AUX1 = EPI == EPI_TANGENT || EPI == EPI_BACK || EPI == EPI_BACK_RELU;
+      float yall[AUX1 ? MT * NT * 16 : 1];
+      if (AUX1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const float* __restrict__ ab = g.aux + (int64_t)(um + mt * 32) * g.ld_aux + (un + nt * 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yall[(mt * NT + nt) * 16 + r] = ab[offA[r]];
+          }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int col = un + nt * 32 + j;
+          const float bias = USE_BIAS ? g.bias[col] : 0.f;
+          const float osc = (EPI == EPI_BIAS_AFFINE || EPI == EPI_FVP_HEAD) ? g.osc[col] : 1.f;
+          const float osh = (EPI == EPI_BIAS_AFFINE && g.osh) ? g.osh[col] : 0.f;
+          float dk = 0.f;
+          if (EPI == EPI_FVP_HEAD) { const float sg = expf(g.ls[col]); dk = 2.0f / (2.0f * sg * sg + 1e-8f); }
+          float* __restrict__ cb = Cz + (int64_t)(um + mt * 32) * g.ldc + (un + nt * 32);
+          float y[16], t2[16], pre[16];
+          if (AUX1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = yall[(mt * NT + nt) * 16 + r];
+          } else if (USE_AUX) {                       // EPI_RBACK: three operands, per block
+            const int64_t ao = (int64_t)(um + mt * 32) * g.ld_aux + (un + nt * 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { y[r] = (g.aux + ao)[offA[r]]; t2[r] = (g.aux2 + ao)[offA[r]]; pre[r] = (g.aux3 + ao)[offA[r]]; }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[mt][nt][r];
+            if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
+            else if (EPI == EPI_BIAS_AFFINE) v = (v + bias) * osc + osh;
+            else if (EPI == EPI_FVP_HEAD) { v = (v + bias) * osc; v = osc * (dk * v * g.inv_N); }
+            else if (EPI == EPI_TANGENT) v = (v + bias) * fmaf(-y[r], y[r], 1.0f);
+            else if (EPI == EPI_BACK) v = v * fmaf(-y[r], y[r], 1.0f);
+            else if (EPI == EPI_RBACK) v = v * fmaf(-y[r], y[r], 1.0f) - 2.0f * y[r] * t2[r] * pre[r];
+            else if (EPI == EPI_BIAS) v = v + bias;
+            else if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+            else if (EPI == EPI_BACK_RELU) v = (y[r] > 0.f) ? v : 0.f;
+            cb[offC[r]] = v;
+            if (CSUM) csum[nt] += v;
+          }
+        }
+    } else
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -398,6 +492,7 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second a
     case EPI_FVP_HEAD: epilogue(std::integral_constant<int, EPI_FVP_HEAD>{}); break;
     default: epilogue(std::integral_constant<int, EPI_STORE>{}); break;
   }
+  LW_STAMP(3);
 }
 
 // x~ = (x - in_shift) / (in_scale + 1e-8)    fc_network.py:46
@@ -821,6 +916,13 @@ struct LayerwiseWS {
     constexpr size_t lds = gemm_lds_bytes<BM, BN>();
     static const bool fast_on = [] { const char* e = getenv("MJX_LW_FAST"); return !(e && e[0] == '0'); }();   // MJX_LW_FAST=0: A/B
     if (g.fast != (fast_on ? 1 : 0)) { GemmArgs h = g; h.fast = fast_on ? 1 : 0; launch_tile<BM, BN, NTH>(h, splits, st); return; }
+#ifdef MJX_PHASE_CLOCK
+    if (lw_clk_buf() && !g.clk && lw_clk_slot() < LW_CLK_SLOTS && (int64_t)grid.x * grid.y <= 16384) {
+      GemmArgs h = g; h.clk = lw_clk_buf() + (int64_t)(lw_clk_slot()++) * LW_CLK_SLOT;
+      hipLaunchKernelGGL(kern, grid, dim3(NTH), lds, st, h);
+      return;
+    }
+#endif
 #ifdef MJX_GEMM_EXPERIMENTS
     // timing experiment (results are WRONG): every row of a K-contiguous A operand reads the same 128-byte line, so the
     // k-loop's activation stream comes from cache -- separates memory stalls from issue / LDS limits

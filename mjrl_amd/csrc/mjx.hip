@@ -538,6 +538,11 @@ int mjx_profile_read(mjx_ctx* c, double* out) {
 int mjx_set_debug_buffer(mjx_ctx* c, float* dbg, int64_t floats) {
   if (!c || (dbg && floats < 2048 * 8)) return fail(MJX_ERR_ARG, "debug buffer too small");
   c->dbg = dbg;
+#ifdef MJX_PHASE_CLOCK
+  // timing build: a buffer of at least LW_CLK_SLOTS slots also receives the per-workgroup stamps of the next k_gemm launches
+  lw_clk_buf() = (dbg && floats >= 2 * (int64_t)LW_CLK_SLOT * LW_CLK_SLOTS) ? (long long*)dbg : nullptr;
+  lw_clk_slot() = 0;
+#endif
   return MJX_OK;
 }
 
