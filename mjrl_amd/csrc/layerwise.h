@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "fused_policy.h"
+#include "lw_head.h"
 #include "vecops.h"
 
 namespace mjx {
@@ -1007,10 +1008,12 @@ struct LayerwiseWS {
   // backward from d3 (N x m cotangent on the pre-affine output) into grad (flat, W and b blocks).
   // Bias gradients (column sums of delta_l) come out of the GEMM that produces delta_l (per-block column sums in its
   // epilogue, reduced in a fixed order); only the top delta (d3, written by the head kernel) needs its own pass.
-  int backward(const float* theta, int64_t N, float* grad, hipStream_t st) {
-    const float* delta = d3;
-    bool bias_done = false;
-    for (int l = nL() - 1; l >= 0; --l) {
+  // (l_start / delta0: continue below the output layer when fvp_head() already produced that layer's gradients, the
+  // delta of the last hidden layer and its column sums)
+  int backward(const float* theta, int64_t N, float* grad, hipStream_t st, int l_start = -1, const float* delta0 = nullptr) {
+    const float* delta = delta0 ? delta0 : d3;
+    bool bias_done = delta0 != nullptr;
+    for (int l = (l_start >= 0 ? l_start : nL() - 1); l >= 0; --l) {
       const int ho = sizes[l + 1], hi_ = sizes[l];
       const float* in = (l == 0) ? Xn : H[l - 1];
       // weight gradient: gW[ho x hi] = delta^T (ho x N) * in (N x hi), split over samples
@@ -1121,11 +1124,59 @@ struct LayerwiseWS {
       // the output layer's tangent goes straight to d3 = out_scale D mudot / N in the GEMM epilogue (no pass over N x m)
       if (last) { g.C = d3; g.ldc = m; g.epi = EPI_FVP_HEAD; g.osc = tr + 2 * n + m; g.ls = theta + oS; g.inv_N = (float)(1.0 / (double)Ng); }
       else { g.C = T[l]; g.ldc = sizes[l + 1]; g.epi = EPI_TANGENT; g.aux = H[l]; g.ld_aux = sizes[l + 1]; }
+      if (last && head_fused()) break;
       launch_gemm(g, 1, st);
       tin = last ? nullptr : T[l];
     }
     hipLaunchKernelGGL(k_fvp_logstd, dim3(1), dim3(64), 0, st, theta + oS, v + oS, m, (float)((double)N / (double)Ng), out + oS);
+    if (head_fused()) {
+      if (int rc = fvp_head(theta, tr, v, N, Ng, out, st)) return rc;
+      return backward(theta, N, out, st, nL() - 2, T[nL() - 2]);
+    }
     return backward(theta, N, out, st);
+  }
+
+  // the output layer of the product as one pass over the last hidden layer (lw_head.h); MJX_LW_HEAD=0 keeps the generic chain
+  bool head_fused() const {
+    static const bool on = [] { const char* e = getenv("MJX_LW_HEAD"); return !(e && e[0] == '0'); }();
+    if (!on || nL() < 2 || m > 32) return false;
+    const int hl = sizes[nL() - 1];
+    return (hl % 128) == 0 && hl <= 512 && (oW[nL() - 1] % 4) == 0;
+  }
+  int fvp_head(const float* theta, const float* tr, const float* v, int64_t N, int64_t Ng, float* out, hipStream_t st) {
+    const int L = nL() - 1, hl = sizes[L];
+    if ((((uintptr_t)theta | (uintptr_t)v) & 15) != 0) return -3;
+    static const int ncu = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c; }();
+    const int64_t ntile = (N + LH_R - 1) / LH_R;
+    const int grid = (int)(ntile < ncu ? ntile : ncu);             // one workgroup per CU (the kernel takes the whole register file: lw_head.h)
+    if (ensure_part((int64_t)grid * ((int64_t)m * hl + 32 + hl))) return 2;
+    HeadArgs a{};
+    a.H = H[L - 1]; a.T = T[L - 1]; a.V3 = v + oW[L]; a.W3 = theta + oW[L]; a.c3 = v + ob[L];
+    a.osc = tr + 2 * n + m; a.ls = theta + oS; a.inv_N = (float)(1.0 / (double)Ng);
+    a.N = N; a.h = hl; a.m = m;
+    a.gw_part = part; a.gb_part = part + (int64_t)grid * m * hl; a.cs_part = a.gb_part + (int64_t)grid * 32;
+    auto launch = [&](auto ch) {
+      constexpr int CH = decltype(ch)::value;
+      void (*const kern)(HeadArgs) = k_lw_head<CH>;
+      static const bool attr_set = [kern] {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw_head_lds_bytes());
+        return true;
+      }();
+      (void)attr_set;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lw_head_lds_bytes(), st, a);
+    };
+    switch (hl / 128) {
+      case 1: launch(std::integral_constant<int, 1>{}); break;
+      case 2: launch(std::integral_constant<int, 2>{}); break;
+      case 3: launch(std::integral_constant<int, 3>{}); break;
+      default: launch(std::integral_constant<int, 4>{}); break;
+    }
+    reduce_split(a.gw_part, grid, (int64_t)m * hl, out + oW[L], st);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((m + 15) / 16), dim3(256), 0, st, a.gb_part, grid, m, out + ob[L], (const float*)nullptr,
+                       (const float*)nullptr, 0, 0.f);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((hl + 15) / 16), dim3(256), 0, st, a.cs_part, grid, hl, out + ob[L - 1], (const float*)nullptr,
+                       (const float*)nullptr, 0, 0.f);
+    return 0;
   }
 
   // Exact Hessian-vector product of mean_kl(new, old) wrt theta_new for theta_new != theta_old
