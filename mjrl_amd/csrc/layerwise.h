@@ -954,6 +954,29 @@ struct LayerwiseWS {
     if (g.ls) h.ls = g.ls + j0;
     return h;
   }
+  // Sample splits of a weight-gradient launch: whole rounds of workgroups over the CUs.  One workgroup per CU runs at a time
+  // (LDS), so tiles x splits = 490 workgroups on 256 CUs (configs[3]: 2 row tiles x 245 splits) is two rounds, the second
+  // 91 % full, each paying the per-workgroup prologue / epilogue; 2 x 128 is ONE full round of twice-as-long workgroups.
+  // cost(s) = rounds(s) x (samples per workgroup + ~9 us of fixed cost in sample units); the search keeps s within [cap/4, cap].
+  static int pick_splits(int64_t N, int row_tiles, int ncols, int cap) {
+    static const int ncu = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c; }();
+    static const bool on = [] { const char* e = getenv("MJX_LW_SPLITS"); return !(e && e[0] == '0'); }();
+    if (cap < 4 || !on) return cap;
+    int cb = 1;                                        // column blocks of the main launch (launch_gemm)
+    if (ncols > 32) {
+      if (!wide_tiles()) cb = (ncols + 127) / 128;
+      else { cb = ncols / 256 + ((ncols % 256) > 128 ? 1 : 0); if (cb < 1) cb = 1; }
+    }
+    const int64_t tl = (int64_t)row_tiles * cb;
+    int best = cap;
+    double bestc = 1e300;
+    for (int s = cap; s >= cap / 4 && s >= 1; --s) {
+      const int64_t rounds = (tl * s + ncu - 1) / ncu;
+      const double c = (double)rounds * ((double)N / s + 74.0);
+      if (c < bestc * 0.999) { bestc = c; best = s; }
+    }
+    return best;
+  }
   // wgrad: the contraction runs over samples (split over blockIdx.z) and the M x N output is small
   static void launch_gemm(const GemmArgs& g, int splits, hipStream_t st, bool wgrad = false) {
     (void)wgrad;
@@ -1025,6 +1048,7 @@ struct LayerwiseWS {
       int maxs = (1024 + tiles - 1) / tiles;
       if (splits > maxs) splits = maxs;
       if (splits < 1) splits = 1;
+      splits = pick_splits(N, narrow ? (hi_ + tbm - 1) / tbm : (ho + tbm - 1) / tbm, narrow ? ho : hi_, splits);
       const int csplits = 256;
       const int rsplits = 64;                      // second-stage split of the per-row-block column sums
       if (ensure_part((int64_t)splits * ho * hi_ + (int64_t)csplits * ho + (int64_t)rowblocks * hi_ + (int64_t)rsplits * hi_)) return 2;
@@ -1230,6 +1254,7 @@ struct LayerwiseWS {
       int maxs = (1024 + tiles - 1) / tiles;
       if (splits > maxs) splits = maxs;
       if (splits < 1) splits = 1;
+      splits = pick_splits(N, (ho + tbm - 1) / tbm, hi_, splits);
       if (ensure_part((int64_t)splits * ho * hi_ + (int64_t)splits * ho)) return 2;
       GemmArgs g{};                                         // R{gW_l} = Rdelta^T in + delta^T Tin
       g.M = ho; g.N = hi_; g.npairs = tinl ? 2 : 1;
