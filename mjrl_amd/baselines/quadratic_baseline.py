@@ -4,8 +4,8 @@
 mirrors linear_baseline.py:5-65: same constructor, ``fit(paths, return_errors)``, ``predict(path)``,
 ``_coeffs``.  The feature matrix A (N x F, fp64; 52.7 GB at BASELINE cfg5) is never materialised:
 ``mjx_bl_gram`` accumulates A^T A and A^T y on the device from the raw observation block
-(csrc/baseline.h k_bl_gram); the F x F solve stays on the host with the reference's own
-``np.linalg.lstsq`` call and regularisation escalation.
+(csrc/baseline.h k_bl_gram); the F x F solve stays on the host: the reference's ``np.linalg.lstsq`` call with its
+regularisation escalation, preceded for F >= 128 by a Cholesky attempt on the same (SPD) system (``_solve_spd``).
 """
 import copy
 
@@ -38,23 +38,24 @@ class _RidgeBaseline:
         handful of cores: with the BLAS pool at its default of one thread per core, LAPACK's SVD spent 10-50 ms (erratic)
         on the 128-core hosts of the GPU boxes -- the unexplained stall of round 1's iteration timings."""
         reg_coeff = copy.deepcopy(self._reg_coeff)
-        with _few_blas_threads():
-            for _ in range(10):
-                A = G + reg_coeff * np.identity(G.shape[0])
-                coeffs = self._solve_spd(A, b) if G.shape[0] >= self._CHOLESKY_FROM else None
-                if coeffs is None:
+        for _ in range(10):
+            A = G + reg_coeff * np.identity(G.shape[0])
+            coeffs = self._solve_spd(A, b) if G.shape[0] >= self._CHOLESKY_FROM else None
+            if coeffs is None:
+                with _few_blas_threads():
                     coeffs = np.linalg.lstsq(A, b, rcond=-1)[0]
-                if not np.any(np.isnan(coeffs)):
-                    break
-                reg_coeff *= 10
+            if not np.any(np.isnan(coeffs)):
+                break
+            reg_coeff *= 10
         return coeffs
 
     # From this many features on, the regularised normal matrix (symmetric positive definite: A^T A + reg I) is solved by
     # Cholesky factorisation first: LAPACK's SVD-based lstsq needs 65-130 ms for the 825 x 825 system of a 39-dimensional
-    # observation (BASELINE configs[4]), the factorisation 6 ms, and the two solutions agree to ~1e-9 relative (condition
-    # number ~1e9) -- seven orders below what the baseline's predictions are compared at.  Any failure (not positive
+    # observation (BASELINE configs[4]) and 2.2 ms (+ 0.8 ms for capping the BLAS pool) for the 176 x 176 one of a
+    # 17-dimensional observation (configs[1]); the factorisation 6 ms / 0.3 ms, and the two solutions agree to ~1e-9 relative
+    # (condition number ~1e9) -- seven orders below what the baseline's predictions are compared at.  Any failure (not positive
     # definite, non-finite result) falls back to the reference's lstsq call.  MJX_RIDGE_LSTSQ=1 forces lstsq everywhere.
-    _CHOLESKY_FROM = 256
+    _CHOLESKY_FROM = 128
 
     @staticmethod
     def _solve_spd(A, b):

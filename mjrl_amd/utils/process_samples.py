@@ -7,7 +7,8 @@ fp64 reward block (``mjx_discount_scan`` / ``mjx_gae``, csrc/vecops.h k_traj_sca
 batched baseline prediction when the baseline offers ``predict_batch_device`` / ``predict_batch``.
 
 The chain stays on the device: the rewards are uploaded once (page-locked stager, shared with the
-rest of the iteration), returns, baseline values and advantages are computed there and REGISTERED
+rest of the iteration; ``compute_returns`` also starts the upload of the batch's observations and actions in the
+background, utils/ingest.prefetch), returns, baseline values and advantages are computed there and REGISTERED
 (utils/ingest.publish), so that the advantage whitening of ``process_paths`` and the baseline fit
 later in the same ``train_step`` read the device blocks instead of concatenating and uploading the
 host arrays again.  The paths still receive ``returns`` / ``baseline`` / ``advantages`` as NumPy arrays
@@ -83,6 +84,11 @@ def compute_returns(paths, gamma):
     if not paths:
         return
     h = _handle()
+    # the first touch of a rollout batch in an iteration: its observations / actions start their way to the device now, on a
+    # helper thread, under the returns / advantage work below (the baseline prediction and the policy update find them staged).
+    # (Started BEFORE the rewards are staged: the two gathers compete for a moment, but the baseline prediction of
+    # compute_advantages waits for the observations -- starting after the rewards cost 2-3 ms per iteration.)
+    ingest.prefetch(h, paths, ("observations", "actions"))
     off = _offsets(paths)
     r = _rewards_block(h, paths)
     y = h.torch.empty_like(r)
