@@ -415,3 +415,27 @@ def test_wide_quadratic_baseline_block_gram_and_cholesky_route(monkeypatch, n):
     ret = np.concatenate([p["returns"] for p in paths])
     coef = O.ridge_fit(F, ret, 1e-3)
     np.testing.assert_allclose(a[0], F.dot(coef), rtol=1e-6, atol=1e-7)
+
+
+def test_background_prefetch_hands_out_complete_blocks():
+    """compute_returns starts the upload of observations / actions on a helper thread (utils/ingest.prefetch); whoever asks
+    next -- on whatever stream position -- gets the complete block (consumer ordered after the transfer event), the very
+    upload the helper made (no second one), and an edited array is noticed."""
+    import torch
+    from mjrl_amd.utils import ingest, process_samples
+    ingest.drop_shared()
+    n, m = 17, 6
+    paths = synth.make_paths(300, 400, n, m, seed=11, ragged=True)
+    process_samples.compute_returns(paths, 0.99)
+    h = process_samples._handle()
+    got = ingest.stage_shared(h, paths, ("observations", "actions"))
+    obs = np.concatenate([p["observations"] for p in paths])
+    act = np.concatenate([p["actions"] for p in paths])
+    assert torch.equal(got["observations"]["raw"].cpu(), torch.from_numpy(obs))
+    assert torch.equal(got["actions"]["f32"].cpu(), torch.from_numpy(act.astype(np.float32)))
+    again = ingest.stage_shared(h, paths, ("observations",))
+    assert again["observations"]["raw"].data_ptr() == got["observations"]["raw"].data_ptr()      # the same upload
+    paths[0]["observations"][0, 0] += 1.0                                                          # an in-place edit of a probed array
+    fresh = ingest.stage_shared(h, paths, ("observations",))
+    assert torch.equal(fresh["observations"]["raw"].cpu(), torch.from_numpy(np.concatenate([p["observations"] for p in paths])))
+    ingest.drop_shared()
