@@ -228,10 +228,14 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   }
   // MODE_EVAL: the old policy's per-sample outputs of this batch may still be around from MODE_VPG (same update);
   // they are used only if the old parameters and transforms are bit-identical to the ones they were computed with.
-  int mism = 0;
+  int mism = 0, mismx = 0;
   if (MODE == MODE_EVAL && A.ocache) {
     for (int idx = tid; idx < fo.d; idx += 256) mism |= (A.thetaB[idx] != A.snap[idx]);
     for (int idx = tid; idx < 2 * (n + m); idx += 256) mism |= (A.trB[idx] != A.snap[fo.d + idx]);
+    // K1's normalised-observation image (in the forward-activation cache) may stand in for staging + normalising the raw
+    // observations again -- if the NEW policy's input transform is still the one K1 normalised with (= the snapshot's: K1
+    // fills the caches only when old == new)
+    if (A.hcache) for (int idx = tid; idx < 2 * n; idx += 256) mismx |= (A.trA[idx] != A.snap[fo.d + idx]);
   }
   if (MODE == MODE_VPG && A.snap_out) {           // every block copies a slice: at most a few elements per thread
     const int nsnap = fo.d + 2 * (n + m);
@@ -302,10 +306,12 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   // (flag word in wave 0's staging area, zero since the fill above and rewritten by the first tile's staging;
   //  no __syncthreads_or: its static LDS word would not fit next to a 160 KB dynamic allocation)
   if (MODE == MODE_EVAL && mism) lds[L.oWAVES] = 1.0f;
+  if (MODE == MODE_EVAL && mismx) lds[L.oWAVES + 1] = 1.0f;
   __syncthreads();
-  bool use_oc = false;
+  bool use_oc = false, use_xi = false;
   if (MODE == MODE_EVAL && A.ocache) {
     use_oc = (lds[L.oWAVES] == 0.0f);
+    use_xi = use_oc && NPC != 0 && A.hcache != nullptr && (lds[L.oWAVES + 1] == 0.0f);
     __syncthreads();
   }
   // FVP epilogue constants as wave-uniform scalars (no LDS round trip on the d3 critical path)
@@ -415,11 +421,21 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       }
   };
 
+  auto load_xi = [&](int64_t t) {                 // MODE_EVAL with K1's observation image: the layer-1 operand pairs of tile t
+#pragma unroll
+    for (int q = 0; q < NQC; ++q) xc[q] = *(const f32x2*)(A.hcache + t * HC_TILE + HC_H + (q * 64 + lane) * 2);
+  };
+
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  if (!XCACHED && tile < ntiles) load_x(tile);
+  if (!XCACHED && !use_xi && tile < ntiles) load_x(tile);
   if (XCACHED && tile < ntiles) load_h(tile);
   if (MODE == MODE_EVAL && use_oc && tile < ntiles) load_oc(tile);
+  if (MODE == MODE_EVAL && use_xi && tile < ntiles) load_xi(tile);
 
+  // (the tile loop is instantiated twice for MODE_EVAL: XI = K1's normalised-observation image replaces the staging and
+  //  normalisation of the raw observations; the choice is made once per launch, above)
+  auto run_tiles = [&](auto xi_tag) {
+  constexpr bool XI = decltype(xi_tag)::value;
   for (; tile < ntiles; tile += tstride) {
     const int64_t s0 = tile * 32;
     const bool valid = (s0 + j) < A.N;
@@ -433,7 +449,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       for (int a = 0; a < MP; ++a) actr[a] = A.act[(valid && a < m) ? (s0 + j) * m + a : 0];
       advr = A.adv[valid ? s0 + j : 0];
     }
-    if (!XCACHED) {
+    if (!XCACHED && !XI) {
 #pragma unroll
       for (int c = 0; c < XL4; ++c) {
         const int e4 = c * 64 + lane;
@@ -471,6 +487,8 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         auto xpair = [&](int q) {
           if constexpr (TAN && CACHED) {
             if constexpr (NPC != 0) return xc[q]; else return *(const f32x2*)(ximg + q * 128);
+          } else if constexpr (XI) {
+            return xc[q];
           } else {
             const int f = 4 * q + 2 * hi;
             return f32x2{xnorm(f), xnorm(f + 1)};
@@ -514,6 +532,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         }
       }
       MJX_STAMP(2);
+      if (XI && tile + tstride < ntiles) load_xi(tile + tstride);      // xc is dead: the next tile's image flies under the rest of this one
 #pragma unroll
       for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
@@ -1052,6 +1071,12 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
     }
     MJX_STAMP(13);
     wave_sync();                                  // everything read before the next tile's staging
+  }
+  };
+  if constexpr (MODE == MODE_EVAL && NPC != 0) {
+    if (use_xi) run_tiles(std::true_type{}); else run_tiles(std::false_type{});
+  } else {
+    run_tiles(std::false_type{});
   }
 
   MJX_GSTAMP(18);

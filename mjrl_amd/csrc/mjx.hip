@@ -62,6 +62,7 @@ struct mjx_ctx {
   bool batch_bound = false;
   float* hcache = nullptr; size_t hcache_bytes = 0;   // forward-activation cache of the fused path
   bool hcache_valid = false; const float* hcache_obs = nullptr; int64_t hcache_rows = 0;
+  bool ximg_ok = false; int64_t ximg_rows = 0;        // the cache's normalised-observation image outlives a parameter change (K3 reads it)
   int use_hcache = 1;
   float* ocache = nullptr; size_t ocache_bytes = 0;   // old-policy outputs of the batch (K1 -> K3)
   float* snap = nullptr;                              // parameters + transforms they were computed with
@@ -275,6 +276,7 @@ int mjx_bind_batch(mjx_ctx* c, const float* obs, const float* act, const float* 
   c->rows_bound = N_local;
   c->hcache_valid = false;                      // a new batch: nothing cached from earlier calls applies
   c->ocache_valid = false;
+  c->ximg_ok = false;
   c->lw.invalidate();
   if (!c->fused) { int rc = c->lw.reserve(N_local); if (rc) return fail(rc, "layer-wise workspace allocation failed"); }
   return MJX_OK;
@@ -562,6 +564,7 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
                           grad_out, scal_out, st) ? fail(MJX_ERR_STATE, "layer-wise surr_vpg failed") : MJX_OK;
   FusedArgs a = make_args(c, c->theta_old);
   c->hcache_valid = false;
+  c->ximg_ok = false;
   if (c->use_hcache && c->old_is_new && c->hidden.size() == 2) {
     // keep h1 / h2 of every sample for the Fisher-vector products of this update (theta is fixed during CG)
     // per 32-sample tile: h1, h2 (sample-lane accumulator image) + the normalised observations (layer-1 operand image)
@@ -572,7 +575,8 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
       c->hcache = nullptr; c->hcache_bytes = 0;
       if (hipMalloc(&c->hcache, need) == hipSuccess) c->hcache_bytes = need; else (void)hipGetLastError();
     }
-    if (c->hcache) { a.hcache = c->hcache; c->hcache_valid = true; c->hcache_obs = c->obs; c->hcache_rows = c->N_local; }
+    if (c->hcache) { a.hcache = c->hcache; c->hcache_valid = true; c->hcache_obs = c->obs; c->hcache_rows = c->N_local;
+                     c->ximg_ok = true; c->ximg_rows = c->N_local; }
     // ... and the old policy's means / log-likelihoods for mjx_eval_surr_kl (old == new here), with a snapshot of
     // the parameters they belong to (the EVAL kernel compares before trusting them)
     const size_t oneed = (size_t)((c->N_local + 31) / 32) * 33 * 32 * sizeof(float);     // [tile][MP + 1][32] with MP <= 32 (largest fused variant)
@@ -648,6 +652,10 @@ int mjx_eval_surr_kl(mjx_ctx* c, double* scal_out, void* stream) {
                ? fail(MJX_ERR_STATE, "layer-wise eval failed") : MJX_OK;
   FusedArgs a = make_args(c, c->theta_old);
   if (c->ocache_valid && c->N_local <= c->ocache_rows) { a.ocache = c->ocache; a.snap = c->snap; }
+  // K1's normalised-observation image of this batch (same rows, same observations; the kernel checks the input transform
+  // against the snapshot before it trusts it) spares K3 the staging and normalisation of the raw observations
+  static const bool ximg_on = [] { const char* e = getenv("MJX_K3_XIMG"); return !(e && e[0] == '0'); }();
+  if (ximg_on && a.ocache && c->ximg_ok && c->hcache && c->N_local <= c->ximg_rows && c->obs == c->hcache_obs) a.hcache = c->hcache;
   if (int rc = dispatch_fused(c, MODE_EVAL, a, st)) return rc;
   hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, 2 * c->grid, scal_out);
   HIPCHK(hipGetLastError());

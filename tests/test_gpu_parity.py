@@ -733,6 +733,45 @@ def test_empty_shard_contributes_zero():
         eng.close()
 
 
+def test_eval_reads_k1_observation_image_only_under_the_same_input_transform():
+    """K3 after K1 takes the normalised observations from the image K1 left in the forward-activation cache (no staging,
+    no normalisation of the raw block) -- results are bit-identical to the raw path (MJX_K3_XIMG is read once per process,
+    so the two paths are compared through the kernel's own guard): when the NEW policy's input transform is changed in
+    place after K1, the kernel must notice (it compares with the snapshot) and normalise the raw observations itself."""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    n, m, hid, N = 17, 6, (64, 64), 6000 + 7
+    rng = np.random.RandomState(21)
+    obs, act, adv = rng.randn(N, n), rng.randn(N, m), rng.randn(N)
+    th = synth.perturbed_params(synth.init_params(n, m, hid))
+    step = (0.02 * rng.randn(th.size)).astype(np.float32)
+    tr = O.Transforms(n, m, 0.1 * rng.randn(n), 1 + 0.1 * rng.rand(n), 0.05 * rng.randn(m), 1 + 0.2 * rng.rand(m))
+    pk = np.concatenate([tr.in_shift, tr.in_scale, tr.out_shift, tr.out_scale]).astype(np.float32)
+    tr2 = O.Transforms(n, m, tr.in_shift + 0.05, tr.in_scale * 1.1, tr.out_shift, tr.out_scale)
+    pk2 = np.concatenate([tr2.in_shift, tr2.in_scale, tr2.out_shift, tr2.out_scale]).astype(np.float32)
+    t_new, t_old = (th + step).astype(np.float64), th.astype(np.float64)
+    eng = UpdateEngine(n, m, hid)
+    assert eng.fused
+    eng.set_policy(th, th, pk, pk)
+    eng.set_batch(obs, act, adv)
+    eng.surr_vpg()                                        # K1: activation cache incl. the observation image, old outputs, snapshot
+    eng.theta_new.copy_(torch.from_numpy(th + step).to(eng.device))
+    eng.old_is_new = False
+    eng._bind_policy()
+    s1, k1 = eng.eval_surr_kl()                           # image path
+    assert abs(s1 - O.surrogate(t_new, t_old, obs, act, adv, n, m, hid, tr, tr)) < 2e-6
+    k1t = O.mean_kl(t_new, t_old, obs, n, m, hid, tr, tr)
+    assert abs(k1 - k1t) < 1e-5 * k1t
+    eng.tr_new.copy_(torch.from_numpy(pk2).to(eng.device))     # in place: no bind call tells the library
+    s2, k2 = eng.eval_surr_kl()                           # the image belongs to another transform: raw path
+    assert abs(s2 - O.surrogate(t_new, t_old, obs, act, adv, n, m, hid, tr2, tr)) < 2e-6
+    k2t = O.mean_kl(t_new, t_old, obs, n, m, hid, tr2, tr)
+    assert abs(k2 - k2t) < 1e-5 * k2t and abs(k2 - k1) > 1e-3 * k1t
+    eng.tr_new.copy_(torch.from_numpy(pk).to(eng.device))      # back: the image applies again, same bits as before
+    assert eng.eval_surr_kl() == (s1, k1)
+    eng.close()
+
+
 def test_eval_reuses_old_policy_outputs_only_when_unchanged():
     """K3 after K1 takes the old policy's means / log-likelihoods from what K1 stored -- but only while the
     old parameters still equal the snapshot taken then; an in-place change of theta_old must be noticed by
