@@ -41,6 +41,7 @@ struct GemmArgs {
   const float* osc; const float* osh;             // per-column affine (EPI_BIAS_AFFINE)
   const float* ls; float inv_N;                   // EPI_FVP_HEAD: log_std per column, 1 / N_global
   int fast;                                       // set by launch_tile: the interior fast path of the 256-column tiles may be used
+  int rows_padded;                                // A / aux / C are workspace blocks with rows allocated up to a multiple of 128
   int epi;
 #ifdef MJX_PHASE_CLOCK
   long long* clk;                                 // timing build: 8 int64 per workgroup (tools/lw_clock.py)
@@ -497,6 +498,10 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second a
 }
 
 // x~ = (x - in_shift) / (in_scale + 1e-8)    fc_network.py:46
+}  // namespace mjx
+#include "lw_gemm_p.h"
+namespace mjx {
+
 __global__ void k_normalize(const float* __restrict__ x, int64_t N, int n, const float* __restrict__ tr, float* __restrict__ o) {
   const int64_t tot = N * n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
@@ -868,7 +873,7 @@ struct LayerwiseWS {
     fwd_valid = false;
     if (m > MPH) return -3;
     if (N <= cap) return 0;
-    int64_t newcap = N;
+    int64_t newcap = (N + 127) / 128 * 128;       // whole 128-row tiles: the persistent GEMM (lw_gemm_p.h) reads / writes the padding rows
     std::vector<int> hid(sizes.begin() + 1, sizes.end() - 1);
     release();
     if (hipMalloc(&Xn, (size_t)newcap * n * 4) != hipSuccess) return 2;
@@ -977,10 +982,54 @@ struct LayerwiseWS {
     }
     return best;
   }
+  // Sample-major products in their steady-state shape go to the persistent kernel (lw_gemm_p.h).
+  // MJX_LW_PERSIST=0 keeps everything on the general kernel.
+  static int persistent_lb(const GemmArgs& g, int splits) {        // -> 0 / 1: the B layout it can run with, -1: not eligible
+    static const bool on = [] { const char* e = getenv("MJX_LW_PERSIST"); return !(e && e[0] == '0'); }();
+    if (!on || splits != 1 || tile_mode() != 1 || g.M < 2 * GP_BM || g.N < GP_BN || (g.N % GP_BN) != 0) return -1;
+    if ((g.M % GP_BM) != 0 && !g.rows_padded) return -1;
+    if ((g.epi != EPI_TANGENT && g.epi != EPI_BACK) || !g.aux || (g.c_cs != 0 && g.c_cs != 1) || g.c_zs != 0) return -1;
+    if (g.epi == EPI_TANGENT && !g.bias) return -1;
+    if (g.ldc >= (1 << 24) || g.ld_aux >= (1 << 24) || (((uintptr_t)g.C | (uintptr_t)g.aux) & 3)) return -1;
+    int lb = -1;
+    for (int p = 0; p < g.npairs; ++p) {
+      if (g.K[p] < 2 * GP_BK || (g.K[p] % GP_BK) != 0) return -1;
+      if (g.a_ks[p] != 1 || (g.a_rs[p] & 3) != 0 || (((uintptr_t)g.A[p]) & 15) != 0) return -1;
+      int l;
+      if (g.b_ks[p] == 1 && (g.b_cs[p] & 3) == 0 && (((uintptr_t)g.B[p]) & 15) == 0) l = 0;
+      else if (g.b_cs[p] == 1 && (g.b_ks[p] & 3) == 0 && (((uintptr_t)g.B[p]) & 15) == 0) l = 1;
+      else return -1;
+      if (lb >= 0 && l != lb) return -1;
+      lb = l;
+    }
+    return lb;
+  }
+  template <int LB, int EPI>
+  static void launch_p(const GemmArgs& g, int row_tiles, hipStream_t st) {
+    void (*const kern)(GemmArgs, int, int, int*) = k_gemm_p<LB, EPI, GemmArgs>;
+    static const bool attr_set = [kern] {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gp_lds_bytes<LB>());
+      return true;
+    }();
+    (void)attr_set;
+    static const int ncu = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c; }();
+    const int cbs = g.N / GP_BN, ntiles = row_tiles * cbs;
+    static int* ticket = [] { int* p = nullptr; (void)hipMalloc(&p, 256); return p; }();      // (one per process: launches are stream-ordered)
+    (void)hipMemsetAsync(ticket, 0, sizeof(int), st);
+    hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(GP_NTH), gp_lds_bytes<LB>(), st, g, row_tiles, cbs, ticket);
+  }
+  static void launch_persistent(const GemmArgs& g0, int lb, hipStream_t st) {
+    GemmArgs g = g0;
+    if (!g.cs_ld) g.cs_ld = g.N;
+    const int row_tiles = (g.M + GP_BM - 1) / GP_BM;
+    if (g.epi == EPI_TANGENT) { if (lb) launch_p<1, EPI_TANGENT>(g, row_tiles, st); else launch_p<0, EPI_TANGENT>(g, row_tiles, st); }
+    else { if (lb) launch_p<1, EPI_BACK>(g, row_tiles, st); else launch_p<0, EPI_BACK>(g, row_tiles, st); }
+  }
   // wgrad: the contraction runs over samples (split over blockIdx.z) and the M x N output is small
   static void launch_gemm(const GemmArgs& g, int splits, hipStream_t st, bool wgrad = false) {
     (void)wgrad;
     if (g.N <= 32) { launch_tile<128, 32>(g, splits, st); return; }
+    { const int lb = persistent_lb(g, splits); if (lb >= 0) { launch_persistent(g, lb, st); return; } }
     if (tile_mode() == 2) { launch_tile<128, 128, 256>(g, splits, st); return; }
     if (!wide_tiles()) { launch_tile<128, 128>(g, splits, st); return; }
     // 256-column blocks; a remainder of up to 128 columns gets its own 128-column launch (a half-empty 256-column
@@ -1090,6 +1139,7 @@ struct LayerwiseWS {
         b.C = T[l - 1]; b.ldc = hi_; b.c_zs = 0;
         b.aux = H[l - 1]; b.ld_aux = hi_;
         b.epi = EPI_BACK;
+        b.rows_padded = (delta != d3) ? 1 : 0;         // (delta of a hidden layer lives in T[l]; the top delta d3 has no padding rows)
         b.colsum = (rowblocks == 1) ? grad + ob[l - 1] : cpart;
         launch_gemm(b, 1, st);
         if (rowblocks > 1024) {
@@ -1147,7 +1197,7 @@ struct LayerwiseWS {
       g.c_zs = 0;
       // the output layer's tangent goes straight to d3 = out_scale D mudot / N in the GEMM epilogue (no pass over N x m)
       if (last) { g.C = d3; g.ldc = m; g.epi = EPI_FVP_HEAD; g.osc = tr + 2 * n + m; g.ls = theta + oS; g.inv_N = (float)(1.0 / (double)Ng); }
-      else { g.C = T[l]; g.ldc = sizes[l + 1]; g.epi = EPI_TANGENT; g.aux = H[l]; g.ld_aux = sizes[l + 1]; }
+      else { g.C = T[l]; g.ldc = sizes[l + 1]; g.epi = EPI_TANGENT; g.aux = H[l]; g.ld_aux = sizes[l + 1]; g.rows_padded = 1; }
       if (last && head_fused()) break;
       launch_gemm(g, 1, st);
       tin = last ? nullptr : T[l];

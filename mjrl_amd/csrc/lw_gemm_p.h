@@ -1,0 +1,230 @@
+// lw_gemm_p.h -- persistent interior-tile GEMM for the sample-major products of the layer-wise Fisher-vector product.
+//
+// The per-workgroup clocks of the general kernel (tools/lw_clock.py) show a 128 x 256 tile whose k-loop
+// already runs at the matrix-core rate, wrapped in 2.5-3.5 us of prologue (first operand tiles: one exposed memory latency),
+// 5-6 us of epilogue (the activation operand's latency + 2 us of store issue) and 0.3-0.8 us of dispatch gap -- 8-14 % of a
+// K <= 512 product, with nothing to overlap it: one workgroup per CU (108 KB of LDS).  The general k_gemm cannot take
+// another live register (256 VGPRs at two waves per SIMD; every addition re-allocates its hot loops, +-5 %), so this is a
+// separate, lean kernel for exactly the steady-state case:
+//   * one workgroup per CU walks the 128 x 256 tiles of the product (tickets from an atomic counter); the operands live in workspace buffers
+//     whose row count is padded to a multiple of 128 (LayerwiseWS::reserve), so the last row tile is computed like the others
+//     -- its surplus rows read and write padding, only the column sums mask them (a masked variant of the loads / stores cost
+//     the hot loop 5-8 % through register allocation);
+//   * A operands K-contiguous (activations), B either K-contiguous (LB = 0: weights as "NT", the tangent products) or
+//     row-contiguous (LB = 1: weights as "NN", the backward products); K of every operand pair a multiple of 32, >= 64;
+//   * under the MFMAs of a tile's LAST k-tile it requests the epilogue's activation block (64 registers) and the NEXT tile's
+//     first operand k-tile, so that the epilogue computes on data that has arrived and the next k-loop starts without a
+//     cold prologue; the epilogue's stores drain under the next tile's MFMAs.
+// Other shapes and other epilogues stay with the general kernel (layerwise.h).
+// Same arithmetic in the same order as k_gemm's fast path: bit-identical products; the column sums of the delta products
+// (bias gradients) can differ in the last bit (the compiler contracts `sum += acc * factor` differently around the row mask);
+// tests/test_gpu_parity.py::test_persistent_gemm_bitwise_equals_general_kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "fused_policy.h"
+
+// (included by layerwise.h after GemmArgs and the EPI_* kinds are declared)
+namespace mjx {
+
+constexpr int GP_BM = 128, GP_BN = 256, GP_BK = 32, GP_LD = GP_BK + 4, GP_NTH = 512;
+constexpr int GP_ASZ = GP_BM * GP_LD;                                                  // [row][k] image of the A tile
+template <int LB> constexpr int gp_bsz() { return LB ? GP_BK * (GP_BN + 4) : GP_BN * GP_LD; }
+template <int LB> constexpr size_t gp_lds_bytes() { return sizeof(float) * (size_t)(2 * GP_ASZ + 2 * gp_bsz<LB>() + 2 * GP_BN); }
+
+template <int LB, int EPI, class Args>
+__global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int col_blocks, int* __restrict__ ticket) {
+  constexpr int WN = 4, TM = 64, TN = 64, MT = 2, NT = 2;
+  constexpr int BSZ = gp_bsz<LB>();
+  constexpr int CA = GP_BM * 8 / GP_NTH, CB = GP_BN * 8 / GP_NTH;        // float4 per thread and operand k-tile: 2, 4
+  extern __shared__ __attribute__((aligned(16))) float gps[];
+  float* As = gps;                         // [2][GP_ASZ]
+  float* Bs = gps + 2 * GP_ASZ;            // [2][BSZ]
+  float* Cs = Bs + 2 * BSZ;                // [2][256]: column sums of the two wave rows (EPI_BACK)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wv / WN, wn = wv % WN;
+  __shared__ int s_next;
+  const int ntiles = row_tiles * col_blocks;
+  int t = blockIdx.x;                      // the first tile of every workgroup is its block index, the following ones come from
+  if (t >= ntiles) return;                 // a ticket counter (zeroed before the launch): 3 907 tiles over 256 workgroups as a
+                                           // static stride would end in a 16th round that only 67 workgroups run (+4.7 %)
+  const int KT0 = g.K[0] / GP_BK, KT = KT0 + (g.npairs > 1 ? g.K[1] / GP_BK : 0);
+
+  // per-thread operand pointers of the k-tile that is loaded next (bumped by one k-tile per load)
+  const float* pa[CA];
+  const float* pb[CB];
+  int64_t sb = 0;
+  auto rebase = [&](int tile, int p) {
+    const int m0 = (tile / col_blocks) * GP_BM, n0 = (tile % col_blocks) * GP_BN;
+    const float* __restrict__ Ap = g.A[p];
+    const float* __restrict__ Bp = g.B[p];
+#pragma unroll
+    for (int c = 0; c < CA; ++c) {
+      const int idx = tid + GP_NTH * c;
+      pa[c] = Ap + (int64_t)(m0 + (idx >> 3)) * g.a_rs[p] + 4 * (idx & 7);
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int idx = tid + GP_NTH * c;
+      pb[c] = LB ? Bp + (int64_t)(idx / (GP_BN / 4)) * g.b_ks[p] + n0 + 4 * (idx % (GP_BN / 4)) : Bp + (int64_t)(n0 + (idx >> 3)) * g.b_cs[p] + 4 * (idx & 7);
+    }
+    sb = LB ? (int64_t)GP_BK * g.b_ks[p] : GP_BK;
+  };
+  f32x4 ra[CA], rb[CB];
+  auto gload = [&]() {
+#pragma unroll
+    for (int c = 0; c < CA; ++c) { ra[c] = *(const f32x4*)pa[c]; pa[c] += GP_BK; }
+#pragma unroll
+    for (int c = 0; c < CB; ++c) { rb[c] = *(const f32x4*)pb[c]; pb[c] += sb; }
+  };
+  auto lstore = [&](int buf) {
+    float* Ad = As + buf * GP_ASZ;
+    float* Bd = Bs + buf * BSZ;
+#pragma unroll
+    for (int c = 0; c < CA; ++c) { const int idx = tid + GP_NTH * c; *(f32x4*)&Ad[(idx >> 3) * GP_LD + 4 * (idx & 7)] = ra[c]; }
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int idx = tid + GP_NTH * c;
+      if (LB) *(f32x4*)&Bd[(idx / (GP_BN / 4)) * (GP_BN + 4) + 4 * (idx % (GP_BN / 4))] = rb[c];
+      else *(f32x4*)&Bd[(idx >> 3) * GP_LD + 4 * (idx & 7)] = rb[c];
+    }
+  };
+  // operand fragments of k-group q (k-slot `hi` of step t carries k = 8 q + 4 hi + t for A and B alike)
+  auto fragA = [&](const float* S, int row0, int q) { return *(const f32x4*)&S[(row0 + j) * GP_LD + 8 * q + 4 * hi]; };
+  auto fragB = [&](const float* S, int col0, int q) {
+    if (LB) {
+      const float* p = &S[(8 * q + 4 * hi) * (GP_BN + 4) + col0 + j];
+      return f32x4{p[0], p[GP_BN + 4], p[2 * (GP_BN + 4)], p[3 * (GP_BN + 4)]};
+    }
+    return *(const f32x4*)&S[(col0 + j) * GP_LD + 8 * q + 4 * hi];
+  };
+
+  // `kl` counts the k-tiles of the current output tile that have been REQUESTED so far (the loader runs two ahead)
+  int kl = 0;
+  auto load_next = [&]() {                 // request the next k-tile of this output tile; switches to the second operand pair
+    if (kl == KT0) rebase(t, 1);
+    gload();
+    ++kl;
+  };
+  rebase(t, 0);
+  load_next();                             // k-tile 0
+  lstore(0);
+  load_next();                             // k-tile 1 (KT >= 2)
+  __syncthreads();
+
+  const uint32_t laneC = (uint32_t)(4 * hi) * (uint32_t)g.ldc + (uint32_t)j, laneA = (uint32_t)(4 * hi) * (uint32_t)g.ld_aux + (uint32_t)j;
+  auto rowof = [](int r) { return (r & 3) + 8 * (r >> 2); };
+
+  for (;;) {
+    const int m0 = (t / col_blocks) * GP_BM, n0 = (t % col_blocks) * GP_BN;
+    if (tid == 0) s_next = (int)gridDim.x + atomicAdd(ticket, 1);     // this workgroup's next tile; read after a k-tile barrier
+    int tn = 0;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[a][b] = (f32x16)(0.f);
+    float yall[MT * NT * 16];
+
+    // one k-tile: 64 MFMAs per wave; `mid0` runs after the first, `mid1` after the second MFMA group
+    auto body = [&](int kt, auto&& mid0, auto&& mid1) {
+      const float* Ac = As + (kt & 1) * GP_ASZ;
+      const float* Bc = Bs + (kt & 1) * BSZ;
+      f32x4 a4[MT], b4[NT], an[MT], bn[NT];
+#pragma unroll
+      for (int a = 0; a < MT; ++a) a4[a] = fragA(Ac, wm * TM + 32 * a, 0);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) b4[b] = fragB(Bc, wn * TN + 32 * b, 0);
+#pragma unroll
+      for (int q = 0; q < GP_BK / 8; ++q) {
+        if (q + 1 < GP_BK / 8) {
+#pragma unroll
+          for (int a = 0; a < MT; ++a) an[a] = fragA(Ac, wm * TM + 32 * a, q + 1);
+#pragma unroll
+          for (int b = 0; b < NT; ++b) bn[b] = fragB(Bc, wn * TN + 32 * b, q + 1);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] = MJX_MFMA(a4[a][tt], b4[b][tt], acc[a][b]);
+        if (q == 0) mid0();
+        if (q == 1) mid1();
+#pragma unroll
+        for (int a = 0; a < MT; ++a) a4[a] = an[a];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) b4[b] = bn[b];
+      }
+      __syncthreads();
+    };
+    auto nop = [] {};
+    int kt = 0;
+#pragma unroll 1
+    for (; kt + 2 < KT; ++kt)              // steady state: k-tile kt + 1 -> the other buffer, k-tile kt + 2 -> registers
+      body(kt, [&] { lstore((kt + 1) & 1); }, [&] { load_next(); });
+    body(kt, [&] { lstore((kt + 1) & 1); }, nop);
+    ++kt;
+    tn = s_next;
+    // last k-tile: the epilogue's activation block and the next output tile's first k-tile are requested under its MFMAs
+    body(kt,
+         [&] {
+#pragma unroll
+           for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+             for (int nt = 0; nt < NT; ++nt) {
+               const float* __restrict__ ab = g.aux + (int64_t)(m0 + wm * TM + mt * 32) * g.ld_aux + (n0 + wn * TN + nt * 32);
+#pragma unroll
+               for (int r = 0; r < 16; ++r) yall[(mt * NT + nt) * 16 + r] = (ab + (int64_t)rowof(r) * g.ld_aux)[laneA];
+             }
+         },
+         [&] {
+           if (tn < ntiles) { kl = 0; rebase(tn, 0); gload(); kl = 1; }
+         });
+    // (every wave is past the barrier that ended the last k-tile: both operand buffers are free)
+    if (tn < ntiles) {
+      lstore(0);                            // next tile's k-tile 0 (requested a k-tile ago)
+      // its k-tile 1 flies under the epilogue
+      if (kl == KT0) rebase(tn, 1);
+      gload();
+      ++kl;
+    }
+    // ---- epilogue
+    float csum[NT] = {0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + wn * TN + nt * 32 + j;
+        const float bias = (EPI == EPI_TANGENT) ? g.bias[col] : 0.f;
+        float* __restrict__ cb = g.C + (int64_t)(m0 + wm * TM + mt * 32) * g.ldc + (n0 + wn * TN + nt * 32);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float y = yall[(mt * NT + nt) * 16 + r];
+          float v = acc[mt][nt][r];
+          if (EPI == EPI_TANGENT) v = (v + bias) * fmaf(-y, y, 1.0f);
+          else v = v * fmaf(-y, y, 1.0f);
+          (cb + (int64_t)rowof(r) * g.ldc)[laneC] = v;
+          if (EPI == EPI_BACK) csum[nt] += (m0 + wm * TM + mt * 32 + unit_of(r, hi) < g.M) ? v : 0.f;    // (padding rows of the last tile)
+        }
+      }
+    if (EPI == EPI_BACK && g.colsum) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float s = half_sum(csum[nt]);
+        if (hi == 0) Cs[wm * GP_BN + wn * TN + nt * 32 + j] = s;
+      }
+    }
+    __syncthreads();                        // next tile's k-tile 0 is in buffer 0; the column sums are in Cs
+    if (EPI == EPI_BACK && g.colsum && tid < GP_BN)
+      g.colsum[(int64_t)(m0 / GP_BM) * (g.cs_ld ? g.cs_ld : g.N) + n0 + tid] = Cs[tid] + Cs[GP_BN + tid];
+    if (tn >= ntiles) break;
+    t = tn;
+  }
+}
+
+}  // namespace mjx

@@ -716,6 +716,37 @@ def test_other_shapes_vs_oracle(n, m, hid, expect_fused):
     eng.close()
 
 
+@pytest.mark.parametrize("n,m,h1,h2,N", [(64, 6, 256, 256, 3000 + 37), (96, 28, 512, 512, 2 * 128 + 1), (128, 3, 256, 512, 1024)])
+def test_persistent_gemm_bitwise_equals_general_kernel(tmp_path, n, m, h1, h2, N):
+    """The persistent interior-tile GEMM (csrc/lw_gemm_p.h: tangent and delta products of the layer-wise Fisher-vector
+    product) performs the same operations in the same order as the general kernel: the products must agree BIT FOR BIT
+    with MJX_LW_PERSIST=0 -- including a batch that ends in a partial 128-row tile (padding rows computed, never summed)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for tag, val in (("general", "0"), ("persistent", "1")):
+        env = dict(os.environ, MJX_LW_PERSIST=val)
+        out = str(tmp_path / (tag + ".npz"))
+        subprocess.run([sys.executable, os.path.join(here, "_lw_fvp_worker.py"), out, str(n), str(m), str(h1), str(h2), str(N)],
+                       check=True, env=env, timeout=600)
+        res[tag] = np.load(out)
+    # weights: bit for bit.  Bias gradients of the hidden layers are the column sums formed in the delta product's epilogue:
+    # the compiler contracts `sum += acc * factor` into an FMA in one kernel and not in the other (the row mask sits in
+    # between) -- last-bit differences, so those blocks are compared at 1e-6 of the block's largest entry.
+    bias = np.zeros(res["general"]["g"].size, bool)
+    o = n * h1
+    bias[o:o + h1] = True
+    o += h1 + h1 * h2
+    bias[o:o + h2] = True
+    for k in ("g", "hv"):
+        a, b = res["general"][k], res["persistent"][k]
+        assert np.array_equal(a[~bias], b[~bias]), k
+        assert np.abs(a[bias] - b[bias]).max() <= 1e-6 * np.abs(a[bias]).max(), k
+    assert np.isfinite(res["persistent"]["hv"]).all() and np.abs(res["persistent"]["hv"]).max() > 0
+    assert rel(res["persistent"]["hv2"], res["general"]["hv2"]) < 1e-6      # (a product of the slightly different g)
+
+
 def test_empty_shard_contributes_zero():
     """a rank that holds no trajectories (N_local == 0, N_global > 0) must produce zeros on both paths"""
     import torch
