@@ -503,11 +503,28 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second a
 #include "lw_gemm_p.h"
 namespace mjx {
 
-__global__ void k_normalize(const float* __restrict__ x, int64_t N, int n, const float* __restrict__ tr, float* __restrict__ o) {
-  const int64_t tot = N * n;
+__global__ void k_normalize(const float* __restrict__ x, int64_t N, int n, int ldo, const float* __restrict__ tr, float* __restrict__ o) {
+  // rows of o are padded to ldo = n rounded up to 4 floats (zeros): 16-byte operand granules for any observation width
+  const int64_t tot = N * ldo;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
-    int f = (int)(i % n);
-    o[i] = (x[i] - tr[f]) / (tr[n + f] + 1e-8f);
+    const int f = (int)(i % ldo);
+    const int64_t r = i / ldo;
+    o[i] = (f < n) ? (x[r * n + f] - tr[f]) / (tr[n + f] + 1e-8f) : 0.f;
+  }
+}
+
+// rows of `cols` floats <-> rows padded to `ld` floats (zeros): the first layer's weight block for observation widths
+// that are not a multiple of 4 (the 39 / 45 / 46-wide Adroit observations)
+__global__ void k_pad_rows(const float* __restrict__ src, int rows, int cols, int ld, float* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * ld; i += gridDim.x * blockDim.x) {
+    const int r = i / ld, c = i - r * ld;
+    dst[i] = c < cols ? src[r * cols + c] : 0.f;
+  }
+}
+__global__ void k_unpad_rows(const float* __restrict__ src, int rows, int cols, int ld, float* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += gridDim.x * blockDim.x) {
+    const int r = i / cols, c = i - r * cols;
+    dst[i] = src[r * ld + c];
   }
 }
 
@@ -838,7 +855,10 @@ struct LayerwiseWS {
   std::vector<int64_t> oW, ob;       // offsets in the flat vector
   int64_t oS = 0, d = 0;
   int64_t cap = 0;                   // rows allocated
-  float* Xn = nullptr;               // normalised obs (N x n)
+  float* Xn = nullptr;               // normalised obs (N x ldx(): rows padded with zeros to a multiple of 4 floats)
+  float* V1p = nullptr; float* G1p = nullptr;   // first-layer direction / gradient blocks with rows padded the same way (only when ldx() != n)
+  int ldx() const { return (n + 3) & ~3; }
+  int ld_in(int l) const { return l == 0 ? ldx() : sizes[l]; }   // row stride of layer l's input activations
   std::vector<float*> H;             // hidden activations of the NEW net (cached)
   std::vector<float*> T;             // tangent / delta buffers per hidden layer
   float *mu = nullptr, *mu2 = nullptr, *d3 = nullptr;   // (N x m)
@@ -862,6 +882,7 @@ struct LayerwiseWS {
   void invalidate() { fwd_valid = false; }
   void release() {
     hipFree(Xn); Xn = nullptr;
+    hipFree(V1p); V1p = nullptr; hipFree(G1p); G1p = nullptr;
     for (auto& p : H) { hipFree(p); p = nullptr; }
     for (auto& p : T) { hipFree(p); p = nullptr; }
     hipFree(mu); hipFree(mu2); hipFree(d3); hipFree(part); hipFree(hpart); hipFree(rd3); rd3 = nullptr; gen_cap = 0;
@@ -877,8 +898,12 @@ struct LayerwiseWS {
     int64_t newcap = (N + 127) / 128 * 128;       // whole 128-row tiles: the persistent GEMM (lw_gemm_p.h) reads / writes the padding rows
     std::vector<int> hid(sizes.begin() + 1, sizes.end() - 1);
     release();
-    if (hipMalloc(&Xn, ((size_t)newcap * n + 32) * 4) != hipSuccess) return 2;
-    (void)hipMemset(Xn, 0, ((size_t)newcap * n + 32) * 4);      // padding rows (+ a k-tile of slack) stay finite: lw_gemm_p.h reads them for K tails
+    if (hipMalloc(&Xn, ((size_t)newcap * ldx() + 32) * 4) != hipSuccess) return 2;
+    (void)hipMemset(Xn, 0, ((size_t)newcap * ldx() + 32) * 4);  // padding rows (+ a k-tile of slack) stay finite: lw_gemm_p.h reads them for K tails
+    if (ldx() != n && nL() >= 1) {                              // padded first-layer blocks (direction / gradient)
+      if (hipMalloc(&V1p, (size_t)sizes[1] * ldx() * 4) != hipSuccess) return 2;
+      if (hipMalloc(&G1p, (size_t)sizes[1] * ldx() * 4) != hipSuccess) return 2;
+    }
     for (size_t l = 0; l < hid.size(); ++l) {
       if (hipMalloc(&H[l], (size_t)newcap * hid[l] * 4) != hipSuccess) return 2;
       if (hipMalloc(&T[l], (size_t)newcap * hid[l] * 4) != hipSuccess) return 2;
@@ -995,7 +1020,7 @@ struct LayerwiseWS {
     if (g.ldc >= (1 << 24) || g.ld_aux >= (1 << 24) || (((uintptr_t)g.C | (uintptr_t)g.aux) & 3)) return -1;
     int lb = -1;
     for (int p = 0; p < g.npairs; ++p) {
-      if (g.K[p] < 2 * GP_BK) return -1;
+      if (g.K[p] <= GP_BK) return -1;                   // (at least two k-tiles)
       if ((g.K[p] % GP_BK) != 0) {                      // a K tail: one operand pair, B K-contiguous, whole 16-byte granules, A zero-padded below
         if (g.npairs != 1 || g.epi != EPI_TANGENT || (g.K[p] & 3) != 0 || g.b_ks[p] != 1 || !g.a_tail_ok) return -1;
       }
@@ -1058,13 +1083,13 @@ struct LayerwiseWS {
   // forward pass of one parameter set; acts[l] receives hidden layer l, out receives mu
   void forward(const float* theta, const float* tr, const float* obs, int64_t N, std::vector<float*>& acts, float* out,
                hipStream_t st) {
-    hipLaunchKernelGGL(k_normalize, dim3(ew_grid(N * n)), dim3(256), 0, st, obs, N, n, tr, Xn);
+    hipLaunchKernelGGL(k_normalize, dim3(ew_grid(N * ldx())), dim3(256), 0, st, obs, N, n, ldx(), tr, Xn);
     const float* in = Xn;
     for (int l = 0; l < nL(); ++l) {
       const bool last = (l == nL() - 1);
       GemmArgs g{};
       g.M = (int)N; g.N = sizes[l + 1]; g.npairs = 1; g.K[0] = sizes[l];
-      g.A[0] = in; g.a_rs[0] = sizes[l]; g.a_ks[0] = 1;
+      g.A[0] = in; g.a_rs[0] = (l == 0) ? ldx() : sizes[l]; g.a_ks[0] = 1;
       g.B[0] = theta + oW[l]; g.b_cs[0] = sizes[l]; g.b_ks[0] = 1;
       g.C = last ? out : acts[l]; g.ldc = sizes[l + 1]; g.c_zs = 0;
       g.bias = theta + ob[l];
@@ -1106,26 +1131,33 @@ struct LayerwiseWS {
       splits = pick_splits(N, narrow ? (hi_ + tbm - 1) / tbm : (ho + tbm - 1) / tbm, narrow ? ho : hi_, splits);
       const int csplits = 256;
       const int rsplits = 64;                      // second-stage split of the per-row-block column sums
-      if (ensure_part((int64_t)splits * ho * hi_ + (int64_t)csplits * ho + (int64_t)rowblocks * hi_ + (int64_t)rsplits * hi_)) return 2;
+      // first layer of an observation width that is not a multiple of 4: the gradient block is formed with padded rows
+      // (ldx() columns: 16-byte operand granules of Xn, the pad column is zero) and compacted afterwards
+      const bool padw = (l == 0) && !narrow && ldx() != n && G1p != nullptr;
+      const int wN = padw ? ldx() : hi_;
+      if (ensure_part((int64_t)splits * ho * wN + (int64_t)csplits * ho + (int64_t)rowblocks * hi_ + (int64_t)rsplits * hi_)) return 2;
       GemmArgs g{};
       g.npairs = 1; g.K[0] = (int)N;
       if (narrow) {
         g.M = hi_; g.N = ho;
-        g.A[0] = in; g.a_rs[0] = 1; g.a_ks[0] = hi_;
+        g.A[0] = in; g.a_rs[0] = 1; g.a_ks[0] = ld_in(l);
         g.B[0] = delta; g.b_cs[0] = 1; g.b_ks[0] = ho;
         g.ldc = 1; g.c_cs = hi_;                     // C^T(i = input unit, j = output unit) -> gW[j][i]
       } else {
         g.M = ho; g.N = hi_;
         g.A[0] = delta; g.a_rs[0] = 1; g.a_ks[0] = ho;
-        g.B[0] = in; g.b_cs[0] = 1; g.b_ks[0] = hi_;
+        g.B[0] = in; g.b_cs[0] = 1; g.b_ks[0] = ld_in(l);
         g.ldc = hi_;
       }
+      float* wdst = padw ? G1p : grad + oW[l];
+      if (padw) { g.N = wN; g.ldc = wN; }
       // (a single split / row block -- minibatches -- writes the gradient blocks directly: no reduction launches)
-      g.C = (splits == 1) ? grad + oW[l] : part; g.c_zs = (int64_t)ho * hi_;
+      g.C = (splits == 1) ? wdst : part; g.c_zs = (int64_t)ho * wN;
       g.epi = EPI_STORE;
       launch_gemm(g, splits, st, true);
-      if (splits > 1) reduce_split(part, splits, (int64_t)ho * hi_, grad + oW[l], st);
-      float* bpart = part + (int64_t)splits * ho * hi_;
+      if (splits > 1) reduce_split(part, splits, (int64_t)ho * wN, wdst, st);
+      if (padw) hipLaunchKernelGGL(k_unpad_rows, dim3(ew_grid((int64_t)ho * hi_)), dim3(256), 0, st, G1p, ho, hi_, wN, grad + oW[l]);
+      float* bpart = part + (int64_t)splits * ho * wN;
       float* cpart = bpart + (int64_t)csplits * ho;
       if (!bias_done) {
         const int cs = (N <= 4096) ? 1 : csplits;
@@ -1193,8 +1225,12 @@ struct LayerwiseWS {
       GemmArgs g{};
       g.M = (int)N; g.N = sizes[l + 1];
       g.npairs = tin ? 2 : 1;
-      g.K[0] = sizes[l]; g.A[0] = in; g.a_rs[0] = sizes[l]; g.a_ks[0] = 1;
+      g.K[0] = sizes[l]; g.A[0] = in; g.a_rs[0] = ld_in(l); g.a_ks[0] = 1;
       g.B[0] = v + oW[l]; g.b_cs[0] = sizes[l]; g.b_ks[0] = 1;
+      if (l == 0 && ldx() != n && V1p != nullptr) {       // padded rows: K = ldx() (the pad column of Xn and of V1p is zero)
+        hipLaunchKernelGGL(k_pad_rows, dim3(ew_grid((int64_t)sizes[1] * ldx())), dim3(256), 0, st, v + oW[0], sizes[1], n, ldx(), V1p);
+        g.K[0] = ldx(); g.B[0] = V1p; g.b_cs[0] = ldx();
+      }
       if (tin) {
         g.K[1] = sizes[l]; g.A[1] = tin; g.a_rs[1] = sizes[l]; g.a_ks[1] = 1;
         g.B[1] = theta + oW[l]; g.b_cs[1] = sizes[l]; g.b_ks[1] = 1;
@@ -1286,8 +1322,12 @@ struct LayerwiseWS {
       const float* in = (l == 0) ? Xn : H[l - 1];
       GemmArgs g{};
       g.M = (int)N; g.N = sizes[l + 1]; g.npairs = tin ? 2 : 1;
-      g.K[0] = sizes[l]; g.A[0] = in; g.a_rs[0] = sizes[l]; g.a_ks[0] = 1;
+      g.K[0] = sizes[l]; g.A[0] = in; g.a_rs[0] = ld_in(l); g.a_ks[0] = 1;
       g.B[0] = v + oW[l]; g.b_cs[0] = sizes[l]; g.b_ks[0] = 1;
+      if (l == 0 && ldx() != n && V1p != nullptr) {       // padded rows: K = ldx() (the pad column of Xn and of V1p is zero)
+        hipLaunchKernelGGL(k_pad_rows, dim3(ew_grid((int64_t)sizes[1] * ldx())), dim3(256), 0, st, v + oW[0], sizes[1], n, ldx(), V1p);
+        g.K[0] = ldx(); g.B[0] = V1p; g.b_cs[0] = ldx();
+      }
       if (tin) { g.K[1] = sizes[l]; g.A[1] = tin; g.a_rs[1] = sizes[l]; g.a_ks[1] = 1; g.B[1] = th_new + oW[l]; g.b_cs[1] = sizes[l]; g.b_ks[1] = 1; }
       g.bias = v + ob[l]; g.c_zs = 0;
       if (last) { g.C = rd3; g.ldc = m; g.epi = EPI_BIAS_AFFINE; g.osc = tr_new + 2 * n + m; g.osh = nullptr; }
@@ -1314,7 +1354,7 @@ struct LayerwiseWS {
       if (ensure_part((int64_t)splits * ho * hi_ + (int64_t)splits * ho)) return 2;
       GemmArgs g{};                                         // R{gW_l} = Rdelta^T in + delta^T Tin
       g.M = ho; g.N = hi_; g.npairs = tinl ? 2 : 1;
-      g.K[0] = (int)N; g.A[0] = rdl; g.a_rs[0] = 1; g.a_ks[0] = ho; g.B[0] = in; g.b_cs[0] = 1; g.b_ks[0] = hi_;
+      g.K[0] = (int)N; g.A[0] = rdl; g.a_rs[0] = 1; g.a_ks[0] = ho; g.B[0] = in; g.b_cs[0] = 1; g.b_ks[0] = ld_in(l);
       if (tinl) { g.K[1] = (int)N; g.A[1] = dl; g.a_rs[1] = 1; g.a_ks[1] = ho; g.B[1] = tinl; g.b_cs[1] = 1; g.b_ks[1] = hi_; }
       g.C = part; g.ldc = hi_; g.c_zs = (int64_t)ho * hi_; g.epi = EPI_STORE;
       launch_gemm(g, splits, st, true);
