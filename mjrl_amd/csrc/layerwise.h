@@ -990,6 +990,13 @@ struct LayerwiseWS {
   // (LDS), so tiles x splits = 490 workgroups on 256 CUs (configs[3]: 2 row tiles x 245 splits) is two rounds, the second
   // 91 % full, each paying the per-workgroup prologue / epilogue; 2 x 128 is ONE full round of twice-as-long workgroups.
   // cost(s) = rounds(s) x (samples per workgroup + ~9 us of fixed cost in sample units); the search keeps s within [cap/4, cap].
+  // Weight gradients with 33..128 columns (the first layer of a narrow observation: 512 x 40 at configs[4]) are bound by the
+  // bytes they keep in flight, not by the matrix cores (3.3 us per k-tile against 1 us of MFMAs): 128 x 128 tiles in
+  // 256-thread workgroups, two per CU (MJX_LW_THIN=0: one 512-thread workgroup per CU as for the wide ones)
+  static bool thin_wgrad(int ncols) {
+    static const bool on = [] { const char* e = getenv("MJX_LW_THIN"); return !(e && e[0] == '0'); }();
+    return on && ncols > 32 && ncols <= 128 && tile_mode() == 1;
+  }
   static int pick_splits(int64_t N, int row_tiles, int ncols, int cap) {
     static const int ncu = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c; }();
     static const bool on = [] { const char* e = getenv("MJX_LW_SPLITS"); return !(e && e[0] == '0'); }();
@@ -1000,10 +1007,11 @@ struct LayerwiseWS {
       else { cb = ncols / 256 + ((ncols % 256) > 128 ? 1 : 0); if (cb < 1) cb = 1; }
     }
     const int64_t tl = (int64_t)row_tiles * cb;
+    const int slots = ncu * (thin_wgrad(ncols) ? 2 : 1);     // (thin products run two 256-thread workgroups per CU, launch_gemm)
     int best = cap;
     double bestc = 1e300;
     for (int s = cap; s >= cap / 4 && s >= 1; --s) {
-      const int64_t rounds = (tl * s + ncu - 1) / ncu;
+      const int64_t rounds = (tl * s + slots - 1) / slots;
       const double c = (double)rounds * ((double)N / s + 74.0);
       if (c < bestc * 0.999) { bestc = c; best = s; }
     }
@@ -1065,6 +1073,7 @@ struct LayerwiseWS {
     if (!wide_tiles()) { launch_tile<128, 128>(g, splits, st); return; }
     // 256-column blocks; a remainder of up to 128 columns gets its own 128-column launch (a half-empty 256-column
     // block would spend matrix-core time on padding), a larger one rides in one more 256-column block
+    if (splits > 1 && thin_wgrad(g.N)) { launch_tile<128, 128, 256>(g, splits, st); return; }
     int n256 = (g.N / 256) * 256, rem = g.N - n256;
     if (rem > 128) { n256 = g.N; rem = 0; }
     if (n256 == g.N) { launch_tile<128, 256>(g, splits, st); return; }
