@@ -42,7 +42,6 @@ struct GemmArgs {
   const float* ls; float inv_N;                   // EPI_FVP_HEAD: log_std per column, 1 / N_global
   int fast;                                       // set by launch_tile: the interior fast path of the 256-column tiles may be used
   int rows_padded;                                // A / aux / C are workspace blocks with rows allocated up to a multiple of 128
-  int a_tail_ok;                                  // A[0] may be read up to 28 floats past the end of a row (finite values: Xn)
   int epi;
 #ifdef MJX_PHASE_CLOCK
   long long* clk;                                 // timing build: 8 int64 per workgroup (tools/lw_clock.py)
@@ -857,7 +856,9 @@ struct LayerwiseWS {
   int64_t cap = 0;                   // rows allocated
   float* Xn = nullptr;               // normalised obs (N x ldx(): rows padded with zeros to a multiple of 4 floats)
   float* V1p = nullptr; float* G1p = nullptr;   // first-layer direction / gradient blocks with rows padded the same way (only when ldx() != n)
-  int ldx() const { return (n + 3) & ~3; }
+  // (up to 32 features: whole 16-byte granules; beyond: whole 128-byte k-tiles, so that every k-tile segment of a row is one
+  //  cache line and the first layer needs no K tail -- 376 -> 384, 39 -> 64)
+  int ldx() const { return n <= 32 ? ((n + 3) & ~3) : ((n + 31) & ~31); }
   int ld_in(int l) const { return l == 0 ? ldx() : sizes[l]; }   // row stride of layer l's input activations
   std::vector<float*> H;             // hidden activations of the NEW net (cached)
   std::vector<float*> T;             // tangent / delta buffers per hidden layer
@@ -898,8 +899,8 @@ struct LayerwiseWS {
     int64_t newcap = (N + 127) / 128 * 128;       // whole 128-row tiles: the persistent GEMM (lw_gemm_p.h) reads / writes the padding rows
     std::vector<int> hid(sizes.begin() + 1, sizes.end() - 1);
     release();
-    if (hipMalloc(&Xn, ((size_t)newcap * ldx() + 32) * 4) != hipSuccess) return 2;
-    (void)hipMemset(Xn, 0, ((size_t)newcap * ldx() + 32) * 4);  // padding rows (+ a k-tile of slack) stay finite: lw_gemm_p.h reads them for K tails
+    if (hipMalloc(&Xn, (size_t)newcap * ldx() * 4) != hipSuccess) return 2;
+    (void)hipMemset(Xn, 0, (size_t)newcap * ldx() * 4);
     if (ldx() != n && nL() >= 1) {                              // padded first-layer blocks (direction / gradient)
       if (hipMalloc(&V1p, (size_t)sizes[1] * ldx() * 4) != hipSuccess) return 2;
       if (hipMalloc(&G1p, (size_t)sizes[1] * ldx() * 4) != hipSuccess) return 2;
@@ -1028,10 +1029,7 @@ struct LayerwiseWS {
     if (g.ldc >= (1 << 24) || g.ld_aux >= (1 << 24) || (((uintptr_t)g.C | (uintptr_t)g.aux) & 3)) return -1;
     int lb = -1;
     for (int p = 0; p < g.npairs; ++p) {
-      if (g.K[p] <= GP_BK) return -1;                   // (at least two k-tiles)
-      if ((g.K[p] % GP_BK) != 0) {                      // a K tail: one operand pair, B K-contiguous, whole 16-byte granules, A zero-padded below
-        if (g.npairs != 1 || g.epi != EPI_TANGENT || (g.K[p] & 3) != 0 || g.b_ks[p] != 1 || !g.a_tail_ok) return -1;
-      }
+      if (g.K[p] < 2 * GP_BK || (g.K[p] % GP_BK) != 0) return -1;       // whole k-tiles, at least two
       if (g.a_ks[p] != 1 || (g.a_rs[p] & 3) != 0 || (((uintptr_t)g.A[p]) & 15) != 0) return -1;
       int l;
       if (g.b_ks[p] == 1 && (g.b_cs[p] & 3) == 0 && (((uintptr_t)g.B[p]) & 15) == 0) l = 0;
@@ -1042,9 +1040,9 @@ struct LayerwiseWS {
     }
     return lb;
   }
-  template <int LB, int EPI, bool TAIL = false>
+  template <int LB, int EPI>
   static void launch_p(const GemmArgs& g, int row_tiles, hipStream_t st) {
-    void (*const kern)(GemmArgs, int, int, int*) = k_gemm_p<LB, EPI, TAIL, GemmArgs>;
+    void (*const kern)(GemmArgs, int, int, int*) = k_gemm_p<LB, EPI, GemmArgs>;
     static const bool attr_set = [kern] {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gp_lds_bytes<LB>());
       return true;
@@ -1060,7 +1058,6 @@ struct LayerwiseWS {
     GemmArgs g = g0;
     if (!g.cs_ld) g.cs_ld = g.N;
     const int row_tiles = (g.M + GP_BM - 1) / GP_BM;
-    if (g.epi == EPI_TANGENT && (g.K[0] % GP_BK) != 0) { launch_p<0, EPI_TANGENT, true>(g, row_tiles, st); return; }
     if (g.epi == EPI_TANGENT) { if (lb) launch_p<1, EPI_TANGENT>(g, row_tiles, st); else launch_p<0, EPI_TANGENT>(g, row_tiles, st); }
     else { if (lb) launch_p<1, EPI_BACK>(g, row_tiles, st); else launch_p<0, EPI_BACK>(g, row_tiles, st); }
   }
@@ -1248,7 +1245,7 @@ struct LayerwiseWS {
       g.c_zs = 0;
       // the output layer's tangent goes straight to d3 = out_scale D mudot / N in the GEMM epilogue (no pass over N x m)
       if (last) { g.C = d3; g.ldc = m; g.epi = EPI_FVP_HEAD; g.osc = tr + 2 * n + m; g.ls = theta + oS; g.inv_N = (float)(1.0 / (double)Ng); }
-      else { g.C = T[l]; g.ldc = sizes[l + 1]; g.epi = EPI_TANGENT; g.aux = H[l]; g.ld_aux = sizes[l + 1]; g.rows_padded = 1; g.a_tail_ok = (l == 0); }
+      else { g.C = T[l]; g.ldc = sizes[l + 1]; g.epi = EPI_TANGENT; g.aux = H[l]; g.ld_aux = sizes[l + 1]; g.rows_padded = 1; }
       if (last && head_fused()) break;
       launch_gemm(g, 1, st);
       tin = last ? nullptr : T[l];

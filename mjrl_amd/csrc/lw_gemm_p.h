@@ -11,7 +11,8 @@
 //     -- its surplus rows read and write padding, only the column sums mask them (a masked variant of the loads / stores cost
 //     the hot loop 5-8 % through register allocation);
 //   * A operands K-contiguous (activations), B either K-contiguous (LB = 0: weights as "NT", the tangent products) or
-//     row-contiguous (LB = 1: weights as "NN", the backward products); K of every operand pair a multiple of 32, >= 64;
+//     row-contiguous (LB = 1: weights as "NN", the backward products); K of every operand pair a multiple of 32, >= 64 (the
+//     first layer gets there through observation rows padded to whole 128-byte k-tiles: LayerwiseWS::ldx);
 //   * under the MFMAs of a tile's last two k-tiles it requests the epilogue's activation block (64 registers) and the NEXT
 //     tile's first operand k-tile, so that the epilogue computes on data that has arrived and the next k-loop starts without a
 //     cold prologue; the epilogue's stores drain under the next tile's MFMAs.
@@ -35,12 +36,8 @@ constexpr int GP_ASZ = GP_BM * GP_LD;                                           
 template <int LB> constexpr int gp_bsz() { return LB ? GP_BK * (GP_BN + 4) : GP_BN * GP_LD; }
 template <int LB> constexpr size_t gp_lds_bytes() { return sizeof(float) * (size_t)(2 * GP_ASZ + 2 * gp_bsz<LB>() + 2 * GP_BN); }
 
-// TAIL: a single operand pair whose K is a multiple of 4 but not of 32 (the first layer of a 376-wide observation, B as "NT"):
-// the last k-tile's weight granules past K are zeroed; the activation operand is read past its row end (the next row; for the
-// last row the zero-initialised padding rows of the workspace) and multiplied by those zeros.
-template <int LB, int EPI, bool TAIL, class Args>
+template <int LB, int EPI, class Args>
 __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int col_blocks, int* __restrict__ ticket) {
-  static_assert(!TAIL || LB == 0, "K tails are handled for K-contiguous B operands only");
   constexpr int WN = 4, TM = 64, TN = 64, MT = 2, NT = 2;
   constexpr int BSZ = gp_bsz<LB>();
   constexpr int CA = GP_BM * 8 / GP_NTH, CB = GP_BN * 8 / GP_NTH;        // float4 per thread and operand k-tile: 2, 4
@@ -56,8 +53,7 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
   int t = blockIdx.x;                      // the first tile of every workgroup is its block index, the following ones come from
   if (t >= ntiles) return;                 // a ticket counter (zeroed before the launch): 3 907 tiles over 256 workgroups as a
                                            // static stride would end in a 16th round that only 67 workgroups run (+4.7 %)
-  const int KT0 = (g.K[0] + GP_BK - 1) / GP_BK, KT = KT0 + ((!TAIL && g.npairs > 1) ? g.K[1] / GP_BK : 0);
-  int kcur = 0;                            // TAIL: k offset of the k-tile the loader requests next
+  const int KT0 = g.K[0] / GP_BK, KT = KT0 + (g.npairs > 1 ? g.K[1] / GP_BK : 0);
 
   // per-thread operand pointers of the k-tile that is loaded next (bumped by one k-tile per load)
   const float* pa[CA];
@@ -78,18 +74,13 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
       pb[c] = LB ? Bp + (int64_t)(idx / (GP_BN / 4)) * g.b_ks[p] + n0 + 4 * (idx % (GP_BN / 4)) : Bp + (int64_t)(n0 + (idx >> 3)) * g.b_cs[p] + 4 * (idx & 7);
     }
     sb = LB ? (int64_t)GP_BK * g.b_ks[p] : GP_BK;
-    if (TAIL) kcur = 0;
   };
   f32x4 ra[CA], rb[CB];
   auto gload = [&]() {
 #pragma unroll
     for (int c = 0; c < CA; ++c) { ra[c] = *(const f32x4*)pa[c]; pa[c] += GP_BK; }
 #pragma unroll
-    for (int c = 0; c < CB; ++c) {
-      rb[c] = *(const f32x4*)pb[c]; pb[c] += sb;
-      if (TAIL) { if (kcur + 4 * ((tid + GP_NTH * c) & 7) >= g.K[0]) rb[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    }
-    if (TAIL) kcur += GP_BK;
+    for (int c = 0; c < CB; ++c) { rb[c] = *(const f32x4*)pb[c]; pb[c] += sb; }
   };
   auto lstore = [&](int buf) {
     float* Ad = As + buf * GP_ASZ;

@@ -717,7 +717,7 @@ def test_other_shapes_vs_oracle(n, m, hid, expect_fused):
 
 
 @pytest.mark.parametrize("n,m,h1,h2,N", [(64, 6, 256, 256, 3000 + 37), (96, 28, 512, 512, 2 * 128 + 1), (128, 3, 256, 512, 1024),
-                                         (88, 5, 256, 256, 1500 + 3)])      # (n = 88: a K tail of 24 in the first layer, like configs[3]'s 376)
+                                         (88, 5, 256, 256, 1500 + 3)])      # (n = 88: observation rows padded to 96 = three whole k-tiles, like configs[3]'s 376 -> 384)
 def test_persistent_gemm_bitwise_equals_general_kernel(tmp_path, n, m, h1, h2, N):
     """The persistent interior-tile GEMM (csrc/lw_gemm_p.h: tangent and delta products of the layer-wise Fisher-vector
     product) performs the same operations in the same order as the general kernel: the products must agree BIT FOR BIT
