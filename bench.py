@@ -184,7 +184,7 @@ def secondary_measurements(eng, theta0, theta0_dev):
         flop = 2 * (4 * P - 2 * n * hid[0]) * N
         ms = prof[0] / prof[1]
         lw[name] = {"rows": N, "fvp_ms": ms, "TFLOPs": flop / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
-                    "flop_per_fvp": flop, "kernels": "k_gemm<128,256> / <128,128> / <128,32> chain with fused epilogues (csrc/layerwise.h)",
+                    "flop_per_fvp": flop, "kernels": "k_gemm_p (persistent tangent / delta products, csrc/lw_gemm_p.h) + k_gemm<128,256> / <128,128> weight gradients + k_lw_head (one-pass output layer, csrc/lw_head.h)",
                     "timed": "4 products, HIP events around the whole chain of one product"}
         e.close()
         del e
