@@ -1287,7 +1287,20 @@ struct LayerwiseWS {
       (void)attr_set;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lw_head_lds_bytes(), st, a);
     };
-    switch (hl / 128) {
+    auto launch8 = [&](auto ch) {             // 256 / 512 units: the eight-wave build (two waves per SIMD)
+      constexpr int CH = decltype(ch)::value;
+      void (*const kern)(HeadArgs) = k_lw_head8<CH>;
+      static const bool attr_set = [kern] {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw_head8_lds_bytes());
+        return true;
+      }();
+      (void)attr_set;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lw_head8_lds_bytes(), st, a);
+    };
+    static const bool eight = [] { const char* e = getenv("MJX_LW_HEAD8"); return !(e && e[0] == '0'); }();
+    if (eight && hl == 256) launch8(std::integral_constant<int, 1>{});
+    else if (eight && hl == 512) launch8(std::integral_constant<int, 2>{});
+    else switch (hl / 128) {
       case 1: launch(std::integral_constant<int, 1>{}); break;
       case 2: launch(std::integral_constant<int, 2>{}); break;
       case 3: launch(std::integral_constant<int, 3>{}); break;

@@ -225,4 +225,172 @@ __global__ __launch_bounds__(256, 1) void k_lw_head(HeadArgs a) {
   if (tid < m) a.gb_part[(int64_t)blockIdx.x * m + tid] = gbacc;
 }
 
+// The same pass with EIGHT waves (512 threads, two per SIMD at <= 256 registers) for last hidden layers of 256 / 512 units:
+// phase 1 splits every k-tile's four k-groups over two wave quartets (4 partial mudots), phase 2 gives each wave h / 8 columns
+// (one or two 32-column chunks: 16..32 accumulator registers instead of 64), so two waves per SIMD fit without spills and hide
+// each other's memory latency.
+constexpr size_t lw_head8_lds_bytes() { return sizeof(float) * (size_t)(2 * 2 * LH_R * LH_LD + 2 * 2 * 32 * LH_LD + 4 * LH_R * LH_MS); }
+
+template <int CH>       // h = 256 * CH
+__global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lhs[];
+  float* Abuf = lhs;                                   // [pair][buf][64][36]
+  float* Bbuf = Abuf + 2 * 2 * LH_R * LH_LD;           // [pair][buf][32][36]
+  float* mud = Bbuf + 2 * 2 * 32 * LH_LD;              // [4 partials][64][33]; [0] becomes d3
+  constexpr int h = 256 * CH, NKT = h / 32;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int rb1 = wv & 1, pr1 = (wv >> 1) & 1, kh1 = wv >> 2;      // phase 1: row block, operand pair, half of the k-groups
+  const int m = a.m;
+  const int64_t ntile = (a.N + LH_R - 1) / LH_R;
+  f32x16 gacc[CH];
+  float csum[CH];
+  float gbacc = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) { gacc[i] = (f32x16)(0.f); csum[i] = 0.f; }
+  const int ca = tid & 31;
+  float c_osc = 0.f, c_dk = 0.f, c_b = 0.f;
+  if (ca < m) {
+    const float sg = expf(a.ls[ca]);
+    c_osc = a.osc[ca]; c_dk = 2.0f / (2.0f * sg * sg + 1e-8f); c_b = a.c3[ca];
+  }
+  const uint32_t laneoff = (uint32_t)(4 * hi) * (uint32_t)h + (uint32_t)j;
+  auto rowof = [](int r) { return (r & 3) + 8 * (r >> 2); };
+
+  // per k-tile: A 2 pairs x 64 rows x 8 float4 = 1024 -> two per thread; B 2 pairs x 32 rows x 8 = 512 -> one per thread
+  auto gload = [&](f32x4 (&ra)[2], f32x4& rbq, int64_t r0, int kt) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float* __restrict__ S = p ? (const float*)a.T : a.H;
+      const int row = tid >> 3;                        // 0..63
+      const bool ok = r0 + row < a.N;
+      const f32x4 v = *(const f32x4*)(S + (ok ? (r0 + row) : 0) * (int64_t)h + 32 * kt + 4 * (tid & 7));
+      ra[p] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int pb = tid >> 8, act = (tid >> 3) & 31;
+    const float* __restrict__ Wm = pb ? a.W3 : a.V3;
+    const f32x4 w = *(const f32x4*)(Wm + (int64_t)(act < m ? act : 0) * h + 32 * kt + 4 * (tid & 7));
+    rbq = act < m ? w : (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto lstore = [&](const f32x4 (&ra)[2], const f32x4& rbq, int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *(f32x4*)&Abuf[((p * 2 + buf) * LH_R + (tid >> 3)) * LH_LD + 4 * (tid & 7)] = ra[p];
+    *(f32x4*)&Bbuf[(((tid >> 8) * 2 + buf) * 32 + ((tid >> 3) & 31)) * LH_LD + 4 * (tid & 7)] = rbq;
+  };
+  f32x4 raA[2], rbA, raB[2], rbB;
+  if ((int64_t)blockIdx.x < ntile) { gload(raA, rbA, (int64_t)blockIdx.x * LH_R, 0); gload(raB, rbB, (int64_t)blockIdx.x * LH_R, 1); }
+
+  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int64_t row0 = tile * LH_R;
+    const bool full = row0 + LH_R <= a.N;
+    f32x16 acc1 = (f32x16)(0.f);
+    auto compute = [&](int buf) {
+      const float* Ac = Abuf + ((pr1 * 2 + buf) * LH_R + 32 * rb1 + j) * LH_LD + 4 * hi + 16 * kh1;
+      const float* Bc = Bbuf + ((pr1 * 2 + buf) * 32 + j) * LH_LD + 4 * hi + 16 * kh1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 a4 = *(const f32x4*)(Ac + 8 * q), b4 = *(const f32x4*)(Bc + 8 * q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc1 = MJX_MFMA(a4[t], b4[t], acc1);
+      }
+    };
+    __syncthreads();
+    lstore(raA, rbA, 0);
+    gload(raA, rbA, row0, 2);              // (NKT >= 8)
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < NKT; kt += 2) {
+      lstore(raB, rbB, 1);
+      if (kt + 3 < NKT) gload(raB, rbB, row0, kt + 3);
+      compute(0);
+      __syncthreads();
+      if (kt + 2 < NKT) {
+        lstore(raA, rbA, 0);
+        if (kt + 4 < NKT) gload(raA, rbA, row0, kt + 4);
+      }
+      compute(1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mud[((kh1 * 2 + pr1) * LH_R + 32 * rb1 + unit_of(r, hi)) * LH_MS + j] = acc1[r];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < LH_R * 32 / 512; ++c) {
+      const int row = (tid >> 5) + 16 * c;
+      float v = (mud[row * LH_MS + ca] + mud[(LH_R + row) * LH_MS + ca]) + (mud[(2 * LH_R + row) * LH_MS + ca] + mud[(3 * LH_R + row) * LH_MS + ca]) + c_b;
+      v = v * c_osc;
+      v = c_osc * (c_dk * v * a.inv_N);
+      mud[row * LH_MS + ca] = (ca < m && row0 + row < a.N) ? v : 0.f;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int row = 0; row < LH_R; ++row) s += mud[row * LH_MS + tid];
+      gbacc += s;
+    }
+    if (tile + gridDim.x < ntile) { gload(raA, rbA, (tile + gridDim.x) * LH_R, 0); gload(raB, rbB, (tile + gridDim.x) * LH_R, 1); }
+    auto phase2 = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int cb = 32 * (8 * i + wv);
+        __builtin_amdgcn_sched_barrier(0);
+        float w3f[16];
+        const float* w3p = a.W3;             // (laundered: keeps these loads inside the tile loop, see k_lw_head)
+        asm volatile("" : "+s"(w3p));
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int act = 2 * s + hi;
+          const float w = w3p[(int64_t)(act < m ? act : 0) * h + cb + j];
+          w3f[s] = act < m ? w : 0.f;
+        }
+#pragma unroll 1
+        for (int rb = 0; rb < 2; ++rb) {
+          __builtin_amdgcn_sched_barrier(0);
+          const float* __restrict__ Hb = a.H + (row0 + 32 * rb) * (int64_t)h + cb;
+          float* __restrict__ Db = a.T + (row0 + 32 * rb) * (int64_t)h + cb;
+          float y[16];
+          if (FULL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = (Hb + rowof(r) * h)[laneoff];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int64_t row = row0 + 32 * rb + unit_of(r, hi);
+              y[r] = a.H[(row < a.N ? row : a.N - 1) * (int64_t)h + cb + j];
+            }
+          }
+          f32x16 dacc = (f32x16)(0.f);
+#pragma unroll
+          for (int s = 0; s < 16; ++s) dacc = MJX_MFMA(mud[(32 * rb + j) * LH_MS + 2 * s + hi], w3f[s], dacc);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float dv = dacc[r] * fmaf(-y[r], y[r], 1.0f);
+            csum[i] += dv;
+            if (FULL) (Db + rowof(r) * h)[laneoff] = dv;
+            else if (row0 + 32 * rb + unit_of(r, hi) < a.N) (Db + rowof(r) * h)[laneoff] = dv;
+            gacc[i] = MJX_MFMA(mud[(32 * rb + unit_of(r, hi)) * LH_MS + j], y[r], gacc[i]);
+          }
+        }
+      }
+    };
+    if (full) phase2(std::true_type{});
+    else phase2(std::false_type{});
+  }
+  float* gw = a.gw_part + (int64_t)blockIdx.x * m * h;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int col = 32 * (8 * i + wv) + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int act = unit_of(r, hi);
+      if (act < m) gw[(int64_t)act * h + col] = gacc[i][r];
+    }
+    const float t = half_sum(csum[i]);
+    if (hi == 0) a.cs_part[(int64_t)blockIdx.x * h + col] = t;
+  }
+  if (tid < m) a.gb_part[(int64_t)blockIdx.x * m + tid] = gbacc;
+}
+
 }  // namespace mjx
