@@ -56,7 +56,9 @@ constexpr int LW_CLK_SLOT = 8 + 8 * 16384, LW_CLK_SLOTS = 24;
 inline long long*& lw_clk_buf() { static long long* p = nullptr; return p; }
 inline int& lw_clk_slot() { static int s = 0; return s; }
 #define LW_STAMP(k) do { if (g.clk && tid == 0 && blockIdx.z == 0) { __builtin_amdgcn_sched_barrier(0); \
-  g.clk[8 + 8 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+  g.clk[8 + 8 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+  if ((k) == 1 || (k) == 2) g.clk[8 + 8 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) + 5 + (k)] = (long long)__builtin_readcyclecounter(); \
+  __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define LW_STAMP(k) do {} while (0)
 #endif
@@ -1052,6 +1054,13 @@ struct LayerwiseWS {
     const int cbs = g.N / GP_BN, ntiles = row_tiles * cbs;
     static int* ticket = [] { int* p = nullptr; (void)hipMalloc(&p, 256); return p; }();      // (one per process: launches are stream-ordered)
     (void)hipMemsetAsync(ticket, 0, sizeof(int), st);
+#ifdef MJX_PHASE_CLOCK
+    if (lw_clk_buf() && lw_clk_slot() < LW_CLK_SLOTS) {
+      GemmArgs h = g; h.clk = lw_clk_buf() + (int64_t)(lw_clk_slot()++) * LW_CLK_SLOT;
+      hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(GP_NTH), gp_lds_bytes<LB>(), st, h, row_tiles, cbs, ticket);
+      return;
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(GP_NTH), gp_lds_bytes<LB>(), st, g, row_tiles, cbs, ticket);
   }
   static void launch_persistent(const GemmArgs& g0, int lb, hipStream_t st) {

@@ -120,8 +120,24 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
   const uint32_t laneC = (uint32_t)(4 * hi) * (uint32_t)g.ldc + (uint32_t)j, laneA = (uint32_t)(4 * hi) * (uint32_t)g.ld_aux + (uint32_t)j;
   auto rowof = [](int r) { return (r & 3) + 8 * (r >> 2); };
 
+#ifdef MJX_PHASE_CLOCK
+#define GP_STAMP(k) do { if (g.clk && tid == 0 && t < 16384) { __builtin_amdgcn_sched_barrier(0); \
+  g.clk[8 + 8 * t + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+  if ((k) == 0 || (k) == 1) g.clk[8 + 8 * t + 6 + (k)] = (long long)__builtin_readcyclecounter(); \
+  __builtin_amdgcn_sched_barrier(0); } } while (0)
+  if (g.clk && tid == 0 && blockIdx.x == 0) {
+    g.clk[0] = g.M; g.clk[1] = g.N; g.clk[2] = g.K[0]; g.clk[3] = g.npairs > 1 ? g.K[1] : 0; g.clk[4] = g.epi; g.clk[5] = 1000 + GP_BN;
+    g.clk[6] = ntiles < 16384 ? ntiles : 16384; g.clk[7] = 1;
+  }
+#else
+#define GP_STAMP(k) do {} while (0)
+#endif
   for (;;) {
     const int m0 = (t / col_blocks) * GP_BM, n0 = (t % col_blocks) * GP_BN;
+    GP_STAMP(0);
+#ifdef MJX_PHASE_CLOCK
+    if (g.clk && tid == 0 && t < 16384) { g.clk[8 + 8 * t + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g.clk[8 + 8 * t + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+#endif
     if (tid == 0) s_next = (int)gridDim.x + atomicAdd(ticket, 1);     // this workgroup's next tile; read after a k-tile barrier
     int tn = 0;
     f32x16 acc[MT][NT];
@@ -184,6 +200,7 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
     ++kt;
     tn = s_next;
     body(kt, [&] { if (tn < ntiles) { kl = 0; rebase(tn, 0); gload(); kl = 1; } }, nop);
+    GP_STAMP(1); GP_STAMP(2);
     // (every wave is past the barrier that ended the last k-tile: both operand buffers are free)
     if (tn < ntiles) {
       lstore(0);                            // next tile's k-tile 0 (requested a k-tile ago)
@@ -221,6 +238,7 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
     __syncthreads();                        // next tile's k-tile 0 is in buffer 0; the column sums are in Cs
     if (EPI == EPI_BACK && g.colsum && tid < GP_BN)
       g.colsum[(int64_t)(m0 / GP_BM) * (g.cs_ld ? g.cs_ld : g.N) + n0 + tid] = Cs[tid] + Cs[GP_BN + tid];
+    GP_STAMP(3);
     if (tn >= ntiles) break;
     t = tn;
   }

@@ -1,7 +1,9 @@
 """Per-workgroup timeline of the k_gemm launches of ONE layer-wise Fisher-vector product (timing build of the library:
 hipcc ... -DMJX_PHASE_CLOCK -o mjrl_amd/csrc/libmjx_clock.so; MJX_LIB=mjrl_amd/csrc/libmjx_clock.so python tools/lw_clock.py --cfg cfg4).
-For every launch: lifetime of a workgroup split into prologue (entry -> first MFMA), k-loop, epilogue, and the idle gap
-between consecutive workgroups on the same CU (launch + dispatch overhead)."""
+For every launch: lifetime of a workgroup split into prologue (entry -> first MFMA), k-loop, epilogue, the idle gap
+between consecutive workgroups on the same CU (launch + dispatch overhead) and the shader clock over the k-loop.  For the
+persistent kernel (BN printed as 1000 + 256) a "workgroup" is one output tile: `prologue_us` is its k-loop, `epilogue_us`
+its epilogue up to the barrier before the next tile."""
 import argparse
 import collections
 import json
@@ -64,6 +66,12 @@ def main():
         for lst in per_cu.values():
             for x, y in zip(lst[:-1], lst[1:]):
                 gaps.append(t[y, 0] - t[x, 3])
+        # shader clock over the k-loop (cycle counter against the 100 MHz real-time counter; persistent kernel: stamps 0..1)
+        pers = int(hdr[5]) >= 1000
+        dt_us = (t[:, 1] - t[:, 0]) if pers else (t[:, 2] - t[:, 1])
+        cyc = (st[:, 7] - st[:, 6]).astype(np.float64)
+        okc = (dt_us > 1.0) & (cyc > 0)
+        ghz = float(np.median(cyc[okc] / dt_us[okc]) / 1e3) if okc.any() else None
         span = t[:, 3].max() - t[:, 0].min()
         M, Nn, K0, K1 = int(hdr[0]), int(hdr[1]), int(hdr[2]), int(hdr[3])
         flop = 2.0 * M * Nn * (K0 + K1)
@@ -72,7 +80,7 @@ def main():
                    wg_life_us=round(float(np.median(life)), 2), prologue_us=round(float(np.median(pro)), 2), loop_us=round(float(np.median(loop)), 2),
                    epilogue_us=round(float(np.median(epi)), 2), gap_us=round(float(np.median(gaps)), 2) if gaps else None,
                    gap_p90_us=round(float(np.percentile(gaps, 90)), 2) if gaps else None,
-                   wgs_per_cu=round(nb / max(1, len(per_cu)), 2))
+                   wgs_per_cu=round(nb / max(1, len(per_cu)), 2), kloop_clock_GHz=round(ghz, 3) if ghz else None)
         out.append(rec)
         print(json.dumps(rec))
     e.close()
