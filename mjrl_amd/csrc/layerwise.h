@@ -857,7 +857,7 @@ struct LayerwiseWS {
   int64_t oS = 0, d = 0;
   int64_t cap = 0;                   // rows allocated
   float* Xn = nullptr;               // normalised obs (N x ldx(): rows padded with zeros to a multiple of 4 floats)
-  float* V1p = nullptr; float* G1p = nullptr;   // first-layer direction / gradient blocks with rows padded the same way (only when ldx() != n)
+  float* V1p = nullptr; float* G1p = nullptr; float* W1p = nullptr;   // first-layer direction / gradient / weight blocks with rows padded the same way (only when ldx() != n)
   // (up to 32 features: whole 16-byte granules; beyond: whole 128-byte k-tiles, so that every k-tile segment of a row is one
   //  cache line and the first layer needs no K tail -- 376 -> 384, 39 -> 64)
   int ldx() const { return n <= 32 ? ((n + 3) & ~3) : ((n + 31) & ~31); }
@@ -885,7 +885,7 @@ struct LayerwiseWS {
   void invalidate() { fwd_valid = false; }
   void release() {
     hipFree(Xn); Xn = nullptr;
-    hipFree(V1p); V1p = nullptr; hipFree(G1p); G1p = nullptr;
+    hipFree(V1p); V1p = nullptr; hipFree(G1p); G1p = nullptr; hipFree(W1p); W1p = nullptr;
     for (auto& p : H) { hipFree(p); p = nullptr; }
     for (auto& p : T) { hipFree(p); p = nullptr; }
     hipFree(mu); hipFree(mu2); hipFree(d3); hipFree(part); hipFree(hpart); hipFree(rd3); rd3 = nullptr; gen_cap = 0;
@@ -906,6 +906,7 @@ struct LayerwiseWS {
     if (ldx() != n && nL() >= 1) {                              // padded first-layer blocks (direction / gradient)
       if (hipMalloc(&V1p, (size_t)sizes[1] * ldx() * 4) != hipSuccess) return 2;
       if (hipMalloc(&G1p, (size_t)sizes[1] * ldx() * 4) != hipSuccess) return 2;
+      if (hipMalloc(&W1p, (size_t)sizes[1] * ldx() * 4) != hipSuccess) return 2;
     }
     for (size_t l = 0; l < hid.size(); ++l) {
       if (hipMalloc(&H[l], (size_t)newcap * hid[l] * 4) != hipSuccess) return 2;
@@ -1026,8 +1027,9 @@ struct LayerwiseWS {
     static const bool on = [] { const char* e = getenv("MJX_LW_PERSIST"); return !(e && e[0] == '0'); }();
     if (!on || splits != 1 || tile_mode() != 1 || g.M < 2 * GP_BM || g.N < GP_BN || (g.N % GP_BN) != 0) return -1;
     if ((g.M % GP_BM) != 0 && !g.rows_padded) return -1;
-    if ((g.epi != EPI_TANGENT && g.epi != EPI_BACK) || !g.aux || (g.c_cs != 0 && g.c_cs != 1) || g.c_zs != 0) return -1;
-    if (g.epi == EPI_TANGENT && !g.bias) return -1;
+    if ((g.epi != EPI_TANGENT && g.epi != EPI_BACK && g.epi != EPI_BIAS_TANH) || (g.c_cs != 0 && g.c_cs != 1) || g.c_zs != 0) return -1;
+    if (g.epi != EPI_BIAS_TANH && !g.aux) return -1;
+    if (g.epi != EPI_BACK && !g.bias) return -1;
     if (g.ldc >= (1 << 24) || g.ld_aux >= (1 << 24) || (((uintptr_t)g.C | (uintptr_t)g.aux) & 3)) return -1;
     int lb = -1;
     for (int p = 0; p < g.npairs; ++p) {
@@ -1067,6 +1069,7 @@ struct LayerwiseWS {
     GemmArgs g = g0;
     if (!g.cs_ld) g.cs_ld = g.N;
     const int row_tiles = (g.M + GP_BM - 1) / GP_BM;
+    if (g.epi == EPI_BIAS_TANH) { if (lb) launch_p<1, EPI_BIAS_TANH>(g, row_tiles, st); else launch_p<0, EPI_BIAS_TANH>(g, row_tiles, st); return; }
     if (g.epi == EPI_TANGENT) { if (lb) launch_p<1, EPI_TANGENT>(g, row_tiles, st); else launch_p<0, EPI_TANGENT>(g, row_tiles, st); }
     else { if (lb) launch_p<1, EPI_BACK>(g, row_tiles, st); else launch_p<0, EPI_BACK>(g, row_tiles, st); }
   }
@@ -1106,10 +1109,15 @@ struct LayerwiseWS {
       g.M = (int)N; g.N = sizes[l + 1]; g.npairs = 1; g.K[0] = sizes[l];
       g.A[0] = in; g.a_rs[0] = (l == 0) ? ldx() : sizes[l]; g.a_ks[0] = 1;
       g.B[0] = theta + oW[l]; g.b_cs[0] = sizes[l]; g.b_ks[0] = 1;
+      if (l == 0 && !last && ldx() != n && W1p != nullptr) {       // padded rows: K = ldx() (the pad columns of Xn and of W1p are zero)
+        hipLaunchKernelGGL(k_pad_rows, dim3(ew_grid((int64_t)sizes[1] * ldx())), dim3(256), 0, st, theta + oW[0], sizes[1], n, ldx(), W1p);
+        g.K[0] = ldx(); g.B[0] = W1p; g.b_cs[0] = ldx();
+      }
       g.C = last ? out : acts[l]; g.ldc = sizes[l + 1]; g.c_zs = 0;
       g.bias = theta + ob[l];
       g.epi = last ? EPI_BIAS_AFFINE : EPI_BIAS_TANH;
       g.osc = tr + 2 * n + m; g.osh = tr + 2 * n;
+      g.rows_padded = last ? 0 : 1;                  // hidden activations live in workspace blocks (H / T: whole 128-row tiles)
       launch_gemm(g, 1, st);
       in = g.C;
     }

@@ -16,6 +16,7 @@
 //   * under the MFMAs of a tile's last two k-tiles it requests the epilogue's activation block (64 registers) and the NEXT
 //     tile's first operand k-tile, so that the epilogue computes on data that has arrived and the next k-loop starts without a
 //     cold prologue; the epilogue's stores drain under the next tile's MFMAs.
+// Epilogues: tangent ((acc + c)(1 - y^2)), delta (acc (1 - y^2) + column sums), forward (tanh(acc + b)).
 // Other shapes and other epilogues stay with the general kernel (layerwise.h).
 // Same arithmetic in the same order as k_gemm's fast path: bit-identical products; the column sums of the delta products
 // (bias gradients) can differ in the last bit (the compiler contracts `sum += acc * factor` differently around the row mask);
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
     // registers are free once k-tile KT - 1 is in LDS), the NEXT output tile's first k-tile under the last one
     body(kt, [&] { lstore((kt + 1) & 1); },
          [&] {
+           if (EPI == EPI_BIAS_TANH) return;       // (the forward products have no activation operand)
 #pragma unroll
            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -216,13 +218,14 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int col = n0 + wn * TN + nt * 32 + j;
-        const float bias = (EPI == EPI_TANGENT) ? g.bias[col] : 0.f;
+        const float bias = (EPI == EPI_TANGENT || EPI == EPI_BIAS_TANH) ? g.bias[col] : 0.f;
         float* __restrict__ cb = g.C + (int64_t)(m0 + wm * TM + mt * 32) * g.ldc + (n0 + wn * TN + nt * 32);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float y = yall[(mt * NT + nt) * 16 + r];
+          const float y = (EPI == EPI_BIAS_TANH) ? 0.f : yall[(mt * NT + nt) * 16 + r];
           float v = acc[mt][nt][r];
-          if (EPI == EPI_TANGENT) v = (v + bias) * fmaf(-y, y, 1.0f);
+          if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
+          else if (EPI == EPI_TANGENT) v = (v + bias) * fmaf(-y, y, 1.0f);
           else v = v * fmaf(-y, y, 1.0f);
           (cb + (int64_t)rowof(r) * g.ldc)[laneC] = v;
           if (EPI == EPI_BACK) csum[nt] += (m0 + wm * TM + mt * 32 + unit_of(r, hi) < g.M) ? v : 0.f;    // (padding rows of the last tile)
