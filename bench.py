@@ -183,9 +183,19 @@ def secondary_measurements(eng, theta0, theta0_dev):
         P = sum(sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1))
         flop = 2 * (4 * P - 2 * n * hid[0]) * N
         ms = prof[0] / prof[1]
+        # one whole NPG update of this shard (K1, the config's CG iterations, step, K3) through the one-call entry point
+        cg_iters = 25 if hid[0] == 256 else 10
+        e.npg_update(cg_iters, 1e-4, 0.05, -3.0)
+        e.set_policy(th, th, ident, ident)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e.npg_update(cg_iters, 1e-4, 0.05, -3.0)
+        torch.cuda.synchronize()
+        upd_ms = 1e3 * (time.perf_counter() - t0)
         lw[name] = {"rows": N, "fvp_ms": ms, "TFLOPs": flop / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
                     "flop_per_fvp": flop, "kernels": "k_gemm_p (persistent tangent / delta products, csrc/lw_gemm_p.h) + k_gemm<128,256> / <128,128> weight gradients + k_lw_head (one-pass output layer, csrc/lw_head.h)",
-                    "timed": "4 products, HIP events around the whole chain of one product"}
+                    "timed": "4 products, HIP events around the whole chain of one product",
+                    "npg_update_ms": upd_ms, "cg_iters": cg_iters}
         e.close()
         del e
         torch.cuda.empty_cache()
