@@ -337,54 +337,51 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         return fmaf(-step_size * mi, r, p);
       };
       f32x2* __restrict__ MV = (f32x2*)A.mv;
-      auto adam = [&](float* p_lds, int64_t gi, float g) {
-        f32x2 q = MV[gi];
-        *p_lds = adam_math(*p_lds, g, q);
-        MV[gi] = q;
-      };
-      // Every owned element sits at a compile-time offset from one per-lane base.  All moment pairs of the
-      // thread's 64 W2 weights are requested up front (the backward pass's registers are free by now), so the
-      // L2 latency is paid once; then update, write the weight to LDS and the pair back.
+      // Every owned element sits at a compile-time offset from one per-lane base.  ALL moment pairs a thread owns -- its 64 W2
+      // weights, its 16 W1 / b1 entries, its b2 / W3 / b3 entry -- are requested up front (the backward pass's registers are
+      // free by now), so the L2 latency is paid once per step and not once per block (the three small blocks used to
+      // follow as dependent load -> update -> store sequences: ~2 k cycles each); then update, write the weight to LDS and
+      // the pair back.  Threads that do not own an entry of a block read a valid dummy pair and store nothing.
       {
-        const int64_t gbase = oW2g + (int64_t)(32 * w + 4 * hi) * H + j;
-        f32x2* __restrict__ mvW = MV + gbase;
-        float* pW = sW2 + (32 * w + 4 * hi) * S2 + j;
-        f32x2 q[NT][16];
+        const int64_t gbase2 = oW2g + (int64_t)(32 * w + 4 * hi) * H + j;
+        f32x2* __restrict__ mvW2 = MV + gbase2;
+        float* pW2 = sW2 + (32 * w + 4 * hi) * S2 + j;
+        // W1 rows of this wave (lane j < d_in) and b1 (lane j == d_in): one base pointer + a small per-register stride
+        const bool isw = j < d_in, own1 = j <= d_in;
+        const int stg = isw ? d_in : 1;
+        const int64_t gbase1 = isw ? oW1g + (int64_t)(32 * w + 4 * hi) * d_in + j : oB1g + 32 * w + 4 * hi;
+        f32x2* __restrict__ mvW1 = MV + (own1 ? gbase1 : 0);
+        float* pW1 = sW1 + (32 * w + 4 * hi) * S1 + (isw ? j : d_in);
+        const bool ownb2 = hi == 0, ownw3 = tid < H, ownb3 = tid == 0;
+        const int64_t gb2i = oB2g + 32 * w + j, gw3i = oW3g + (ownw3 ? tid : 0), gb3i = oB3g;
+        f32x2 q2[NT][16], q1[16];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) q[nt][r] = mvW[unit_of(r, 0) * H + 32 * nt];
+          for (int r = 0; r < 16; ++r) q2[nt][r] = mvW2[unit_of(r, 0) * H + 32 * nt];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q1[r] = mvW1[own1 ? unit_of(r, 0) * stg : 0];
+        f32x2 qb2 = MV[gb2i], qw3 = MV[gw3i], qb3 = MV[gb3i];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int o = unit_of(r, 0) * H + 32 * nt, ol = unit_of(r, 0) * S2 + 32 * nt;
-            pW[ol] = adam_math(pW[ol], gW2[nt][r], q[nt][r]);
-            mvW[o] = q[nt][r];
+            pW2[ol] = adam_math(pW2[ol], gW2[nt][r], q2[nt][r]);
+            mvW2[o] = q2[nt][r];
           }
-      }
-      {
-        // W1 rows of this wave (lane j < d_in) and b1 (lane j == d_in): one base pointer + a small per-register stride
-        const bool isw = j < d_in, own = j <= d_in;
-        const int stg = isw ? d_in : 1;
-        const int64_t gbase = isw ? oW1g + (int64_t)(32 * w + 4 * hi) * d_in + j : oB1g + 32 * w + 4 * hi;
-        f32x2* __restrict__ mvW = MV + (own ? gbase : 0);
-        float* pW = sW1 + (32 * w + 4 * hi) * S1 + (isw ? j : d_in);
-        f32x2 q[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) q[r] = mvW[own ? unit_of(r, 0) * stg : 0];
-        if (own) {
+        if (own1) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int o = unit_of(r, 0) * stg, ol = unit_of(r, 0) * S1;
-            pW[ol] = adam_math(pW[ol], gW1[r], q[r]);
-            mvW[o] = q[r];
+            pW1[ol] = adam_math(pW1[ol], gW1[r], q1[r]);
+            mvW1[o] = q1[r];
           }
         }
+        if (ownb2) { sB2[32 * w + j] = adam_math(sB2[32 * w + j], gb2, qb2); MV[gb2i] = qb2; }
+        if (ownw3) { sW3[tid] = adam_math(sW3[tid], gw3, qw3); MV[gw3i] = qw3; }
+        if (ownb3) { sB3[0] = adam_math(sB3[0], gb3, qb3); MV[gb3i] = qb3; }
       }
-      if (hi == 0) adam(&sB2[32 * w + j], oB2g + 32 * w + j, gb2);
-      if (tid < H) adam(&sW3[tid], oW3g + tid, gw3);
-      if (tid == 0) adam(&sB3[0], oB3g, gb3);
       __syncthreads();
       { const int hb = 0; MJX_FIT_STAMP(10); }
     }
