@@ -678,6 +678,9 @@ def test_hvp_sample_frac_rng_parity():
     (12, 32, (128, 384), False),   # ... 384, 32 actions (its upper limit) ...
     (39, 28, (512, 512), False),   # ... 512 (configs[4]); N = 3000 + n leaves a partial 64-row tile in every case
     (10, 4, (256, 192), False),    # last hidden layer not a multiple of 128: the generic chain
+    (40, 5, (256, 512, 256), False),   # three hidden layers through every r02 path: padded observation rows (40 -> 64), persistent
+                                       # forward / tangent / delta products with one and two 256-column blocks, the eight-wave output pass
+    (33, 2, (128,), False),        # one hidden layer of 128 units, 33 observations (-> 64): no fused output pass (needs two layers)
 ])
 def test_other_shapes_vs_oracle(n, m, hid, expect_fused):
     """every kernel variant / dispatch branch: K1, K2, K3 against the fp64 oracle (with transforms, old != new in K3)"""
