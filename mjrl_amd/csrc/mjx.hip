@@ -9,7 +9,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <unistd.h>
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -920,6 +924,67 @@ int mjx_policy_minibatch_adam(mjx_ctx* c, int loss, const float* obs, const floa
   return MJX_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// Persistent host workers for mjx_host_gather: a training iteration issues ~12 gathers of 8-50 MB, and creating 7-15
+// std::threads for each (20-50 us apiece) cost as much as the copies they performed.  Workers sleep on a condition variable;
+// one job at a time (a second caller -- the prefetch thread and the trainer may overlap -- falls back to its own threads).
+// The pool is leaked on purpose (no joins in static destructors; a forked child simply finds no workers and copies inline).
+struct HostPool {
+  static constexpr int MAXW = 31;
+  std::mutex m, run_m;
+  std::condition_variable cv, done_cv;
+  const std::function<void(int)>* job = nullptr;
+  int active = 0, pending = 0;
+  uint64_t gen = 0;
+  int nworkers = 0;
+  pid_t owner = 0;
+  void ensure(int n) {
+    if (n > MAXW) n = MAXW;
+    while (nworkers < n) {
+      const int t = ++nworkers;
+      std::thread([this, t] {
+        uint64_t seen = 0;
+        for (;;) {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return gen != seen; });
+          seen = gen;
+          const bool mine = t < active;
+          const std::function<void(int)>* j = job;
+          lk.unlock();
+          if (mine) {
+            (*j)(t);
+            lk.lock();
+            if (--pending == 0) done_cv.notify_one();
+          }
+        }
+      }).detach();
+    }
+  }
+  // run fn(0 .. nt-1), fn(0) on the calling thread; false if the pool is busy or unusable (the caller uses its own threads)
+  bool run(int nt, const std::function<void(int)>& fn) {
+    if (owner != getpid()) { if (owner != 0) return false; owner = getpid(); }
+    std::unique_lock<std::mutex> rl(run_m, std::try_to_lock);
+    if (!rl.owns_lock()) return false;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      ensure(nt - 1);
+      job = &fn; active = nt; pending = nt - 1; ++gen;
+    }
+    cv.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lk(m);
+    done_cv.wait(lk, [&] { return pending == 0; });
+    job = nullptr; active = 0;
+    return true;
+  }
+};
+HostPool& host_pool() { static HostPool* p = new HostPool(); return *p; }
+}  // namespace
+
+extern "C" {
+
 int mjx_host_gather(void* dst, const void* const* src, const int64_t* offsets, int64_t first, int64_t count,
                     int64_t row_bytes, int n_threads) {
   if (!dst || !src || !offsets || first < 0 || count < 0 || row_bytes <= 0) return fail(MJX_ERR_ARG, "bad arguments");
@@ -939,6 +1004,11 @@ int mjx_host_gather(void* dst, const void* const* src, const int64_t* offsets, i
     }
   };
   if (nt == 1) { work(0); return MJX_OK; }
+  if (nt > HostPool::MAXW + 1) nt = HostPool::MAXW + 1;
+  {
+    const std::function<void(int)> fn = work;
+    if (host_pool().run(nt, fn)) return MJX_OK;
+  }
   std::vector<std::thread> th;
   th.reserve(nt - 1);
   for (int t = 1; t < nt; ++t) th.emplace_back(work, t);

@@ -25,7 +25,7 @@ class PathStager:
     The returned tensors are views of buffers owned by the stager: they stay valid until the
     next ``begin`` / ``stage`` call (one batch at a time, like the update engine itself)."""
 
-    def __init__(self, backend, threads=8, group_rows=262144, native=None):
+    def __init__(self, backend, threads=16, group_rows=262144, native=None):
         self.backend = backend
         self.torch = backend.torch
         self.device = backend.device
