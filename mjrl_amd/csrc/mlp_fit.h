@@ -61,7 +61,9 @@ struct MlpFitLayout {
   __host__ __device__ size_t bytes() const { return (size_t)TOTAL * 4; }
 };
 
-template <int H>
+// NF1: 32-feature blocks of the input layer's weight gradient -- 1 for d_in <= 31 (the MuJoCo locomotion observations + 4 time
+// features), 2 for d_in <= 63 as far as the LDS layout fits 160 KB (d_in <= 43: the 39-wide Adroit door / relocate observations).
+template <int H, int NF1 = 1>
 __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   static_assert(H == 128, "wave w owns unit tile w: 4 waves x 32 units");
   using LT = MlpFitLayout<H>;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
 
   const float b1c = 0.9f, b2c = 0.999f, eps = 1e-8f;
   double pw1 = pow((double)b1c, (double)A.step0), pw2 = pow((double)b2c, (double)A.step0);
-  constexpr int GL = (32 * 32 + 255) / 256;         // gather elements per thread (d_in <= 31)
+  constexpr int GL = (32 * 32 * NF1 + 255) / 256;   // gather elements per thread (d_in <= 32 NF1 - 1)
   float gx[GL];
   float gy = 0.f;
 
@@ -133,10 +135,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
     if (A.steps > 0) { index_load(ep, 0, 0); gather_load(); index_load(ep, 0, 1); }
 #pragma unroll 1
     for (int64_t mb = 0; mb < A.steps; ++mb) {
-      f32x16 gW2[NT], gW1;
+      f32x16 gW2[NT], gW1[NF1];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) gW2[nt] = (f32x16)(0.f);
-      gW1 = (f32x16)(0.f);
+#pragma unroll
+      for (int fb = 0; fb < NF1; ++fb) gW1[fb] = (f32x16)(0.f);
       float gb2 = 0.f, gw3 = 0.f, gb3 = 0.f;
 #pragma unroll 1
       for (int hb = 0; hb < 2; ++hb) {
@@ -308,12 +311,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         MJX_FIT_STAMP(7);
         // grad W1a rows of this wave (column d_in = grad b1)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 b4 = *(const f32x4*)&xT[(j < K1 ? j : 0) * ST + 8 * q + 4 * hi];
-          if (j >= K1) b4 = (f32x4)(0.f);
+        for (int fb = 0; fb < NF1; ++fb)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) gW1 = MJX_MFMA(d1u[4 * q + t], b4[t], gW1);
-        }
+          for (int q = 0; q < 4; ++q) {
+            const int f = 32 * fb + j;
+            f32x4 b4 = *(const f32x4*)&xT[(f < K1 ? f : 0) * ST + 8 * q + 4 * hi];
+            if (f >= K1) b4 = (f32x4)(0.f);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) gW1[fb] = MJX_MFMA(d1u[4 * q + t], b4[t], gW1[fb]);
+          }
         __syncthreads();                                    // tiles are rewritten by the next half
         MJX_FIT_STAMP(8);
       }
@@ -346,21 +352,32 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         const int64_t gbase2 = oW2g + (int64_t)(32 * w + 4 * hi) * H + j;
         f32x2* __restrict__ mvW2 = MV + gbase2;
         float* pW2 = sW2 + (32 * w + 4 * hi) * S2 + j;
-        // W1 rows of this wave (lane j < d_in) and b1 (lane j == d_in): one base pointer + a small per-register stride
-        const bool isw = j < d_in, own1 = j <= d_in;
-        const int stg = isw ? d_in : 1;
-        const int64_t gbase1 = isw ? oW1g + (int64_t)(32 * w + 4 * hi) * d_in + j : oB1g + 32 * w + 4 * hi;
-        f32x2* __restrict__ mvW1 = MV + (own1 ? gbase1 : 0);
-        float* pW1 = sW1 + (32 * w + 4 * hi) * S1 + (isw ? j : d_in);
+        // W1 rows of this wave (feature f = 32 fb + j < d_in) and b1 (f == d_in): one base pointer + a small per-register stride
+        bool own1[NF1];
+        int stg[NF1];
+        f32x2* mvW1[NF1];
+        float* pW1[NF1];
+#pragma unroll
+        for (int fb = 0; fb < NF1; ++fb) {
+          const int f = 32 * fb + j;
+          const bool isw = f < d_in;
+          own1[fb] = f <= d_in;
+          stg[fb] = isw ? d_in : 1;
+          const int64_t gbase1 = isw ? oW1g + (int64_t)(32 * w + 4 * hi) * d_in + f : oB1g + 32 * w + 4 * hi;
+          mvW1[fb] = MV + (own1[fb] ? gbase1 : 0);
+          pW1[fb] = sW1 + (32 * w + 4 * hi) * S1 + (isw ? f : d_in);
+        }
         const bool ownb2 = hi == 0, ownw3 = tid < H, ownb3 = tid == 0;
         const int64_t gb2i = oB2g + 32 * w + j, gw3i = oW3g + (ownw3 ? tid : 0), gb3i = oB3g;
-        f32x2 q2[NT][16], q1[16];
+        f32x2 q2[NT][16], q1[NF1][16];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) q2[nt][r] = mvW2[unit_of(r, 0) * H + 32 * nt];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) q1[r] = mvW1[own1 ? unit_of(r, 0) * stg : 0];
+        for (int fb = 0; fb < NF1; ++fb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) q1[fb][r] = mvW1[fb][own1[fb] ? unit_of(r, 0) * stg[fb] : 0];
         f32x2 qb2 = MV[gb2i], qw3 = MV[gw3i], qb3 = MV[gb3i];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -370,14 +387,16 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
             pW2[ol] = adam_math(pW2[ol], gW2[nt][r], q2[nt][r]);
             mvW2[o] = q2[nt][r];
           }
-        if (own1) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int o = unit_of(r, 0) * stg, ol = unit_of(r, 0) * S1;
-            pW1[ol] = adam_math(pW1[ol], gW1[r], q1[r]);
-            mvW1[o] = q1[r];
+        for (int fb = 0; fb < NF1; ++fb)
+          if (own1[fb]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int o = unit_of(r, 0) * stg[fb], ol = unit_of(r, 0) * S1;
+              pW1[fb][ol] = adam_math(pW1[fb][ol], gW1[fb][r], q1[fb][r]);
+              mvW1[fb][o] = q1[fb][r];
+            }
           }
-        }
         if (ownb2) { sB2[32 * w + j] = adam_math(sB2[32 * w + j], gb2, qb2); MV[gb2i] = qb2; }
         if (ownw3) { sW3[tid] = adam_math(sW3[tid], gw3, qw3); MV[gw3i] = qw3; }
         if (ownb3) { sB3[0] = adam_math(sB3[0], gb3, qb3); MV[gb3i] = qb3; }

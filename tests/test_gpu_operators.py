@@ -439,3 +439,42 @@ def test_background_prefetch_hands_out_complete_blocks():
     fresh = ingest.stage_shared(h, paths, ("observations",))
     assert torch.equal(fresh["observations"]["raw"].cpu(), torch.from_numpy(np.concatenate([p["observations"] for p in paths])))
     ingest.drop_shared()
+
+
+@pytest.mark.parametrize("d_in", [21, 35, 43, 47])
+def test_persistent_mlp_trainer_equals_per_step_launches(monkeypatch, d_in):
+    """The persistent single-workgroup trainer of the MLP baseline (csrc/mlp_fit.h; two 32-feature blocks of the input
+    layer beyond 31 inputs, as far as 160 KB of LDS reach: 47 = the 39-wide Adroit observations + 4 time features and a bit)
+    against the same minibatch-Adam chain issued as ~14 launches per step: same permutation, same arithmetic up to summation
+    order -> parameters within 1e-5 of the movement after 2 x 40 steps.  (Kept short on purpose: on random regression data
+    the ReLU chain is chaotic -- a last-bit difference that flips one unit's sign decides whether two correct implementations
+    agree to 3e-7 or to per cent after a few hundred steps; tools/probe_fit_wide.py shows both, seed by seed.)"""
+    import ctypes
+    import torch
+    from mjrl_amd import _lib
+    from mjrl_amd._lib import check, ptr
+    lib = _lib.load()
+    N = 64 * 41
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(d_in)
+    feat = torch.from_numpy(rng.randn(N, d_in).astype(np.float32)).to(dev)
+    y = torch.from_numpy(rng.randn(N).astype(np.float32)).to(dev)
+    P = 128 * d_in + 128 + 128 * 128 + 128 + 128 + 1
+    p0 = (0.1 * rng.randn(P)).astype(np.float32)
+    perm = torch.from_numpy(np.concatenate([rng.permutation(N), rng.permutation(N)]).astype(np.int32)).to(dev)
+    hid = (ctypes.c_int * 2)(128, 128)
+    out = {}
+    for mode in ("persistent", "launches"):
+        monkeypatch.setenv("MJX_MLP_FIT_LAUNCHES", "1" if mode == "launches" else "0")
+        params = torch.from_numpy(p0.copy()).to(dev)
+        m, v = torch.zeros(P, device=dev), torch.zeros(P, device=dev)
+        loss = torch.zeros(32, dtype=torch.float64, device=dev)
+        check(lib.mjx_mlp_fit_adam(ptr(feat), ptr(y), N, d_in, hid, 2, ptr(params), ptr(m), ptr(v), 0, ptr(perm), 2, 64, 1e-3, 1e-3, ptr(loss), None))
+        torch.cuda.synchronize()
+        out[mode] = (params.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy(), loss[:2].cpu().numpy())
+    a, b = out["persistent"], out["launches"]
+    move = np.linalg.norm(b[0] - p0)
+    assert move > 0.1 * np.linalg.norm(p0) * 0.01
+    assert np.linalg.norm(a[0] - b[0]) < 1e-5 * move
+    assert np.linalg.norm(a[1] - b[1]) < 1e-4 * np.linalg.norm(b[1]) and np.linalg.norm(a[2] - b[2]) < 1e-4 * np.linalg.norm(b[2])
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-6)
