@@ -442,7 +442,7 @@ int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, con
     // persistent single-workgroup trainer (csrc/mlp_fit.h) for the reference's default baseline shape
     const char* force = getenv("MJX_MLP_FIT_LAUNCHES");
     const int64_t steps_ = N / batch - 1;
-    MlpFitLayout<128> L(d_in);
+    MlpFitLayout<128> L(d_in, d_in > 31);
     if (!(force && force[0] == '1') && n_hidden == 2 && hidden[0] == 128 && hidden[1] == 128 && batch == 64 && d_in <= 63 &&
         L.bytes() <= (size_t)160 * 1024 && steps_ > 0 && epochs > 0) {
       static thread_local Scratch mvws;
@@ -456,7 +456,7 @@ int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, con
         configured = true;
       }
       if (d_in <= 31) hipLaunchKernelGGL((k_mlp_fit<128, 1>), dim3(1), dim3(256), L.bytes(), st, a);
-      else hipLaunchKernelGGL((k_mlp_fit<128, 2>), dim3(1), dim3(256), L.bytes(), st, a);   // (32 <= d_in <= 43: what 160 KB of LDS hold)
+      else hipLaunchKernelGGL((k_mlp_fit<128, 2>), dim3(1), dim3(256), L.bytes(), st, a);   // (32 <= d_in <= 55: what 160 KB of LDS hold)
       HIPCHK(hipGetLastError());
       return MJX_OK;
     }

@@ -45,11 +45,13 @@ struct MlpFitLayout {
   static constexpr int ST = 36, S2 = H + 4;
   int K1, S1;
   int oW1, oW2, oW3, oB2, oXS, oXT, oH1, oH2, oD2, oY, oPART, oDY, TOTAL;
-  __host__ __device__ explicit MlpFitLayout(int d_in) {
+  // wide (more than 31 inputs): no sample-major copy of the minibatch (layer 1 reads its operand from the transposed tile):
+  // 7 KB that let 50 inputs -- the 46-wide Adroit hammer observations -- fit the 160 KB
+  __host__ __device__ explicit MlpFitLayout(int d_in, bool wide = false) {
     K1 = (d_in + 1 + 3) & ~3; S1 = K1 + 2;
     oW1 = 0; oW2 = oW1 + H * S1; oW3 = oW2 + H * S2; oB2 = oW3 + H;
     oXS = ((oB2 + H + 4 + 3) / 4) * 4;            // [32][S1]  (b3 sits at oB2 + H)
-    oXT = ((oXS + 32 * S1 + 3) / 4) * 4;          // [K1][ST]
+    oXT = wide ? oXS : ((oXS + 32 * S1 + 3) / 4) * 4;          // [K1][ST]
     oH1 = oXT + K1 * ST;                          // [H][ST]
     oH2 = oH1 + H * ST;
     oD2 = oH2 + H * ST;
@@ -62,14 +64,14 @@ struct MlpFitLayout {
 };
 
 // NF1: 32-feature blocks of the input layer's weight gradient -- 1 for d_in <= 31 (the MuJoCo locomotion observations + 4 time
-// features), 2 for d_in <= 63 as far as the LDS layout fits 160 KB (d_in <= 43: the 39-wide Adroit door / relocate observations).
+// features), 2 for d_in <= 63 as far as the LDS layout fits 160 KB (d_in <= 55: all Adroit observations, 39..46 wide).
 template <int H, int NF1 = 1>
 __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   static_assert(H == 128, "wave w owns unit tile w: 4 waves x 32 units");
   using LT = MlpFitLayout<H>;
   constexpr int ST = LT::ST, S2 = LT::S2, NT = H / 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const LT L(A.d_in);
+  const LT L(A.d_in, NF1 > 1);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
   const int d_in = A.d_in, K1 = L.K1, S1 = L.S1;
   float* sW1 = lds + L.oW1; float* sW2 = lds + L.oW2; float* sW3 = lds + L.oW3; float* sB2 = lds + L.oB2;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   for (int i = tid; i < H * H; i += 256) sW2[(i / H) * S2 + (i % H)] = A.params[oW2g + i];
   for (int i = tid; i < H; i += 256) { sW3[i] = A.params[oW3g + i]; sB2[i] = A.params[oB2g + i]; }
   if (tid == 0) sB3[0] = A.params[oB3g];
-  if (tid < 32) { xs[tid * S1 + d_in] = 1.0f; xT[d_in * ST + tid] = 1.0f; }
+  if (tid < 32) { if (NF1 == 1) xs[tid * S1 + d_in] = 1.0f; xT[d_in * ST + tid] = 1.0f; }
   const int64_t Ptot = oB3g + 1;
   for (int64_t i = tid; i < Ptot; i += 256) { A.mv[2 * i] = A.m[i]; A.mv[2 * i + 1] = A.v[i]; }
   __syncthreads();
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
 #pragma unroll
     for (int c = 0; c < GL; ++c) {
       int e = c * 256 + tid, s = e / d_in, f = e - s * d_in;
-      if (e < 32 * d_in) { xs[s * S1 + f] = gx[c]; xT[f * ST + s] = gx[c]; }
+      if (e < 32 * d_in) { if (NF1 == 1) xs[s * S1 + f] = gx[c]; xT[f * ST + s] = gx[c]; }
     }
     if (tid < 32) sY[tid] = gy;
   };
@@ -155,7 +157,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         for (int q = 0; q < K1 / 4; ++q) {
           const int f0 = 4 * q + 2 * hi;
           f32x2 a = *(const f32x2*)&sW1[(32 * w + j) * S1 + f0];
-          f32x2 b = *(const f32x2*)&xs[j * S1 + f0];
+          f32x2 b;
+          if (NF1 == 1) b = *(const f32x2*)&xs[j * S1 + f0];
+          else b = f32x2{xT[f0 * ST + j], xT[(f0 + 1) * ST + j]};
           z1 = MJX_MFMA(a.x, b.x, z1);
           z1 = MJX_MFMA(a.y, b.y, z1);
         }

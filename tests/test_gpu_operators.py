@@ -441,10 +441,10 @@ def test_background_prefetch_hands_out_complete_blocks():
     ingest.drop_shared()
 
 
-@pytest.mark.parametrize("d_in", [21, 35, 43, 47])
+@pytest.mark.parametrize("d_in", [21, 35, 43, 50, 55])
 def test_persistent_mlp_trainer_equals_per_step_launches(monkeypatch, d_in):
     """The persistent single-workgroup trainer of the MLP baseline (csrc/mlp_fit.h; two 32-feature blocks of the input
-    layer beyond 31 inputs, as far as 160 KB of LDS reach: 47 = the 39-wide Adroit observations + 4 time features and a bit)
+    layer beyond 31 inputs, as far as 160 KB of LDS reach: 55; the Adroit observations + 4 time features are 43..50)
     against the same minibatch-Adam chain issued as ~14 launches per step: same permutation, same arithmetic up to summation
     order -> parameters within 1e-5 of the movement after 2 x 40 steps.  (Kept short on purpose: on random regression data
     the ReLU chain is chaotic -- a last-bit difference that flips one unit's sign decides whether two correct implementations
