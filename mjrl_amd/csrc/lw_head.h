@@ -10,11 +10,13 @@
 // d3 stays in LDS; phase 2 re-reads the H rows (just fetched: L2 / MALL hits) in accumulator layout, forms
 // delta = (d3 W3)(1 - H^2) in place over T and accumulates gW3 / gb3 / colsum(delta) in registers for the whole run (each
 // wave owns h / 4 columns).  6 GB instead of 10.
-// Measured (MI355X, rocprofv3): 1M x 512 x 28: 2.30 ms against 2.59 ms for the four launches; 500 k x 256 x 17: 0.55 against
-// 0.72 ms.  The padded matrix-core work (m -> 32, 131 GFLOP = 0.95 ms at 1M x 512) is no longer hidden behind other
-// workgroups: the kernel takes the whole register file (428-480 VGPRs, one wave per SIMD, one workgroup per CU).  Built for two
-// waves per SIMD (__launch_bounds__(256, 2), W3 fragments reloaded per tile, scalar row bases, real loop over row blocks) the
-// compiler still spills 100-300 registers and the kernel is 10-20 % slower (0.61 / 2.73 ms).
+// Two builds:
+//   k_lw_head<CH>   four waves, each owning h / 4 columns in phase 2 (h = 128 CH): 428-480 VGPRs, one wave per SIMD.  Measured
+//                   (MI355X, rocprofv3): 1M x 512 x 28: 2.30 ms against 2.59 ms for the four launches; 500 k x 256 x 17: 0.55 against
+//                   0.72 ms -- the padded matrix-core work (m -> 32, 131 GFLOP = 0.95 ms at 1M x 512) is not hidden behind anything.
+//                   (The same kernel forced to two waves per SIMD spills 100-300 registers and runs 0.61 / 2.73 ms.)
+//   k_lw_head8<CH>  eight waves, each owning h / 8 columns (h = 256 CH), phase 1 split over two wave quartets: 235-256 VGPRs, two
+//                   waves per SIMD that hide each other's latency: 1.74 ms / 0.45 ms.  Used for h = 256 and 512.
 //
 // Requires h % 128 == 0, h <= 512, m <= 32, 16-byte aligned weight rows; everything else takes the generic chain.
 #pragma once
