@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <vector>
 
 #include "fused_policy.h"
@@ -1054,7 +1055,10 @@ struct LayerwiseWS {
     (void)attr_set;
     static const int ncu = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c; }();
     const int cbs = g.N / GP_BN, ntiles = row_tiles * cbs;
-    static int* ticket = [] { int* p = nullptr; (void)hipMalloc(&p, 256); return p; }();      // (one per process: launches are stream-ordered)
+    // (a ring of counters, one per launch in turn: launches on different streams do not share one)
+    static int* ring = [] { int* p = nullptr; (void)hipMalloc(&p, 256 * sizeof(int)); return p; }();
+    static std::atomic<unsigned> turn{0};
+    int* ticket = ring + (turn.fetch_add(1) & 255u);
     (void)hipMemsetAsync(ticket, 0, sizeof(int), st);
 #ifdef MJX_PHASE_CLOCK
     if (lw_clk_buf() && lw_clk_slot() < LW_CLK_SLOTS) {
