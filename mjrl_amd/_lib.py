@@ -83,6 +83,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles its own HIP runtime (libamdhip64.so.7 + HSA).  If libmjx.so is loaded -- and HIP initialised --
+    # before torch, the process binds /opt/rocm's runtime instead and torch then reports "No HIP GPUs are available" (seen with
+    # build() followed by smoke() in one process).  Loaded in this order the dynamic linker hands libmjx the runtime torch uses.
+    try:
+        import torch  # noqa: F401
+    except Exception:       # pragma: no cover  (a host without torch: the C ABI alone)
+        pass
     if not os.path.exists(LIB_PATH):
         raise MjxError("libmjx.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
