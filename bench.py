@@ -119,7 +119,8 @@ def cpu_baseline(theta0, sample_traj):
 def secondary_measurements(eng, theta0, theta0_dev):
     """Measured AFTER the primary timed region, on the same GPU (N = 1):
     * BASELINE configs[2]: one TRPO update (KL line search, mjrl/algos/trpo.py:100-126) on the same 1M batch -- K1, CG,
-      then backtracking evaluations of K3 until KL < kl_dist (kl_dist = 0.025: the first step length is rejected);
+      then backtracking evaluations of K3 until KL < kl_dist (kl_dist = 0.025: the first two step lengths are rejected), the
+      line search decided on the device (mjx_trpo_update);
     * the layer-wise path at the per-GPU shard sizes of configs[3] / [4] (the 8-GPU configs this 1-GPU run cannot time
       as a whole): HIP-event time of the Fisher-vector-product chain and its rate against the fp32-MFMA peak."""
     import torch
@@ -130,20 +131,11 @@ def secondary_measurements(eng, theta0, theta0_dev):
     kl_dist, trials_log = 0.025, []
 
     def trpo_update():
-        g, _ = eng.surr_vpg(sync=False)
-        _, gx = eng.cg_solve(g, CG_ITERS, DAMPING)
-        alpha = np.sqrt(np.abs(2.0 * kl_dist / (gx + 1e-20)))
-        trials = 0
-        for k in range(100):
-            eng.apply_step(alpha, -3.0)
-            _, kl = eng.eval_surr_kl()
-            trials += 1
-            if kl < kl_dist:
-                break
-            alpha = 0.9 * alpha
-        eng.apply_step(alpha, -3.0)
-        eng.eval_surr_kl()
-        trials_log.append(trials)
+        # what TRPO.train_from_paths runs: mjx_trpo_update (K1, CG, step length, line-search trials three at a time with the
+        # accept / shrink decision on the device), one read-back per batch of trials
+        res = eng.trpo_update(CG_ITERS, DAMPING, 2.0 * kl_dist, kl_dist, -3.0)
+        assert res is not None and res["accepted"]
+        trials_log.append(res["trials"])
         eng.theta_new.copy_(theta0_dev); eng.old_is_new = True; eng._bind_policy()
     trpo_update()
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -174,6 +174,18 @@ int mjx_comm_allreduce(mjx_ctx* ctx, void* buf, int64_t count, int dtype, void* 
 int mjx_npg_update(mjx_ctx* ctx, int iters, float damping, double tol, double step_size, double const_alpha,
                    float min_log_std, float* grad_out, float* x_out, float* theta_out, double* results, void* stream);
 
+/* The TRPO update with its backtracking line search on the device (mjrl/algos/trpo.py:100-126): K1, CG and
+ * alpha = sqrt(|step_size / (grad.x + 1e-20)|) (step_size = 2 kl_dist, :103-104) as in mjx_npg_update when `first`, then
+ * n_trials (1..24) line-search trials enqueued back to back: theta_out = theta_old + alpha x, K3 (rank sums as above), accept
+ * if the mean KL is below kl_dist, otherwise alpha <- 0.9 alpha (:107-118).  Once a trial is accepted the remaining trials of
+ * the call leave theta_out alone (their evaluations repeat the accepted one).  The caller reads `results` once per call and
+ * calls again with first = 0 while results[10] == 0 and results[11] < 100 (the reference gives up after 100 trials, :119-120).
+ * results (device, 64 doubles): as for mjx_npg_update, and [9] step length of the last trial performed, [10] 1 if a trial was
+ * accepted, [11] trials performed so far, [12] step length the next trial would use, [16 + 2k] / [17 + 2k] sum LR*adv /
+ * sum KL of trial k (k < 24 per update). */
+int mjx_trpo_update(mjx_ctx* ctx, int iters, float damping, double tol, double step_size, double kl_dist, int n_trials, int first,
+                    float min_log_std, float* grad_out, float* x_out, float* theta_out, double* results, void* stream);
+
 /* theta_out = theta + alpha * x, then log_std = max(log_std, min_log_std)
  * (npg_cg.py:137-139 + gaussian_mlp.py:73-75). */
 int mjx_apply_step(mjx_ctx* ctx, const float* theta, const float* x, float alpha,

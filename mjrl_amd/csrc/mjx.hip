@@ -794,6 +794,34 @@ int mjx_npg_update(mjx_ctx* c, int iters, float damping, double tol, double step
   return MJX_OK;
 }
 
+int mjx_trpo_update(mjx_ctx* c, int iters, float damping, double tol, double step_size, double kl_dist, int n_trials, int first,
+                    float min_log_std, float* grad_out, float* x_out, float* theta_out, double* results, void* stream) {
+  if (int rc = check_bound(c, true)) return rc;
+  if (!grad_out || !x_out || !theta_out || !results || iters < 0 || n_trials < 1 || n_trials > 24) return fail(MJX_ERR_ARG, "bad arguments");
+  if (theta_out == c->theta_old) return fail(MJX_ERR_ARG, "theta_out must not alias theta_old");
+  hipStream_t st = (hipStream_t)stream;
+  if (first) {
+    if (!c->old_is_new) return fail(MJX_ERR_STATE, "mjx_trpo_update starts from theta_new == theta_old (mjx_bind_policy with old_is_new)");
+    if (int rc = mjx_surr_vpg(c, grad_out, results + 4, stream)) return rc;
+    if (c->comm || c->reduce_cb) {
+      if (int rc = mjx_comm_allreduce(c, grad_out, c->d, 0, stream)) return rc;
+      if (int rc = mjx_comm_allreduce(c, results + 4, 4, 1, stream)) return rc;
+    }
+    if (int rc = mjx_cg_solve(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream)) return rc;
+  }
+  for (int t = 0; t < n_trials; ++t) {
+    hipLaunchKernelGGL(k_trpo_try, dim3((c->d + 255) / 256), dim3(256), 0, st, c->theta_old, x_out, results, step_size,
+                       (first && t == 0) ? 1 : 0, min_log_std, theta_out, (int)c->d, c->oS);
+    HIPCHK(hipGetLastError());
+    if (first && t == 0) { if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc; }
+    if (int rc = mjx_eval_surr_kl(c, results, stream)) return rc;
+    if (c->comm || c->reduce_cb) if (int rc = mjx_comm_allreduce(c, results, 4, 1, stream)) return rc;
+    hipLaunchKernelGGL(k_trpo_check, dim3(1), dim3(64), 0, st, results, kl_dist, (double)c->N_global);
+    HIPCHK(hipGetLastError());
+  }
+  return MJX_OK;
+}
+
 int mjx_apply_step(mjx_ctx* c, const float* theta, const float* x, float alpha, float min_log_std, float* theta_out, void* stream) {
   if (!c || !theta || !x || !theta_out) return fail(MJX_ERR_ARG, "bad arguments");
   hipLaunchKernelGGL(k_apply_step, dim3((c->d + 255) / 256), dim3(256), 0, (hipStream_t)stream, theta, x, alpha, min_log_std,

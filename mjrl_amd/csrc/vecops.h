@@ -241,6 +241,34 @@ __global__ void k_apply_step(const float* __restrict__ theta, const float* __res
   out[i] = v;
 }
 
+// TRPO's backtracking line search on the device (trpo.py:107-120).  res (doubles): [0..3] K3 sums of the last evaluation,
+// [8] g.x, [9] step length of the last trial, [10] accepted flag, [11] trials so far, [12] step length of the next trial,
+// [16 + 2k], [17 + 2k] surrogate / KL sums of trial k.
+// k_trpo_try: theta_out = theta_old + alpha x for the next trial -- unless a trial was accepted already (theta_out keeps
+// the accepted parameters); init: first trial of an update, alpha = sqrt(|step_size / (g.x + 1e-20)|) (trpo.py:104).
+__global__ void k_trpo_try(const float* __restrict__ theta, const float* __restrict__ x, double* res, double step_size, int init,
+                           float min_log_std, float* out, int d, int oS) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double a64 = init ? sqrt(fabs(step_size / (res[8] + 1e-20))) : res[12];
+  const bool done = !init && res[10] != 0.0;
+  if (i == 0 && init) { res[12] = a64; res[10] = 0.0; res[11] = 0.0; }
+  if (i >= d || done) return;
+  const float alpha = (float)a64;
+  float v = __fadd_rn(theta[i], __fmul_rn(alpha, x[i]));
+  if (i >= oS) v = fmaxf(v, min_log_std);
+  out[i] = v;
+}
+// k_trpo_check (one thread): accept the trial if its mean KL is below kl_dist, else alpha <- 0.9 alpha
+__global__ void k_trpo_check(double* res, double kl_dist, double n_global) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || res[10] != 0.0) return;
+  const int k = (int)res[11];
+  if (k < 24) { res[16 + 2 * k] = res[0]; res[17 + 2 * k] = res[1]; }
+  res[11] = (double)(k + 1);
+  res[9] = res[12];
+  if (res[1] / n_global < kl_dist) res[10] = 1.0;
+  else res[12] = 0.9 * res[12];
+}
+
 // the same with the NPG step length formed on the device: alpha = sqrt(|delta / (g.x + 1e-20)|) in fp64 like
 // npg_cg.py:133, so the host does not have to wait for g.x between the CG solve and the parameter step
 __global__ void k_apply_npg_step(const float* __restrict__ theta, const float* __restrict__ x, const double* __restrict__ gdotx,

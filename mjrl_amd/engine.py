@@ -169,6 +169,11 @@ class HipBackend:
         check(self.lib.mjx_npg_update(self.ctx, int(iters), float(damping), float(tol), float(step_size), float(const_alpha or 0.0),
                                       float(min_log_std), ptr(grad_out), ptr(x_out), ptr(theta_out), ptr(results), self.stream()))
 
+    def trpo_update(self, iters, damping, tol, step_size, kl_dist, n_trials, first, min_log_std, grad_out, x_out, theta_out, results):
+        check(self.lib.mjx_trpo_update(self.ctx, int(iters), float(damping), float(tol), float(step_size), float(kl_dist), int(n_trials),
+                                       1 if first else 0, float(min_log_std), ptr(grad_out), ptr(x_out), ptr(theta_out), ptr(results),
+                                       self.stream()))
+
     def apply_step(self, base, x, alpha, min_log_std, out):
         check(self.lib.mjx_apply_step(self.ctx, ptr(base), ptr(x), float(alpha), float(min_log_std), ptr(out), self.stream()))
 
@@ -200,7 +205,7 @@ class UpdateEngine:
         self.Ap = torch.zeros(self.d, **f32)
         # every scalar an update produces sits in one device block, so that one read-back fetches them all:
         # K3's sums | K1's sums (kept apart from K3's) | b.x of the last solve | step length formed on the device
-        self.results = torch.zeros(16, dtype=torch.float64, device=self.device)
+        self.results = torch.zeros(64, dtype=torch.float64, device=self.device)      # ([16:] the per-trial log of mjx_trpo_update)
         self.scal, self.scal_vpg = self.results[0:4], self.results[4:8]
         self.bdotx, self.alpha_dev = self.results[8:9], self.results[9:10]
         self._host_results = None                   # host copy of `results`, valid until the next launch that writes it
@@ -440,6 +445,32 @@ class UpdateEngine:
         else:
             self.apply_npg_step(step_size, min_log_std)
         return self.eval_surr_kl()
+
+    def trpo_update(self, iters, damping, step_size, kl_dist, min_log_std, tol=1e-10, batch=3, max_trials=100):
+        """The whole TRPO update (trpo.py:100-126: K1, CG, step length, backtracking line search on the KL) through libmjx's
+        mjx_trpo_update: the line-search trials are enqueued `batch` at a time with the accept / shrink decision taken on the
+        device, one read-back per batch (the call-by-call form reads back after every trial) -> dict(alpha, trials, accepted,
+        surr_after, kl, history=[(surr, kl) per trial]); deferred() has surr_before / g.x.  None when the one-call path is
+        not available (torch.distributed fallback): the caller runs the loop itself."""
+        assert self.old_is_new, "trpo_update starts from theta_new == theta_old"
+        d = _dist()
+        if not ((d is None or self._native_comm()) and hasattr(self.backend, "trpo_update")):
+            return None
+        first, hist = True, []
+        while True:
+            self._host_results = None
+            self.backend.trpo_update(iters, damping, tol, step_size, kl_dist, batch, first, min_log_std, self.grad, self.x, self.theta_new,
+                                     self.results)
+            self.old_is_new = False
+            first = False
+            s = self._host_results = self.results.cpu().numpy()
+            trials, accepted = int(s[11]), s[10] != 0.0
+            for k in range(len(hist), min(trials, 24)):
+                hist.append((float(s[16 + 2 * k] / self.N_global), float(s[17 + 2 * k] / self.N_global)))
+            if accepted or trials >= max_trials or trials >= 24:
+                break
+        return dict(alpha=float(s[9]), trials=trials, accepted=bool(accepted), surr_after=float(s[0] / self.N_global),
+                    kl=float(s[1] / self.N_global), history=hist)
 
     def deferred(self):
         """-> dict(surr_before, gdotx, alpha) of the calls made with sync=False / apply_npg_step (one read-back after the update)"""

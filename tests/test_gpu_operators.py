@@ -478,3 +478,45 @@ def test_persistent_mlp_trainer_equals_per_step_launches(monkeypatch, d_in):
     assert np.linalg.norm(a[0] - b[0]) < 1e-5 * move
     assert np.linalg.norm(a[1] - b[1]) < 1e-4 * np.linalg.norm(b[1]) and np.linalg.norm(a[2] - b[2]) < 1e-4 * np.linalg.norm(b[2])
     np.testing.assert_allclose(a[3], b[3], rtol=1e-6)
+
+
+@pytest.mark.parametrize("hid", [(64, 64), (128, 128)])
+def test_device_line_search_equals_call_by_call_trpo(hid):
+    """mjx_trpo_update (K1, CG, step length, backtracking trials with the accept / shrink decision on the device, one read-back
+    per batch of trials) against the same update issued call by call with a read-back after every trial (trpo.py:100-126):
+    same number of trials, same step length, the same parameters bit for bit -- on the fused and on the layer-wise path,
+    with a KL bound tight enough to force several shrinks (more than one batch of three trials)."""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    n, m, N = 17, 6, 20000 + 3
+    rng = np.random.RandomState(8)
+    th = synth.perturbed_params(synth.init_params(n, m, hid))
+    ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    obs, act, adv = rng.randn(N, n), rng.randn(N, m), rng.randn(N)
+    for kl_dist, step_size in ((0.01, 0.02), (0.002, 0.02)):   # (the second: the step is sized for 5 x the KL it has to meet)
+        eng = UpdateEngine(n, m, hid)
+        eng.set_policy(th, th, ident, ident)
+        eng.set_batch(obs, act, adv)
+        res = eng.trpo_update(10, 1e-4, step_size, kl_dist, -3.0)
+        assert res is not None and res["accepted"]
+        one = dict(theta=eng.theta_new.clone(), **res)
+        late = eng.deferred()
+        # call by call
+        eng.set_policy(th, th, ident, ident)
+        g, surr_before = eng.surr_vpg()
+        _, gdotx = eng.cg_solve(g, 10, 1e-4)
+        alpha = np.sqrt(np.abs(step_size / (gdotx + 1e-20)))
+        trials = 0
+        for k in range(100):
+            eng.apply_step(alpha, -3.0)
+            surr_after, kl = eng.eval_surr_kl()
+            trials += 1
+            if kl < kl_dist:
+                break
+            alpha = 0.9 * alpha
+        assert trials == one["trials"] and (trials > 3 or kl_dist == 0.01)
+        assert float(alpha) == one["alpha"] and kl == one["kl"] and surr_after == one["surr_after"]
+        assert torch.equal(eng.theta_new, one["theta"])
+        assert late["surr_before"] == surr_before and late["gdotx"] == gdotx
+        assert len(one["history"]) == trials and one["history"][-1] == (surr_after, kl)
+        eng.close()
