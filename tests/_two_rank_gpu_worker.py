@@ -45,8 +45,15 @@ def main():
     late2 = eng.deferred()
     res["one_call_equal"] = np.array([np.array_equal(eng.x.cpu().numpy(), res["x"]) and np.array_equal(eng.theta_new.cpu().numpy(), res["theta"])
                                       and sa2 == surr_after and kl2 == kl and late2 == late])
+    # the TRPO update with its line search decided on the device (mjx_trpo_update): the rank sums of K1, the solve and every
+    # trial's K3 run inside the C loop; a KL bound that forces several shrinks
+    eng.set_policy(th, th, ident, ident)
+    tr = eng.trpo_update(10, 1e-4, 0.02, 0.002, -3.0)
+    res["trpo"] = np.array([tr["alpha"], tr["trials"], tr["kl"], tr["surr_after"], float(tr["accepted"])])
+    res["trpo_theta"] = eng.theta_new.cpu().numpy()
     # every rank must hold identical results (the CG scalars are recomputed redundantly from the reduced vectors)
-    t = torch.from_numpy(np.concatenate([res["x"], res["theta"], res["scal"].astype(np.float32)])).cuda()
+    t = torch.from_numpy(np.concatenate([res["x"], res["theta"], res["scal"].astype(np.float32), res["trpo_theta"],
+                                         res["trpo"].astype(np.float32)])).cuda()
     lo_t, hi_t = t.clone(), t.clone()
     dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)

@@ -310,6 +310,12 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     assert rel(two["theta"], eng.theta_new.cpu().numpy()) < 1e-6
     one = np.array([late["surr_before"], late["gdotx"], late["alpha"], surr_after, kl])
     np.testing.assert_allclose(two["scal"], one, rtol=2e-5, atol=1e-7)
+    # TRPO with the device-side line search: same number of trials, same step length / KL / parameters as on one rank
+    eng.set_policy(th, th, ident, ident)
+    tr = eng.trpo_update(10, 1e-4, 0.02, 0.002, -3.0)
+    assert two["trpo"][4] == 1.0 and tr["accepted"] and int(two["trpo"][1]) == tr["trials"] and tr["trials"] > 3
+    np.testing.assert_allclose(two["trpo"][[0, 2, 3]], [tr["alpha"], tr["kl"], tr["surr_after"]], rtol=2e-5, atol=1e-7)
+    assert rel(two["trpo_theta"], eng.theta_new.cpu().numpy()) < 1e-6
     eng.close()
 
 
