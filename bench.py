@@ -116,7 +116,7 @@ def cpu_baseline(theta0, sample_traj):
                 seconds=dt, nproc=os.cpu_count())
 
 
-def secondary_measurements(eng, theta0, theta0_dev):
+def secondary_measurements(eng, theta0, theta0_dev, ref=None):
     """Measured AFTER the primary timed region, on the same GPU (N = 1):
     * BASELINE configs[2]: one TRPO update (KL line search, mjrl/algos/trpo.py:100-126) on the same 1M batch -- K1, CG,
       then backtracking evaluations of K3 until KL < kl_dist (kl_dist = 0.025: the first two step lengths are rejected), the
@@ -128,7 +128,7 @@ def secondary_measurements(eng, theta0, theta0_dev):
     from mjrl_amd.engine import UpdateEngine
     out = {}
     # ---- TRPO
-    kl_dist, trials_log = 0.025, []
+    kl_dist, trials_log, first = 0.025, [], {}
 
     def trpo_update():
         # what TRPO.train_from_paths runs: mjx_trpo_update (K1, CG, step length, line-search trials three at a time with the
@@ -136,6 +136,8 @@ def secondary_measurements(eng, theta0, theta0_dev):
         res = eng.trpo_update(CG_ITERS, DAMPING, 2.0 * kl_dist, kl_dist, -3.0)
         assert res is not None and res["accepted"]
         trials_log.append(res["trials"])
+        if not first:
+            first.update(res, surr_before=eng.deferred()["surr_before"], step=eng.theta_new.cpu().numpy().astype(np.float64) - theta0)
         eng.theta_new.copy_(theta0_dev); eng.old_is_new = True; eng._bind_policy()
     trpo_update()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -145,6 +147,19 @@ def secondary_measurements(eng, theta0, theta0_dev):
     ms = 1e3 * (time.perf_counter() - t0) / 5
     out["trpo_configs2"] = {"updates_per_s": 1e3 / ms, "ms_per_update": ms, "kl_dist": kl_dist, "line_search_trials": trials_log[-1],
                             "workload": "BASELINE configs[2]: the same 1M-timestep batch and 64x64 policy, TRPO with KL line search"}
+    if ref is not None and abs(float(ref["trpo_kl_dist"]) - kl_dist) < 1e-12:
+        rs = ref["trpo_new_params"].astype(np.float64) - theta0
+        si = first["surr_after"] - first["surr_before"]
+        drift = {"alpha": abs(first["alpha"] - float(ref["trpo_alpha"])) / float(ref["trpo_alpha"]),
+                 "kl": abs(first["kl"] - float(ref["trpo_kl"])) / float(ref["trpo_kl"]),
+                 "surr_improvement": abs(si - float(ref["trpo_surr_improvement"])) / float(ref["trpo_surr_improvement"]),
+                 "step_rel_l2": float(np.linalg.norm(first["step"] - rs) / np.linalg.norm(rs))}
+        same_trials = int(first["trials"]) == int(ref["trpo_trials"])
+        out["trpo_configs2"]["check_vs_reference"] = {
+            "rel_error": drift, "trials": int(first["trials"]), "reference_trials": int(ref["trpo_trials"]), "bar": 1e-5,
+            "fixture": "tests/golden/bench_ref_1m.npz",
+            "what": "the unmodified reference's TRPO.train_from_paths (mjrl/algos/trpo.py:56-146) on this batch",
+            "failed": bool(max(drift.values()) > 1e-5 or not same_trials)}
     # ---- layer-wise FVP at the shard sizes of the 8-GPU configs
     lw = {}
     for name, n, m, hid, N in (("configs3_humanoid_256x256", 376, 17, (256, 256), 500000), ("configs4_adroit_512x512", 39, 28, (512, 512), 1000000)):
@@ -263,7 +278,7 @@ def main():
     eng.set_batch(obs, act, adv, N_global=N_TRAJ * T if args.rehearse_world > 1 else None)   # resident in HBM from here on
     assert eng.N_global == N_TRAJ * T, eng.N_global
     theta0_dev = torch.from_numpy(theta0).to(eng.device)
-    last = {}
+    last, last_vec = {}, {}
 
     def one_update():
         # the call sequence of NPG.train_from_paths (mjrl_amd/algos/npg_cg.py): everything is enqueued, one read-back
@@ -272,6 +287,8 @@ def main():
         surr_after, kl = eng.npg_update(CG_ITERS, DAMPING, STEP, -3.0)
         late = eng.deferred()
         last.update(alpha=late["alpha"], kl=kl, surr_improvement=surr_after - late["surr_before"])
+        if "step" not in last_vec:                   # (first warm-up update only: the step every later update repeats)
+            last_vec["step"] = eng.theta_new.cpu().numpy().astype(np.float64) - theta0
         # old := new happens here in training; the bench restores theta0 so every step does identical work
         eng.theta_new.copy_(theta0_dev)
         eng.old_is_new = True
@@ -368,11 +385,31 @@ def main():
             if max(drift.values()) > 1e-5:
                 print(json.dumps({"error": "update drifted from the fp64 oracle beyond 1e-5", "drift": drift, "check": last}), file=sys.stderr, flush=True)
                 failed = True
+        # ... and against the UNMODIFIED REFERENCE's NPG.train_from_paths on this very batch (tests/golden/bench_ref_1m.npz,
+        # tests/golden/make_golden_big.py bench_ref_1m: 25 s + 45 s of CPU for configs[1] / configs[2]): scalars and the step
+        # direction at the north-star's 1e-5
+        fr = os.path.join(ROOT, "tests", "golden", "bench_ref_1m.npz")
+        ref = np.load(fr) if os.path.exists(fr) else None
+        if ref is not None and args.rehearse_world <= 1 and "step" in last_vec:
+            rs = ref["npg_new_params"].astype(np.float64) - theta0
+            drift = {"alpha": abs(last["alpha"] - float(ref["npg_alpha"])) / float(ref["npg_alpha"]),
+                     "kl": abs(last["kl"] - float(ref["npg_kl"])) / float(ref["npg_kl"]),
+                     "surr_improvement": abs(last["surr_improvement"] - float(ref["npg_surr_improvement"])) / float(ref["npg_surr_improvement"]),
+                     "step_rel_l2": float(np.linalg.norm(last_vec["step"] - rs) / np.linalg.norm(rs))}
+            out["check_vs_reference"] = {"rel_error": drift, "bar": 1e-5, "fixture": "tests/golden/bench_ref_1m.npz",
+                                         "what": "the unmodified reference's NPG.train_from_paths (mjrl/algos/npg_cg.py:91-163) on this batch"}
+            if max(drift.values()) > 1e-5:
+                print(json.dumps({"error": "update differs from the reference beyond 1e-5", "drift": drift, "check": last}), file=sys.stderr, flush=True)
+                failed = True
         if args.rehearse_world > 1:
             out["rehearsal"] = "rank 0 of %d on one GPU, 1-rank RCCL group: NOT the metric" % args.rehearse_world
             out["roofline"]["traffic"] = None
         if world == 1 and not args.no_secondary and args.rehearse_world <= 1:
-            out["secondary"] = secondary_measurements(eng, theta0, theta0_dev)
+            out["secondary"] = secondary_measurements(eng, theta0, theta0_dev, ref)
+            if out["secondary"]["trpo_configs2"].get("check_vs_reference", {}).get("failed"):
+                print(json.dumps({"error": "TRPO update differs from the reference beyond 1e-5",
+                                  "check": out["secondary"]["trpo_configs2"]["check_vs_reference"]}), file=sys.stderr, flush=True)
+                failed = True
         if world == 1 and not args.no_cpu_baseline and args.rehearse_world <= 1:
             out["cpu_baseline"] = cpu_baseline(theta0, args.cpu_sample_traj)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

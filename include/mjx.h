@@ -162,7 +162,8 @@ int mjx_comm_allreduce(mjx_ctx* ctx, void* buf, int64_t count, int dtype, void* 
  * process_paths and the parameter read-back (mjrl/algos/npg_cg.py:108-142):
  *   K1   grad = flat_vpg, surrogate sums                                   [rank sum: d floats + 4 doubles]
  *   K4   x = CG(F + damping I, grad): iters x (K2 [rank sum: d floats] + vector update), early stop below tol
- *        alpha = sqrt(|step_size / (grad.x + 1e-20)|)   (:133), or alpha = const_alpha when const_alpha > 0 (:128-130)
+ *        alpha = sqrt(|step_size / (grad.x + 1e-20)|)   (:133), or alpha = const_alpha when const_alpha is not NaN (:128-130; any finite
+ *        value, zero and negative included, is applied as given -- NAN selects the normalised step)
  *        theta_out = theta_old + alpha x, log_std = max(log_std, min_log_std)   (:137-139, gaussian_mlp.py:73-75)
  *   K3   surrogate / KL sums of theta_out against theta_old                [rank sum: 4 doubles]
  * Requires mjx_bind_batch and mjx_bind_policy(old_is_new = 1).  theta_out (d floats) may be the bound theta_new
@@ -182,9 +183,23 @@ int mjx_npg_update(mjx_ctx* ctx, int iters, float damping, double tol, double st
  * calls again with first = 0 while results[10] == 0 and results[11] < 100 (the reference gives up after 100 trials, :119-120).
  * results (device, 64 doubles): as for mjx_npg_update, and [9] step length of the last trial performed, [10] 1 if a trial was
  * accepted, [11] trials performed so far, [12] step length the next trial would use, [16 + 2k] / [17 + 2k] sum LR*adv /
- * sum KL of trial k (k < 24 per update). */
+ * sum KL of trial k at ring position k % 24 (a call performs at most 24 trials, so nothing is overwritten before it is read).
+ * After 100 rejected trials the caller applies the zero step (mjx_apply_step with alpha = 0, :119-126). */
 int mjx_trpo_update(mjx_ctx* ctx, int iters, float damping, double tol, double step_size, double kl_dist, int n_trials, int first,
                     float min_log_std, float* grad_out, float* x_out, float* theta_out, double* results, void* stream);
+
+/* The whole DAPG update (mjrl/algos/dapg.py:92-121) enqueued by one call.  At entry the batch bound with mjx_bind_batch is
+ * the block [on-policy rows ; demonstration rows] with the advantages of dapg.py:65-70 (N_global = all rows over all
+ * ranks) and theta_new == theta_old.  Sequence: K1 over all rows (rank sum), gradient x N_all / N_on (:97-98, one fp32
+ * product per element); mjx_bind_rows(rows_on, N_on_global, adv_on) -- the Fisher metric, surrogate and KL use the on-policy
+ * prefix with the whitened on-policy advantages adv_on (device, rows_on floats) --; K3 = surr_before (:92); CG (:103-106);
+ * alpha = sqrt(|step_size / (grad.x + 1e-20)|) with step_size = 2 kl_dist (:111-112); theta_out = theta_old + alpha x with
+ * the log_std clamp; K3 at theta_out (:117-118).  On return the context is bound to the on-policy prefix and to theta_out
+ * as after mjx_bind_rows + mjx_bind_policy(theta_out, theta_old, tr_new, tr_old, 0).
+ * results as for mjx_npg_update, with [4] = sum LR*adv over the ON-POLICY rows at theta_old (surr_before x N_on_global). */
+int mjx_dapg_update(mjx_ctx* ctx, int iters, float damping, double tol, double step_size, float min_log_std, int64_t rows_on,
+                    int64_t N_on_global, const float* adv_on, float* grad_out, float* x_out, float* theta_out, double* results,
+                    void* stream);
 
 /* theta_out = theta + alpha * x, then log_std = max(log_std, min_log_std)
  * (npg_cg.py:137-139 + gaussian_mlp.py:73-75). */

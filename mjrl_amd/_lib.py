@@ -50,6 +50,8 @@ PROTOTYPES = {
                                c_void_p]),
     "mjx_trpo_update": (c_int, [c_void_p, c_int, c_float, c_double, c_double, c_double, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
+    "mjx_dapg_update": (c_int, [c_void_p, c_int, c_float, c_double, c_double, c_float, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
     "mjx_apply_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "mjx_apply_npg_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_float, c_void_p, c_void_p, c_void_p]),
     "mjx_discount_scan": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p]),

@@ -66,6 +66,24 @@ class DAPG(NPG):
         N_all_global = eng.N_global
         N_on_global = eng.global_count(N)
 
+        subsampled = self.hvp_subsample is not None and self.hvp_subsample < 0.99
+        if not subsampled and eng.old_is_new:
+            # the whole update in ONE call into libmjx (mjx_dapg_update): K1 over all rows, gradient x N_all / N_on, the
+            # on-policy prefix bound with its own advantages, K3, CG, step length, step, K3 -- one read-back
+            t0 = timer.time()
+            res = eng.dapg_update(self.FIM_invert_args['iters'], self.FIM_invert_args['damping'], 2.0 * self.kl_dist,
+                                  self.policy.min_log_std, N, advantages, N_on_global=N_on_global)
+            if res is not None:
+                surr_after, kl_dist = res
+                late = eng.deferred()
+                surr_before, gdotx, alpha = late["surr_before"], late["gdotx"], late["alpha"]
+                self.policy.set_param_values(eng.to_host(eng.theta_new), set_new=True, set_old=True)
+                if self.save_logs:
+                    self._log_update(paths, alpha, 2.0 * self.kl_dist, 0.0, timer.time() - t0, kl_dist, surr_before, surr_after)
+                self.last_update = dict(alpha=float(alpha), kl_dist=kl_dist, surr_before=surr_before, surr_after=surr_after,
+                                        gdotx=gdotx)
+                return base_stats
+
         t0 = timer.time()
         g, _ = eng.surr_vpg()                                  # K1 over all rows, mean over N_all
         g.mul_(N_all_global / N_on_global)                     # sample_coef, dapg.py:97-98

@@ -39,16 +39,16 @@ class TRPO(NPG):
 
         subsampled = self.hvp_subsample is not None and self.hvp_subsample < 0.99
         if not subsampled and eng.old_is_new:
-            # K1, CG, step length and the line search in libmjx (mjx_trpo_update): trials enqueued three at a time, the accept /
-            # shrink decision on the device, one read-back per batch.  (More than 24 trials -- the reference allows 100 -- or a
-            # torch.distributed fallback: the loop below.)
+            # K1, CG, step length and the line search in libmjx (mjx_trpo_update): trials enqueued in batches, the accept /
+            # shrink decision on the device, one read-back per batch, up to the reference's 100 trials (then alpha = 0).
+            # (torch.distributed fallback: the loop below.)
             t0 = timer.time()
             iters, damping = self.FIM_invert_args['iters'], self.FIM_invert_args['damping']
             res = eng.trpo_update(iters, damping, 2.0 * self.kl_dist, self.kl_dist, self.policy.min_log_std)
-            if res is not None and res["accepted"]:
+            if res is not None:
                 late = eng.deferred()
                 surr_before, gdotx = late["surr_before"], late["gdotx"]
-                for (sa, klk) in res["history"][:-1]:
+                for (sa, klk) in (res["history"][:-1] if res["accepted"] else res["history"]):
                     print("Step size too high. Backtracking. | kl = %f | surr diff = %f" % (klk, sa - surr_before))
                 alpha, trials, surr_after, kl_dist = res["alpha"], res["trials"], res["surr_after"], res["kl"]
                 self.policy.set_param_values(eng.to_host(eng.theta_new), set_new=True, set_old=True)
@@ -57,10 +57,6 @@ class TRPO(NPG):
                 self.last_update = dict(alpha=float(alpha), kl_dist=kl_dist, surr_before=surr_before, surr_after=surr_after,
                                         gdotx=gdotx, trials=trials)
                 return base_stats
-            if res is not None:                       # not accepted within 24 trials: start over on the call-by-call path
-                eng.theta_new.copy_(eng.theta_old)
-                eng.old_is_new = True
-                eng._bind_policy()
 
         t0 = timer.time()
         g, surr_before = eng.surr_vpg()

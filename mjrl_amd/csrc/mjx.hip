@@ -786,7 +786,7 @@ int mjx_npg_update(mjx_ctx* c, int iters, float damping, double tol, double step
   }
   if (int rc = mjx_cg_solve(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream)) return rc;
   const float* base = c->theta_old;               // == theta_new in value; theta_out may be the theta_new buffer itself
-  if (const_alpha > 0.0) { if (int rc = mjx_apply_step(c, base, x_out, (float)const_alpha, min_log_std, theta_out, stream)) return rc; }
+  if (!std::isnan(const_alpha)) { if (int rc = mjx_apply_step(c, base, x_out, (float)const_alpha, min_log_std, theta_out, stream)) return rc; }
   else if (int rc = mjx_apply_npg_step(c, base, x_out, results + 8, step_size, min_log_std, theta_out, results + 9, stream)) return rc;
   if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc;
   if (int rc = mjx_eval_surr_kl(c, results, stream)) return rc;
@@ -819,6 +819,34 @@ int mjx_trpo_update(mjx_ctx* c, int iters, float damping, double tol, double ste
     hipLaunchKernelGGL(k_trpo_check, dim3(1), dim3(64), 0, st, results, kl_dist, (double)c->N_global);
     HIPCHK(hipGetLastError());
   }
+  return MJX_OK;
+}
+
+int mjx_dapg_update(mjx_ctx* c, int iters, float damping, double tol, double step_size, float min_log_std, int64_t rows_on,
+                    int64_t N_on_global, const float* adv_on, float* grad_out, float* x_out, float* theta_out, double* results,
+                    void* stream) {
+  if (int rc = check_bound(c, true)) return rc;
+  if (!grad_out || !x_out || !theta_out || !results || !adv_on || iters < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (!c->old_is_new) return fail(MJX_ERR_STATE, "mjx_dapg_update starts from theta_new == theta_old (mjx_bind_policy with old_is_new)");
+  if (theta_out == c->theta_old) return fail(MJX_ERR_ARG, "theta_out must not alias theta_old");
+  if (rows_on < 0 || rows_on > c->N_local || N_on_global <= 0 || N_on_global > c->N_global) return fail(MJX_ERR_ARG, "bad on-policy row counts");
+  hipStream_t st = (hipStream_t)stream;
+  const bool ranks = c->comm || c->reduce_cb;
+  // the vanilla gradient over [on-policy ; demonstrations] (mean over N_all), then x N_all / N_on (dapg.py:97-98)
+  const float coef = (float)((double)c->N_global / (double)N_on_global);
+  if (int rc = mjx_surr_vpg(c, grad_out, results + 4, stream)) return rc;
+  if (ranks) if (int rc = mjx_comm_allreduce(c, grad_out, c->d, 0, stream)) return rc;
+  hipLaunchKernelGGL(k_scale_f32, dim3((c->d + 255) / 256), dim3(256), 0, st, grad_out, coef, (int)c->d);
+  HIPCHK(hipGetLastError());
+  // Fisher metric, surrogate and KL: the on-policy prefix with its own advantages, means over the on-policy count (:92, :103)
+  if (int rc = mjx_bind_rows(c, rows_on, N_on_global, adv_on)) return rc;
+  if (int rc = mjx_eval_surr_kl(c, results + 4, stream)) return rc;                    // surr_before (theta_new == theta_old)
+  if (ranks) if (int rc = mjx_comm_allreduce(c, results + 4, 4, 1, stream)) return rc;
+  if (int rc = mjx_cg_solve(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream)) return rc;
+  if (int rc = mjx_apply_npg_step(c, c->theta_old, x_out, results + 8, step_size, min_log_std, theta_out, results + 9, stream)) return rc;
+  if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc;
+  if (int rc = mjx_eval_surr_kl(c, results, stream)) return rc;
+  if (ranks) if (int rc = mjx_comm_allreduce(c, results, 4, 1, stream)) return rc;
   return MJX_OK;
 }
 

@@ -241,9 +241,15 @@ __global__ void k_apply_step(const float* __restrict__ theta, const float* __res
   out[i] = v;
 }
 
+// x *= s (DAPG's sample_coef on the gradient, dapg.py:97-98: an fp32 product per element, like NumPy's float32 array x Python float)
+__global__ void k_scale_f32(float* __restrict__ x, float s, int d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d) x[i] = __fmul_rn(x[i], s);
+}
+
 // TRPO's backtracking line search on the device (trpo.py:107-120).  res (doubles): [0..3] K3 sums of the last evaluation,
 // [8] g.x, [9] step length of the last trial, [10] accepted flag, [11] trials so far, [12] step length of the next trial,
-// [16 + 2k], [17 + 2k] surrogate / KL sums of trial k.
+// [16 + 2 (k % 24)], [17 + 2 (k % 24)] surrogate / KL sums of trial k (a ring of 24: a call performs at most 24 trials).
 // k_trpo_try: theta_out = theta_old + alpha x for the next trial -- unless a trial was accepted already (theta_out keeps
 // the accepted parameters); init: first trial of an update, alpha = sqrt(|step_size / (g.x + 1e-20)|) (trpo.py:104).
 __global__ void k_trpo_try(const float* __restrict__ theta, const float* __restrict__ x, double* res, double step_size, int init,
@@ -262,7 +268,7 @@ __global__ void k_trpo_try(const float* __restrict__ theta, const float* __restr
 __global__ void k_trpo_check(double* res, double kl_dist, double n_global) {
   if (threadIdx.x != 0 || blockIdx.x != 0 || res[10] != 0.0) return;
   const int k = (int)res[11];
-  if (k < 24) { res[16 + 2 * k] = res[0]; res[17 + 2 * k] = res[1]; }
+  res[16 + 2 * (k % 24)] = res[0]; res[17 + 2 * (k % 24)] = res[1];
   res[11] = (double)(k + 1);
   res[9] = res[12];
   if (res[1] / n_global < kl_dist) res[10] = 1.0;

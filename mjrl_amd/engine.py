@@ -166,13 +166,18 @@ class HipBackend:
         check(self.lib.mjx_comm_allreduce(self.ctx, ptr(t), t.numel(), 1 if t.dtype == self.torch.float64 else 0, self.stream()))
 
     def npg_update(self, iters, damping, tol, step_size, const_alpha, min_log_std, grad_out, x_out, theta_out, results):
-        check(self.lib.mjx_npg_update(self.ctx, int(iters), float(damping), float(tol), float(step_size), float(const_alpha or 0.0),
+        check(self.lib.mjx_npg_update(self.ctx, int(iters), float(damping), float(tol), float(step_size), float("nan") if const_alpha is None else float(const_alpha),
                                       float(min_log_std), ptr(grad_out), ptr(x_out), ptr(theta_out), ptr(results), self.stream()))
 
     def trpo_update(self, iters, damping, tol, step_size, kl_dist, n_trials, first, min_log_std, grad_out, x_out, theta_out, results):
         check(self.lib.mjx_trpo_update(self.ctx, int(iters), float(damping), float(tol), float(step_size), float(kl_dist), int(n_trials),
                                        1 if first else 0, float(min_log_std), ptr(grad_out), ptr(x_out), ptr(theta_out), ptr(results),
                                        self.stream()))
+
+    def dapg_update(self, iters, damping, tol, step_size, min_log_std, rows_on, N_on_global, adv_on, grad_out, x_out, theta_out, results):
+        check(self.lib.mjx_dapg_update(self.ctx, int(iters), float(damping), float(tol), float(step_size), float(min_log_std),
+                                       int(rows_on), int(N_on_global), ptr(adv_on), ptr(grad_out), ptr(x_out), ptr(theta_out),
+                                       ptr(results), self.stream()))
 
     def apply_step(self, base, x, alpha, min_log_std, out):
         check(self.lib.mjx_apply_step(self.ctx, ptr(base), ptr(x), float(alpha), float(min_log_std), ptr(out), self.stream()))
@@ -446,31 +451,63 @@ class UpdateEngine:
             self.apply_npg_step(step_size, min_log_std)
         return self.eval_surr_kl()
 
+    def dapg_update(self, iters, damping, step_size, min_log_std, rows_on, adv_on, N_on_global=None, tol=1e-10):
+        """The whole DAPG update (dapg.py:92-121) through ONE call into libmjx (mjx_dapg_update), rank sums included: K1
+        over the bound [on-policy ; demonstrations] block, gradient x N_all / N_on, the on-policy prefix bound with its
+        whitened advantages `adv_on`, K3 (surr_before), CG, step length from step_size = 2 kl_dist, step, K3 ->
+        (surr_after, kl); deferred() has surr_before / g.x / alpha.  None when the one-call path is not available
+        (torch.distributed fallback): the caller issues the sequence itself."""
+        assert self.old_is_new, "dapg_update starts from theta_new == theta_old"
+        d = _dist()
+        if not ((d is None or self._native_comm()) and hasattr(self.backend, "dapg_update")):
+            return None
+        adv_dev = self.to_device_f32(adv_on)
+        N_on_global = self.global_count(rows_on) if N_on_global is None else int(N_on_global)
+        self._host_results = None
+        self.backend.dapg_update(iters, damping, tol, step_size, min_log_std, rows_on, N_on_global, adv_dev, self.grad, self.x,
+                                 self.theta_new, self.results)
+        self.adv = adv_dev
+        self.N_global, self.N_bound = N_on_global, int(rows_on)
+        self._prefix = (int(rows_on), N_on_global, adv_dev)
+        self.old_is_new = False
+        s = self._host_results = self.results.cpu().numpy()
+        return float(s[0] / self.N_global), float(s[1] / self.N_global)
+
     def trpo_update(self, iters, damping, step_size, kl_dist, min_log_std, tol=1e-10, batch=3, max_trials=100):
         """The whole TRPO update (trpo.py:100-126: K1, CG, step length, backtracking line search on the KL) through libmjx's
         mjx_trpo_update: the line-search trials are enqueued `batch` at a time with the accept / shrink decision taken on the
         device, one read-back per batch (the call-by-call form reads back after every trial) -> dict(alpha, trials, accepted,
-        surr_after, kl, history=[(surr, kl) per trial]); deferred() has surr_before / g.x.  None when the one-call path is
-        not available (torch.distributed fallback): the caller runs the loop itself."""
+        surr_after, kl, history=[(surr, kl) per trial]); deferred() has surr_before / g.x.  The search runs to the reference's
+        100 trials on the device (batches of 3, 6, 12, 24, 24, ... trials per read-back); when none is accepted the zero step
+        is applied and evaluated like the reference does (accepted = False, alpha = 0).  None when the one-call path is not
+        available (torch.distributed fallback): the caller runs the loop itself."""
         assert self.old_is_new, "trpo_update starts from theta_new == theta_old"
         d = _dist()
         if not ((d is None or self._native_comm()) and hasattr(self.backend, "trpo_update")):
             return None
-        first, hist = True, []
+        first, hist, done = True, [], 0
         while True:
             self._host_results = None
-            self.backend.trpo_update(iters, damping, tol, step_size, kl_dist, batch, first, min_log_std, self.grad, self.x, self.theta_new,
+            nb = max(1, min(int(batch), 24, max_trials - done))          # the per-trial log is a ring of 24 entries
+            self.backend.trpo_update(iters, damping, tol, step_size, kl_dist, nb, first, min_log_std, self.grad, self.x, self.theta_new,
                                      self.results)
             self.old_is_new = False
             first = False
             s = self._host_results = self.results.cpu().numpy()
             trials, accepted = int(s[11]), s[10] != 0.0
-            for k in range(len(hist), min(trials, 24)):
-                hist.append((float(s[16 + 2 * k] / self.N_global), float(s[17 + 2 * k] / self.N_global)))
-            if accepted or trials >= max_trials or trials >= 24:
+            for k in range(len(hist), trials):
+                hist.append((float(s[16 + 2 * (k % 24)] / self.N_global), float(s[17 + 2 * (k % 24)] / self.N_global)))
+            done = trials
+            if accepted or trials >= max_trials:
                 break
-        return dict(alpha=float(s[9]), trials=trials, accepted=bool(accepted), surr_after=float(s[0] / self.N_global),
-                    kl=float(s[1] / self.N_global), history=hist)
+            batch = 2 * nb                               # a long search reads back less and less often: 3, 6, 12, 24, 24, ...
+        alpha, surr_after, kl = float(s[9]), float(s[0] / self.N_global), float(s[1] / self.N_global)
+        if not accepted:
+            # trpo.py:119-126: after 100 rejected step lengths alpha = 0 -- the parameters stay, KL and surrogate are evaluated there
+            alpha = 0.0
+            self.apply_step(0.0, min_log_std)
+            surr_after, kl = self.eval_surr_kl()
+        return dict(alpha=alpha, trials=trials, accepted=bool(accepted), surr_after=surr_after, kl=kl, history=hist)
 
     def deferred(self):
         """-> dict(surr_before, gdotx, alpha) of the calls made with sync=False / apply_npg_step (one read-back after the update)"""

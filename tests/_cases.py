@@ -71,10 +71,8 @@ class NpgCase:
 
     def check_step(self, key, v, tol):
         """The north-star bar on a step-direction vector of a `wide` fixture: rel-L2 to the REFERENCE's fp32 result
-        < tol.  Where fp32 round-off puts two correct fp32 implementations of the same CG recurrence farther apart than
-        that -- the reference itself then sits farther than tol from fp64 truth on this problem
-        (err_ref_vs_f64_<key> in the fixture) -- the bar is the distance to truth instead:
-        rel(v, fp64 oracle) <= 1.5 x rel(reference, fp64 oracle).  -> dict of the measured errors."""
+        < tol, norm included -- no fallback (r03: the "distance to fp64 truth" escape of earlier rounds is gone; the fp64
+        numbers are still returned for the record).  -> dict of the measured errors."""
         g = self.g
         s = int(g["stride"])
         v = np.asarray(v, np.float64)
@@ -84,10 +82,7 @@ class NpgCase:
         ref_f64 = float(g["err_ref_vs_f64_" + key])
         n_ref = abs(np.linalg.norm(v) - float(g[key + "_norm"])) / float(g[key + "_norm"])
         out = dict(vs_reference=e_ref, vs_fp64=e_f64, reference_vs_fp64=ref_f64, norm_vs_reference=n_ref)
-        if e_ref < tol and n_ref < tol:
-            return out
-        assert ref_f64 > 0.5 * tol, (self.name, key, "reference is within tol/2 of truth, the HIP path is not within tol of it", out)
-        assert e_f64 <= 1.5 * ref_f64, (self.name, key, out)
+        assert e_ref < tol and n_ref < tol, (self.name, key, out)
         return out
 
 

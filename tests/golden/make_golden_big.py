@@ -8,6 +8,8 @@ Run in the build container only (minutes of CPU time):   python tests/golden/mak
                     (mjrl/algos/npg_cg.py:108-142 at BASELINE configs[3] shapes)
   dapg_cfg5_wide    obs 39, act 28, 512x512, 1500 x 200 = 300 000 on-policy timesteps (d = 297 528) + 25 x 200
                     demonstration steps, DAPG, 10 CG iterations (mjrl/algos/dapg.py:92-121 at configs[4] shapes)
+  bench_ref_1m      the same 1M-timestep batch through the UNMODIFIED reference: NPG.train_from_paths (configs[1]) and
+                    TRPO.train_from_paths with kl_dist 0.025 (configs[2], 3 line-search trials); whole vectors stored
   bench_cfg2_1m     the 1M-timestep batch bench.py runs (configs[1]): alpha / kl / surr_improvement of one NPG update
                     from the fp64 oracle (the reference needs ~20 s and agrees to 1e-6)
 
@@ -160,6 +162,68 @@ def bench_case(name):
     print(name, {k: v for k, v in out.items() if np.ndim(v) == 0}, flush=True)
 
 
+def bench_reference_case(name):
+    """The UNMODIFIED reference on bench.py's own 1M-timestep batch (BASELINE configs[1] and configs[2]):
+    NPG.train_from_paths (mjrl/algos/npg_cg.py:91-163) and TRPO.train_from_paths with kl_dist = 0.025
+    (mjrl/algos/trpo.py:56-146; the first two step lengths are rejected -> 3 trials) -- ~20 s + ~25 s of CPU.
+    d = 5 708, so the whole vectors are stored (gradient, CG solution, both update steps)."""
+    import contextlib
+    import io
+    import bench
+    from mjrl.algos.trpo import TRPO
+    n, m, hidden = bench.N_OBS, bench.N_ACT, bench.HIDDEN
+    theta0 = bench.initial_params()
+    obs, act, adv = bench.synth_shard(0, 1)
+    T = bench.T
+    paths = [dict(observations=obs[i * T:(i + 1) * T].astype(np.float64), actions=act[i * T:(i + 1) * T].astype(np.float64),
+                  rewards=np.zeros(T), advantages=adv[i * T:(i + 1) * T].copy(), terminated=False) for i in range(bench.N_TRAJ)]
+    kw = dict(FIM_invert_args={'iters': bench.CG_ITERS, 'damping': bench.DAMPING}, save_logs=True)
+    spec = EnvSpec(n, m, T)
+    out = dict(N=obs.shape[0], n=n, m=m, hidden=np.array(hidden, dtype=np.int64), cg_iters=bench.CG_ITERS, damping=bench.DAMPING,
+               step=bench.STEP, trpo_kl_dist=0.025, theta0=theta0, torch_threads=torch.get_num_threads())
+
+    def fresh():
+        pol = MLP(spec, hidden_sizes=hidden, seed=1, init_log_std=-0.5)
+        pol.set_param_values(theta0.copy())
+        assert np.array_equal(pol.get_param_values(), theta0)
+        return pol
+    # ---- configs[1]: NPG
+    pol = fresh()
+    agent = NPG(None, pol, None, normalized_step_size=bench.STEP, **kw)
+    agent.logger = DataLog()
+    adv_w = (adv - np.mean(adv)) / (np.std(adv) + 1e-6)
+    t0 = time.time()
+    g = agent.flat_vpg(obs.astype(np.float64), act.astype(np.float64), adv_w)
+    x = cg_solve(agent.build_Hvp_eval([obs.astype(np.float64), act.astype(np.float64)], regu_coef=bench.DAMPING), g, x_0=g.copy(),
+                 cg_iters=bench.CG_ITERS)
+    print(name, "reference vpg + cg_solve %.1f s" % (time.time() - t0), flush=True)
+    t0 = time.time()
+    agent.train_from_paths(paths)
+    out["npg_reference_seconds"] = time.time() - t0
+    log = agent.logger.log
+    out.update(npg_vpg=g, npg_cg_x=x, npg_alpha=log['alpha'][-1], npg_kl=log['kl_dist'][-1],
+               npg_surr_improvement=log['surr_improvement'][-1], npg_new_params=pol.get_param_values())
+    print(name, "reference NPG.train_from_paths %.1f s: alpha %r kl %r surr_improvement %r"
+          % (out["npg_reference_seconds"], out["npg_alpha"], out["npg_kl"], out["npg_surr_improvement"]), flush=True)
+    # ---- configs[2]: TRPO, kl_dist = 0.025
+    pol = fresh()
+    agent = TRPO(None, pol, None, kl_dist=0.025, **kw)
+    agent.logger = DataLog()
+    buf = io.StringIO()
+    t0 = time.time()
+    with contextlib.redirect_stdout(buf):
+        agent.train_from_paths(paths)
+    out["trpo_reference_seconds"] = time.time() - t0
+    log = agent.logger.log
+    rejected = buf.getvalue().count("Backtracking")
+    out.update(trpo_alpha=log['alpha'][-1], trpo_kl=log['kl_dist'][-1], trpo_surr_improvement=log['surr_improvement'][-1],
+               trpo_new_params=pol.get_param_values(), trpo_trials=rejected + 1)
+    print(name, "reference TRPO.train_from_paths %.1f s: alpha %r kl %r surr_improvement %r trials %d"
+          % (out["trpo_reference_seconds"], out["trpo_alpha"], out["trpo_kl"], out["trpo_surr_improvement"], rejected + 1), flush=True)
+    assert rejected >= 2, "kl_dist must make the line search backtrack at least twice"
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 def inputnorm_truth(name):
     """fp64 truth for the input_normalization fixture of make_golden.py (npg_inputnorm_32x32: the update runs with
     theta_new == theta_old but an input transform on policy.model only, npg_cg.py:101-107, i.e. the GENERAL Hessian):
@@ -195,6 +259,7 @@ CASES = {
     "npg_cfg4_wide": lambda: big_case("npg_cfg4_wide", 376, 17, (256, 256), 800, 250, 25, "npg"),
     "dapg_cfg5_wide": lambda: big_case("dapg_cfg5_wide", 39, 28, (512, 512), 1500, 200, 10, "dapg", kl_dist=0.025, demo=(25, 200)),
     "bench_cfg2_1m": lambda: bench_case("bench_cfg2_1m"),
+    "bench_ref_1m": lambda: bench_reference_case("bench_ref_1m"),
 }
 
 if __name__ == "__main__":

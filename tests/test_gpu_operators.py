@@ -222,13 +222,41 @@ def test_dapg_with_hvp_sample_frac_draws_from_the_on_policy_rows():
     agent.engine.close()
 
 
-def test_whole_update_at_the_baseline_size():
-    """ONE NPG update on bench.py's own 1M-timestep batch (BASELINE configs[1]): alpha / kl / surr_improvement and the
-    step against the stored fp64-oracle values (tests/golden/bench_cfg2_1m.npz; 84 s of CPU to regenerate)."""
-    import torch
+@pytest.mark.parametrize("layerwise", [False, True])
+def test_one_call_dapg_update_equals_call_sequence(layerwise, monkeypatch):
+    """mjx_dapg_update (K1 over [on-policy ; demonstrations], gradient x N_all / N_on, on-policy prefix, K3, CG, step, K3 from
+    ONE C call) == the same steps issued call by call from Python (dapg.py:92-121), bit for bit; two iterations, so the
+    decaying demonstration weight (lam_1^iter) and the re-binding of the next batch are covered too."""
+    from mjrl_amd.algos.dapg import DAPG
+    from mjrl_amd.engine import UpdateEngine
+    if layerwise:
+        monkeypatch.setenv("MJX_FORCE_LAYERWISE", "1")
+    c = NpgCase("npg_cfg2_small")
+    demos = synth.make_paths(3, 200, c.n, c.m, seed=7)
+    outs = []
+    for one_call in (True, False):
+        if not one_call:
+            monkeypatch.setattr(UpdateEngine, "dapg_update", lambda self, *a, **k: None)
+        agent, pol = make_agent(c, cls=DAPG, demo_paths=demos, kl_dist=0.025, lam_0=1e-2, lam_1=0.95)
+        assert agent.engine.fused == (not layerwise)
+        log = []
+        for _ in range(2):
+            agent.train_from_paths(c.paths)
+            u = agent.last_update
+            log.append((pol.get_param_values().copy(), u["alpha"], u["kl_dist"], u["surr_before"], u["surr_after"], u["gdotx"]))
+        eng = agent.engine
+        assert eng.N_bound == c.obs.shape[0] and eng.N_local > eng.N_bound        # left bound to the on-policy prefix
+        outs.append(log)
+        agent.engine.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a[0], b[0])
+        assert a[1:] == b[1:], (a[1:], b[1:])
+    assert not np.array_equal(outs[0][0][0], outs[0][1][0])
+
+
+def _bench_engine():
     import bench
     from mjrl_amd.engine import UpdateEngine
-    g = load("bench_cfg2_1m")
     theta0 = bench.initial_params()
     obs, act, adv = bench.synth_shard(0, 1)
     adv = (adv - adv.mean()) / (adv.std() + 1e-6)
@@ -236,19 +264,65 @@ def test_whole_update_at_the_baseline_size():
     ident = np.concatenate([np.zeros(bench.N_OBS), np.ones(bench.N_OBS), np.zeros(bench.N_ACT), np.ones(bench.N_ACT)]).astype(np.float32)
     eng.set_policy(theta0, theta0, ident, ident)
     eng.set_batch(obs, act, adv)
-    assert eng.N_global == int(g["N"])
-    grad, _ = eng.surr_vpg(sync=False)
-    eng.cg_solve(grad, bench.CG_ITERS, bench.DAMPING, sync=False)
-    eng.apply_npg_step(bench.STEP, -3.0)
-    surr_after, kl = eng.eval_surr_kl()
+    return bench, eng, theta0
+
+
+def test_whole_update_at_the_baseline_size():
+    """ONE NPG update on bench.py's own 1M-timestep batch (BASELINE configs[1]) against the UNMODIFIED REFERENCE's
+    NPG.train_from_paths on that batch (tests/golden/bench_ref_1m.npz, made by make_golden_big.py bench_ref_1m: 25 s of
+    CPU; npg_cg.py:108-142): step direction at TOL_STEP, alpha / kl / surr_improvement at 1e-5 -- and against the fp64
+    oracle's values (bench_cfg2_1m.npz), call by call and through the one-call entry point."""
+    g, r = load("bench_cfg2_1m"), load("bench_ref_1m")
+    bench, eng, theta0 = _bench_engine()
+    assert eng.N_global == int(g["N"]) == int(r["N"]) and np.array_equal(theta0, r["theta0"])
+    ref_step = r["npg_new_params"].astype(np.float64) - theta0
+    for one_call in (False, True):
+        if one_call:
+            eng.set_policy(theta0, theta0, eng.tr_new.cpu().numpy(), eng.tr_old.cpu().numpy())
+            surr_after, kl = eng.npg_update(bench.CG_ITERS, bench.DAMPING, bench.STEP, -3.0)
+        else:
+            grad, _ = eng.surr_vpg(sync=False)
+            assert rel(grad.cpu().numpy(), r["npg_vpg"]) < 1e-5
+            eng.cg_solve(grad, bench.CG_ITERS, bench.DAMPING, sync=False)
+            assert rel(eng.x.cpu().numpy(), r["npg_cg_x"]) < TOL_STEP
+            eng.apply_npg_step(bench.STEP, -3.0)
+            surr_after, kl = eng.eval_surr_kl()
+        late = eng.deferred()
+        step = eng.theta_new.cpu().numpy().astype(np.float64) - theta0
+        # ---- the reference itself
+        assert rel(step, ref_step) < TOL_STEP, rel(step, ref_step)
+        assert abs(late["alpha"] - float(r["npg_alpha"])) < 1e-5 * float(r["npg_alpha"])
+        assert abs(kl - float(r["npg_kl"])) < 1e-5 * float(r["npg_kl"])
+        assert abs((surr_after - late["surr_before"]) - float(r["npg_surr_improvement"])) < 1e-5 * float(r["npg_surr_improvement"])
+        # ---- fp64 truth
+        assert abs(late["alpha"] - float(g["alpha"])) < 1e-5 * float(g["alpha"])
+        assert abs(kl - float(g["kl"])) < 1e-5 * float(g["kl"])
+        assert abs((surr_after - late["surr_before"]) - float(g["surr_improvement"])) < 1e-5 * float(g["surr_improvement"])
+        s = int(g["stride"])
+        assert rel(step[::s], g["step_sub"]) < TOL_STEP
+        assert abs(np.linalg.norm(step) - float(g["step_norm"])) < 1e-5 * float(g["step_norm"])
+    eng.close()
+
+
+def test_trpo_update_at_the_baseline_size():
+    """BASELINE configs[2]: ONE TRPO update (kl_dist 0.025: the first two step lengths are rejected) on the same
+    1M-timestep batch against the UNMODIFIED REFERENCE's TRPO.train_from_paths (bench_ref_1m.npz; trpo.py:100-126, 45 s
+    of CPU): the same number of line-search trials, alpha / kl / surr_improvement at 1e-5, step at TOL_STEP -- device-side
+    line search (mjx_trpo_update) and the agent's call-by-call loop."""
+    r = load("bench_ref_1m")
+    bench, eng, theta0 = _bench_engine()
+    kl_dist = float(r["trpo_kl_dist"])
+    ref_step = r["trpo_new_params"].astype(np.float64) - theta0
+    res = eng.trpo_update(bench.CG_ITERS, bench.DAMPING, 2.0 * kl_dist, kl_dist, -3.0)
     late = eng.deferred()
-    assert abs(late["alpha"] - float(g["alpha"])) < 1e-5 * float(g["alpha"])
-    assert abs(kl - float(g["kl"])) < 1e-5 * float(g["kl"])
-    assert abs((surr_after - late["surr_before"]) - float(g["surr_improvement"])) < 1e-5 * float(g["surr_improvement"])
+    assert res["accepted"] and res["trials"] == int(r["trpo_trials"]) == 3
+    assert abs(res["alpha"] - float(r["trpo_alpha"])) < 1e-5 * float(r["trpo_alpha"])
+    assert abs(res["kl"] - float(r["trpo_kl"])) < 1e-5 * float(r["trpo_kl"]) and res["kl"] < kl_dist
+    assert abs((res["surr_after"] - late["surr_before"]) - float(r["trpo_surr_improvement"])) < 1e-5 * float(r["trpo_surr_improvement"])
     step = eng.theta_new.cpu().numpy().astype(np.float64) - theta0
-    s = int(g["stride"])
-    assert rel(step[::s], g["step_sub"]) < TOL_STEP
-    assert abs(np.linalg.norm(step) - float(g["step_norm"])) < 1e-5 * float(g["step_norm"])
+    assert rel(step, ref_step) < TOL_STEP, rel(step, ref_step)
+    # the rejected trials' KL values exceed the bound, in the reference's order (alpha, 0.9 alpha, 0.81 alpha)
+    assert [h[1] >= kl_dist for h in res["history"]] == [True, True, False]
     eng.close()
 
 
@@ -485,7 +559,9 @@ def test_device_line_search_equals_call_by_call_trpo(hid):
     """mjx_trpo_update (K1, CG, step length, backtracking trials with the accept / shrink decision on the device, one read-back
     per batch of trials) against the same update issued call by call with a read-back after every trial (trpo.py:100-126):
     same number of trials, same step length, the same parameters bit for bit -- on the fused and on the layer-wise path,
-    with a KL bound tight enough to force several shrinks (more than one batch of three trials)."""
+    with a KL bound tight enough to force several shrinks (more than one batch of three trials), one that needs MORE THAN 24
+    trials (the per-trial log of the device loop is a ring of 24) and one that is never met: the reference gives up after 100
+    trials with alpha = 0 (trpo.py:119-126)."""
     import torch
     from mjrl_amd.engine import UpdateEngine
     n, m, N = 17, 6, 20000 + 3
@@ -493,12 +569,16 @@ def test_device_line_search_equals_call_by_call_trpo(hid):
     th = synth.perturbed_params(synth.init_params(n, m, hid))
     ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
     obs, act, adv = rng.randn(N, n), rng.randn(N, m), rng.randn(N)
-    for kl_dist, step_size in ((0.01, 0.02), (0.002, 0.02)):   # (the second: the step is sized for 5 x the KL it has to meet)
+    if hid == (64, 64):
+        cases = ((0.01, 0.02), (0.002, 0.02), (4e-5, 0.02), (-1.0, 0.02))
+    else:
+        cases = ((0.01, 0.02), (0.002, 0.02))
+    for kl_dist, step_size in cases:   # (the second: the step is sized for 5 x the KL it has to meet; third: ~27 trials; fourth: never)
         eng = UpdateEngine(n, m, hid)
         eng.set_policy(th, th, ident, ident)
         eng.set_batch(obs, act, adv)
         res = eng.trpo_update(10, 1e-4, step_size, kl_dist, -3.0)
-        assert res is not None and res["accepted"]
+        assert res is not None and res["accepted"] == (kl_dist > 0)
         one = dict(theta=eng.theta_new.clone(), **res)
         late = eng.deferred()
         # call by call
@@ -511,12 +591,21 @@ def test_device_line_search_equals_call_by_call_trpo(hid):
             eng.apply_step(alpha, -3.0)
             surr_after, kl = eng.eval_surr_kl()
             trials += 1
+            hist_last = (surr_after, kl)
             if kl < kl_dist:
                 break
             alpha = 0.9 * alpha
+            if k == 99:
+                alpha = 0.0
+        eng.apply_step(alpha, -3.0)                    # the reference's closing re-evaluation (trpo.py:122-125)
+        surr_after, kl = eng.eval_surr_kl()
         assert trials == one["trials"] and (trials > 3 or kl_dist == 0.01)
+        if kl_dist == 4e-5:
+            assert 24 < trials < 100, trials
+        if kl_dist < 0:
+            assert trials == 100 and one["alpha"] == 0.0 and torch.equal(eng.theta_new, eng.theta_old)
         assert float(alpha) == one["alpha"] and kl == one["kl"] and surr_after == one["surr_after"]
         assert torch.equal(eng.theta_new, one["theta"])
         assert late["surr_before"] == surr_before and late["gdotx"] == gdotx
-        assert len(one["history"]) == trials and one["history"][-1] == (surr_after, kl)
+        assert len(one["history"]) == trials and one["history"][-1] == hist_last
         eng.close()

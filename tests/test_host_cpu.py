@@ -26,6 +26,64 @@ def test_library_exports_every_declared_symbol():
     assert lib.mjx_device_count() >= 0
 
 
+def _parse_header_prototypes(hdr):
+    """-> {name: (return type string, [parameter type strings])} for every function include/mjx.h declares"""
+    src = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"^\s*#.*$", " ", src, flags=re.M)
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(mjx_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        ret, name, params = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+        if ret.startswith("typedef"):
+            continue
+        plist = []
+        if params not in ("", "void"):
+            for p in params.split(","):
+                p = p.strip()
+                mm = re.match(r"(.*?)([A-Za-z_]\w*)?$", p)           # drop the parameter name
+                t = mm.group(1).strip() if ("*" in p or " " in p) else p
+                plist.append(" ".join(t.replace("*", " * ").split()))
+        out[name] = (" ".join(ret.replace("*", " * ").split()), plist)
+    return out
+
+
+def test_ctypes_prototypes_match_the_header_argument_by_argument():
+    """mjrl_amd/_lib.PROTOTYPES (the hand-written ctypes table) against a parse of include/mjx.h: the same functions, the
+    same number of arguments, and per argument the same C scalar type (int / int64_t / float / double) or a pointer where
+    the header has a pointer (ctx**, int*, char*, data pointers, function-pointer typedefs) -- so the table cannot drift
+    from the ABI silently."""
+    import ctypes
+    from mjrl_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mjx.h")).read()
+    protos = _parse_header_prototypes(hdr)
+    assert set(protos) == set(_lib.PROTOTYPES), set(protos) ^ set(_lib.PROTOTYPES)
+    scalars = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double}
+    fnptrs = {"mjx_allreduce_fn", "mjx_reduce_fn"}
+
+    def is_pointer_ctype(t):
+        return t in (ctypes.c_void_p, ctypes.c_char_p) or (isinstance(t, type) and issubclass(t, (ctypes._Pointer, ctypes._CFuncPtr)))
+
+    for name, (ret, params) in protos.items():
+        res, args = _lib.PROTOTYPES[name]
+        assert len(args) == len(params), (name, params, args)
+        if ret == "void":
+            assert res is None, name
+        elif "*" in ret:
+            assert is_pointer_ctype(res), (name, ret, res)
+        else:
+            assert res is scalars[ret], (name, ret, res)
+        for i, (p, a) in enumerate(zip(params, args)):
+            base = p.replace("const ", "").strip()
+            if "*" in base or base in fnptrs:
+                assert is_pointer_ctype(a), (name, i, p, a)
+                if base == "int *":
+                    assert a in (ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)), (name, i, p, a)
+                if base == "double *" and a is not ctypes.c_void_p:
+                    assert a is ctypes.POINTER(ctypes.c_double), (name, i, p, a)
+            else:
+                assert a is scalars[base], (name, i, p, a)
+
+
 def test_no_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():

@@ -93,6 +93,31 @@ def test_bench_fixture_is_the_oracles_update_on_the_bench_batch():
     assert float(g["surr_improvement"]) > 0 and float(g["alpha"]) > 0 and float(g["step_norm"]) > 0
 
 
+def test_reference_fixture_at_the_baseline_size_pins_the_oracle():
+    """bench_ref_1m.npz (the UNMODIFIED reference's NPG / TRPO updates on bench.py's 1M-timestep batch) against
+    bench_cfg2_1m.npz (the fp64 oracle's NPG update on the same batch): the two were computed independently (fp32 torch
+    autograd vs fp64 analytic NumPy) and agree to the reference's own round-off; the TRPO step is the reference's CG
+    solution scaled by its accepted step length, alpha_0 0.9^2 with alpha_0 from the oracle's g.x."""
+    import bench
+    g, r = load("bench_cfg2_1m"), load("bench_ref_1m")
+    theta0 = bench.initial_params()
+    assert np.array_equal(theta0, r["theta0"]) and int(r["N"]) == bench.N_TRAJ * bench.T == int(g["N"])
+    step = r["npg_new_params"].astype(np.float64) - theta0
+    s = int(g["stride"])
+    assert np.linalg.norm(step[::s] - g["step_sub"]) / np.linalg.norm(g["step_sub"]) < 1e-5
+    for k in ("alpha", "kl", "surr_improvement"):
+        assert abs(float(r["npg_" + k]) - float(g[k])) < 3e-6 * abs(float(g[k])), k
+    x = r["npg_cg_x"].astype(np.float64)
+    tstep = r["trpo_new_params"].astype(np.float64) - theta0
+    assert np.linalg.norm(tstep - float(r["trpo_alpha"]) * x) / np.linalg.norm(tstep) < 1e-6
+    gx = float(np.dot(r["npg_vpg"].astype(np.float64), x))
+    a0 = np.sqrt(abs(2 * float(r["trpo_kl_dist"]) / (gx + 1e-20)))
+    assert int(r["trpo_trials"]) == 3 and abs(float(r["trpo_alpha"]) - 0.81 * a0) < 1e-5 * a0
+    assert float(r["trpo_kl"]) < float(r["trpo_kl_dist"]) < float(r["npg_kl"])
+    # NPG's alpha from the same g.x (npg_cg.py:133)
+    assert abs(float(r["npg_alpha"]) - np.sqrt(abs(bench.STEP / (gx + 1e-20)))) < 1e-5 * float(r["npg_alpha"])
+
+
 def test_torch_port_general_hvp_matches_reference():
     from oracle.torch_port import TorchPolicy
     g = load("hvp_general_64x64")
