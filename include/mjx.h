@@ -311,6 +311,10 @@ int mjx_profile_read(mjx_ctx* ctx, double* out_host);
 /* ---- debugging aid (tests only) ------------------------------------------ */
 /* When non-NULL, the fused kernels dump the first tile's intermediates here. */
 int mjx_set_debug_buffer(mjx_ctx* ctx, float* dbg, int64_t floats);
+/* When non-NULL (device, 4 int64), workgroup 0 of every fused-kernel launch leaves its shader-cycle counter and the 100 MHz
+ * real-time counter at entry ([0], [1]) and exit ([2], [3]) of the PRODUCTION kernels: cycles of a launch and the shader clock
+ * the chip sustained under it (tools/fvp_time.py; the part trades clock for issue density, so both are needed). */
+int mjx_set_clock_buffer(mjx_ctx* ctx, int64_t* clk);
 
 #ifdef __cplusplus
 }

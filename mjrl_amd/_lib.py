@@ -73,6 +73,7 @@ PROTOTYPES = {
     "mjx_profile_enable": (c_int, [c_void_p, c_int]),
     "mjx_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_double)]),
     "mjx_set_debug_buffer": (c_int, [c_void_p, c_void_p, c_int64]),
+    "mjx_set_clock_buffer": (c_int, [c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -46,6 +46,9 @@ struct FusedArgs {
   float* partials;       // [gridDim.x][d]   VPG / FVP
   double* spartials;     // [gridDim.x][4]
   float* dbg;            // optional dump of tile 0 (block 0, wave 0)
+  long long* clk;        // optional: workgroup 0 stamps {cycle, real time} at entry / exit
+  int reverse;           // cached FVP: walk the tiles from the far end (alternate launches: what the previous sweep touched
+                         // last is still in the memory-side cache when this one starts there)
   float* hcache;         // forward-activation cache [tile][MT1+MT2][4][64 lanes][4]: written by MODE_VPG, read by cached FVP
   float* ocache;         // old-policy outputs [tile][MP + 1][32]: mean per action + log-likelihood; written by MODE_VPG
                          // (old == new), read by MODE_EVAL when thetaB / trB still equal `snap`
@@ -65,6 +68,13 @@ struct FusedArgs {
 #define MJX_GSTAMP(k) do {} while (0)
 #endif
 #define MJX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// 4- and 8-byte LDS accesses of the cached Fisher-vector product.  (Measured, r03: making them volatile LDS-space accesses keeps
+// hipcc from pairing them into ds_read2 / ds_write2 -- whose 8-bit offset fields cost a vector add per pair to re-base the
+// address, 48 per tile -- and saves 2.5 % of the kernel's cycles, but the chip gives the same 2.5 % back in clock: no
+// change in time, and hipcc 7.2 crashes on the volatile form in one instance.  Plain accesses it is.)
+#define LDS_ST(p, v) (*(p) = (v))
+#define LDS_LD(p) (*(p))
+#define LDS_LD2(p) (*(const f32x2*)(p))
 
 __device__ __forceinline__ void wave_sync() {
   // LDS traffic between lanes of ONE wave: hardware executes a wave's DS ops in order,
@@ -167,12 +177,18 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   constexpr int MT1 = LT::MT1, MT2 = LT::MT2, S2 = LT::S2, S3 = LT::S3, ST = LT::ST;
   constexpr int RA = MP / 2;                      // accumulator rows per lane that map to actions: a = unit_of(r, hi), r < RA
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+  // (wave-uniform by construction: as a scalar, the tile index and everything derived from it -- cache addresses, the
+  //  wave's LDS base -- is computed on the scalar unit instead of per lane)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t himask = hi ? 0xffffffffu : 0u;
   const int n = A.n, m = A.m;
   // small per-wave scratch, two workgroups per CU (up to 8 actions: the 16- / 32-action instances do not fit 256 registers)
   constexpr bool EV2 = (MODE == MODE_EVAL) && !DBG && MP <= 8;
-  const LT L(n, EV2);
+  // (instances with a compile-time feature count lay their LDS out for the widest observation they serve, NPC - 1 features:
+  //  every offset is then a compile-time constant and folds into the DS instructions' immediate fields instead of costing a
+  //  vector add per access -- vector-ALU instructions are not hidden by fp32 MFMAs, see the cached Fisher-vector product)
+  const LT L(NPC ? NPC - 1 : n, EV2);
   const int NP = NPC ? NPC : L.NP;                // compile-time when the variant is specialised for the obs dim
   const int S1 = NP + 2;
   const FlatOff fo(n, m, H1, H2);
@@ -188,6 +204,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   float* bufB = ws + L.oBB;
 
   MJX_GSTAMP(16);
+  if (A.clk && blockIdx.x == 0 && threadIdx.x == 0) { A.clk[0] = (long long)__builtin_readcyclecounter(); A.clk[1] = (long long)__builtin_amdgcn_s_memrealtime(); }
   // ---------------- stage weights (whole workgroup) ----------------
   // Every global value is requested first (one batch of independent loads per thread), the LDS zero-fill runs
   // while they are in flight, then the values are scattered to their padded LDS rows: one memory round trip for
@@ -348,6 +365,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   constexpr int NFQ = NPC ? NPC / 4 : 1;
   f32x4 gW1q[MT1][NFQ];
   f32x4 gW3[NT3];
+  f32x4 gW3b[XCACHED ? NT3 : 1];      // cached FVP: a second set (odd sample quads), so that 4 chains of 4x4x1 MFMAs are in flight
   float sb2[MT2], sb3r[RA], gls[RA];      // grad b2[32*nt + j] (every lane); grad b3 / grad log_std of action unit_of(r, hi), this lane's samples
 #pragma unroll
   for (int a = 0; a < MT1; ++a)
@@ -363,6 +381,8 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
     for (int b = 0; b < MT1; ++b) gW2[a][b] = (f32x16)(0.f);
 #pragma unroll
   for (int a = 0; a < NT3; ++a) gW3[a] = (f32x4)(0.f);
+#pragma unroll
+  for (int a = 0; a < (XCACHED ? NT3 : 1); ++a) gW3b[a] = (f32x4)(0.f);
 #pragma unroll
   for (int a = 0; a < RA; ++a) { gls[a] = 0.f; sb3r[a] = 0.f; }
 #pragma unroll
@@ -399,26 +419,40 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   // same registers as soon as the current ones are dead (behind the weight-gradient products), so nothing is copied.
   f32x16 hn1[MT1], hn2[MT2];
   f32x2 xc[NQC];
+  // One wave-uniform base per 4 KB of the tile's cache lines (scalar registers, formed on the scalar unit) + the lane's
+  // 32-bit byte offset + an immediate: no vector-ALU address arithmetic per load.  (readfirstlane of a uniform value is a
+  // scalar move; it keeps the compiler from folding the 4 KB steps back into 64-bit vector adds.)
+  typedef const char __attribute__((address_space(1)))* gcptr;
+  auto ubase = [&](const float* p) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (gcptr)(((uint64_t)hi32 << 32) | lo);
+  };
   auto load_h = [&](int64_t t) {
-    const float* base = A.hcache + t * HC_TILE + lane * 4;
+    const float* tb = A.hcache + t * HC_TILE;
     if (NPC) {
+      gcptr xb = ubase(tb + HC_H);
 #pragma unroll
-      for (int q = 0; q < NQC; ++q) xc[q] = *(const f32x2*)(A.hcache + t * HC_TILE + HC_H + (q * 64 + lane) * 2);
+      for (int q = 0; q < NQC; ++q) xc[q] = *(const f32x2 __attribute__((address_space(1)))*)(xb + (uint32_t)(lane * 8) + q * 512);
     }
 #pragma unroll
-    for (int mt = 0; mt < MT1; ++mt)
+    for (int mt = 0; mt < MT1; ++mt) {
+      gcptr b = ubase(tb + mt * 1024);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        f32x4 v = *(const f32x4*)(base + (mt * 4 + q) * 256);
+        f32x4 v = *(const f32x4 __attribute__((address_space(1)))*)(b + (uint32_t)(lane * 16) + q * 1024);
         hn1[mt][4 * q] = v.x; hn1[mt][4 * q + 1] = v.y; hn1[mt][4 * q + 2] = v.z; hn1[mt][4 * q + 3] = v.w;
       }
+    }
 #pragma unroll
-    for (int mt = 0; mt < MT2; ++mt)
+    for (int mt = 0; mt < MT2; ++mt) {
+      gcptr b = ubase(tb + (MT1 + mt) * 1024);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        f32x4 v = *(const f32x4*)(base + ((MT1 + mt) * 4 + q) * 256);
+        f32x4 v = *(const f32x4 __attribute__((address_space(1)))*)(b + (uint32_t)(lane * 16) + q * 1024);
         hn2[mt][4 * q] = v.x; hn2[mt][4 * q + 1] = v.y; hn2[mt][4 * q + 2] = v.z; hn2[mt][4 * q + 3] = v.w;
       }
+    }
   };
 
   auto load_xi = [&](int64_t t) {                 // MODE_EVAL with K1's observation image: the layer-1 operand pairs of tile t
@@ -427,8 +461,10 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   };
 
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const bool rev = XCACHED && A.reverse;
+  auto ptile = [&](int64_t t) { return rev ? ntiles - 1 - t : t; };          // logical -> physical tile of this launch
   if (!XCACHED && !use_xi && tile < ntiles) load_x(tile);
-  if (XCACHED && tile < ntiles) load_h(tile);
+  if (XCACHED && tile < ntiles) load_h(ptile(tile));
   if (MODE == MODE_EVAL && use_oc && tile < ntiles) load_oc(tile);
   if (MODE == MODE_EVAL && use_xi && tile < ntiles) load_xi(tile);
 
@@ -437,9 +473,425 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   auto run_tiles = [&](auto xi_tag) {
   constexpr bool XI = decltype(xi_tag)::value;
   for (; tile < ntiles; tile += tstride) {
-    const int64_t s0 = tile * 32;
+    const int64_t s0 = (XCACHED ? ptile(tile) : tile) * 32;
     const bool valid = (s0 + j) < A.N;
     MJX_STAMP(0);
+    if constexpr (XCACHED) {
+      // ================= cached-forward Fisher-vector product: its own tile schedule (r03) =================
+      // Measured on gfx950 (tools/probe_fill.hip): a v_mfma_f32_32x32x2_f32 does NOT hide vector-ALU instructions -- fp32
+      // matrix products run at the vector-FMA rate on a shared datapath: every VALU instruction between two MFMAs costs its
+      // 4 cycles, and the first one of a gap 8 more; LDS reads / stores, s_waitcnt, s_nop and scalar instructions are free
+      // in the 64-cycle shadow.  So the tile is a sequence of MFMA phases that carry ONLY LDS traffic, separated by a few
+      // VALU bursts (one entry penalty each), VALU instructions are counted, and whatever can go through LDS does:
+      //   R1  t1  = V1a x~                      (20 MFMAs)   LDS: x~^T -> xT
+      //   R2  t2  = c2 + V2 h1                  (64)         LDS: h1^T -> bufB, h2^T -> bufA
+      //   VA  t1 *= 1 - h1^2 ; f2 = 1 - h2^2                 (96 VALU)
+      //   R3  t2 += W2 t1                       (64)
+      //   R4a out = V3 h2 (4x4x1; fills the drain of R3)   VB  t2 *= f2 (32)   R4b out += W3 t2 (4x4x1)
+      //   VC  d3 (epilogue, ~35 VALU), d3^T -> LDS
+      //   R6  delta2 = W3^T d3, lane = sample   (8)          -- ONE layout: the lane = unit copy takes a trip through LDS
+      //   R7  gW3 += d3^T h2 (4x4x1; fills the drain of R6)   VD  delta2 *= f2 (32)
+      //   R8  delta1 = W2^T delta2, lane = unit (64)         LDS: delta2^T -> bufA (h2^T is dead) -> lane = unit registers;
+      //                                                       next tile's cache lines requested
+      //   R9  gW2 += delta2^T h1                (64)         LDS: h1^T fetches
+      //   VE  delta1 *= 1 - h1^2 (64, from the h1^T fetches) ; b2 sums (32)
+      //   R10 gW1 += delta1^T x~  (4x4x1 / 32x32x2)
+      constexpr int NGRP = MP / 4;
+      f32x16 (&h1)[MT1] = hn1;
+      f32x16 (&h2)[MT2] = hn2;
+      f32x16 t1[MT1], t2[MT2];
+      float f2s[MT2][16];
+      // ---------------- R1
+#pragma unroll
+      for (int mt = 0; mt < MT1; ++mt) t1[mt] = (f32x16)(0.f);
+      {
+        f32x2 vc[MT1];
+        const int f00 = 2 * hi;
+        const float* ximg = A.hcache + ptile(tile) * HC_TILE + HC_H + lane * 2;
+        auto xpair = [&](int q) {
+          if constexpr (NPC != 0) return xc[q]; else return *(const f32x2*)(ximg + q * 128);
+        };
+        f32x2 xb = xpair(0);
+        float xb0 = xb.x, xb1 = xb.y;
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt) vc[mt] = LDS_LD2(&slotB[L.oW1 + (32 * mt + j) * S1 + f00]);
+#pragma unroll NPC ? NPC / 4 : 1
+        for (int q = 0; q < (NPC ? NPC / 4 : NP / 4); ++q) {
+          const int f0 = 4 * q + 2 * hi;
+          const int f1 = (q + 1 < NP / 4) ? f0 + 4 : f0;
+          f32x2 vn[MT1];
+          const f32x2 xnx = xpair((q + 1 < NP / 4) ? q + 1 : q);
+#pragma unroll
+          for (int mt = 0; mt < MT1; ++mt) vn[mt] = LDS_LD2(&slotB[L.oW1 + (32 * mt + j) * S1 + f1]);
+          LDS_ST(&xT[f0 * ST + j], xb0); LDS_ST(&xT[(f0 + 1) * ST + j], xb1);
+#pragma unroll
+          for (int mt = 0; mt < MT1; ++mt) t1[mt] = MJX_MFMA(vc[mt].x, xb0, t1[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MT1; ++mt) t1[mt] = MJX_MFMA(vc[mt].y, xb1, t1[mt]);
+          xb0 = xnx.x; xb1 = xnx.y;
+#pragma unroll
+          for (int mt = 0; mt < MT1; ++mt) vc[mt] = vn[mt];
+        }
+      }
+      MJX_STAMP(1);
+      // ---------------- R2: t2 = c2 + V2 h1 ; the [unit][sample] copies of h1 / h2 (LDS stores: free) ride along
+      constexpr int NS = MT1 * 4;                               // (kb, q) operand groups
+#pragma unroll
+      for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 c = *(const f32x4*)&slotB[L.oB2 + 32 * mt + 8 * q + 4 * hi];
+          t2[mt][4 * q + 0] = c.x; t2[mt][4 * q + 1] = c.y; t2[mt][4 * q + 2] = c.z; t2[mt][4 * q + 3] = c.w;
+        }
+      {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 vc[MT2], vn[MT2];
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) vc[mt] = *(const f32x4*)&slotB[L.oW2 + (32 * mt + j) * S2 + 4 * hi];
+        constexpr int R1 = 16 * MT1 / NS, R2 = 16 * MT2 / NS;   // registers of h1 / h2 stored per step
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          const int kb = st >> 2, q = st & 3;
+          if (st + 1 < NS) {
+            const int kb1 = (st + 1) >> 2, q1 = (st + 1) & 3;
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) vn[mt] = *(const f32x4*)&slotB[L.oW2 + (32 * mt + j) * S2 + 32 * kb1 + 8 * q1 + 4 * hi];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) t2[mt] = MJX_MFMA(vc[mt][t], h1[kb][4 * q + t], t2[mt]);
+#pragma unroll
+          for (int e = 0; e < R1; ++e) {
+            const int idx = st * R1 + e, mt = idx >> 4, r = idx & 15;
+            LDS_ST(&bufB[(32 * mt + unit_of(r, hi)) * ST + j], h1[mt][r]);
+          }
+#pragma unroll
+          for (int e = 0; e < R2; ++e) {
+            const int idx = st * R2 + e, mt = idx >> 4, r = idx & 15;
+            LDS_ST(&bufA[(32 * mt + unit_of(r, hi)) * ST + j], h2[mt][r]);
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT2; ++mt) vc[mt] = vn[mt];
+        }
+        // pipeline: fragment prefetch, then the MFMAs with the LDS stores between them -- and no vector-ALU instruction
+        __builtin_amdgcn_sched_group_barrier(0x100, MT2, 0);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, MT2, 0);
+#pragma unroll
+          for (int i = 0; i < 4 * MT2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      MJX_STAMP(2);
+      // (the first operands of the next MFMA phases are requested before each burst, so that they land during it)
+      f32x4 wc3[MT2];
+#pragma unroll
+      for (int mt = 0; mt < MT2; ++mt) wc3[mt] = *(const f32x4*)&slotA[L.oW2 + (32 * mt + j) * S2 + 4 * hi];
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- VA: t1 *= 1 - h1^2 ; f2 = 1 - h2^2   (one burst; R1 retired long ago, R2 does not touch t1)
+#pragma unroll
+      for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t1[mt][r] *= fmaf(-h1[mt][r], h1[mt][r], 1.0f);
+#pragma unroll
+      for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) f2s[mt][r] = fmaf(-h2[mt][r], h2[mt][r], 1.0f);
+      __builtin_amdgcn_sched_barrier(0);
+      MJX_STAMP(3);
+      // ---------------- R3: t2 += W2 t1
+      {
+        f32x4 wc[MT2], wn[MT2];
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) wc[mt] = wc3[mt];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          const int kb = st >> 2, q = st & 3;
+          if (st + 1 < NS) {
+            const int kb1 = (st + 1) >> 2, q1 = (st + 1) & 3;
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) wn[mt] = *(const f32x4*)&slotA[L.oW2 + (32 * mt + j) * S2 + 32 * kb1 + 8 * q1 + 4 * hi];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) t2[mt] = MJX_MFMA(wc[mt][t], t1[kb][4 * q + t], t2[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MT2; ++mt) wc[mt] = wn[mt];
+        }
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, MT2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT2, 0);
+        }
+      }
+      // (output-layer fragments of both weight sets: requested under R3's last MFMAs)
+      f32x4 wa[MP / 4], wb[MP / 4];
+      {
+        const int b = (lane >> 2) & 7;
+        const int woff = L.oW3 + (lane & 3) * S3 + 32 * ((b >> 2) % MT2) + 8 * (b & 3) + 4 * hi;
+#pragma unroll
+        for (int gp = 0; gp < MP / 4; ++gp) { wa[gp] = *(const f32x4*)(slotB + woff + 4 * gp * S3); wb[gp] = *(const f32x4*)(slotA + woff + 4 * gp * S3); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      MJX_STAMP(4);
+      // ---------------- R4: output layer on v_mfma_f32_4x4x1_16b_f32 (operands through the A-broadcast, see out_small below).
+      // V3 h2 does not depend on t2: its instructions keep the matrix pipe busy while R3 drains; then the t2 *= f2 burst.
+      constexpr int CH = (NGRP >= 4) ? 1 : 2;                   // independent accumulator chains per action group and product
+      f32x4 og[NGRP];
+      float w6[RA][MT2];
+      {
+        f32x4 oa[NGRP][CH], ob[NGRP][CH];
+#pragma unroll
+        for (int gp = 0; gp < NGRP; ++gp)
+#pragma unroll
+          for (int c = 0; c < CH; ++c) { oa[gp][c] = (f32x4)(0.f); ob[gp][c] = (f32x4)(0.f); }
+        static_for<MT2 * 4>([&](auto st) {
+          constexpr int mt = decltype(st)::value >> 2, q = decltype(st)::value & 3, c = decltype(st)::value % CH;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int gp = 0; gp < NGRP; ++gp)
+              oa[gp][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[gp][t], h2[mt][4 * q + t], oa[gp][c], 3, mt * 4 + q, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t2[mt][r] *= f2s[mt][r];
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<MT2 * 4>([&](auto st) {
+          constexpr int mt = decltype(st)::value >> 2, q = decltype(st)::value & 3, c = decltype(st)::value % CH;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int gp = 0; gp < NGRP; ++gp)
+              ob[gp][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[gp][t], t2[mt][4 * q + t], ob[gp][c], 3, mt * 4 + q, 0);
+        });
+        // (R6's weight operands: requested before the epilogue burst)
+#pragma unroll
+        for (int sidx = 0; sidx < RA; ++sidx)
+#pragma unroll
+          for (int mt = 0; mt < MT2; ++mt) w6[sidx][mt] = LDS_LD(&slotA[L.oW3 + unit_of(sidx, hi) * S3 + 32 * mt + j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gp = 0; gp < NGRP; ++gp) {
+          og[gp] = oa[gp][0] + ob[gp][0];
+          if (CH == 2) og[gp] += oa[gp][CH - 1] + ob[gp][CH - 1];
+        }
+      }
+      MJX_STAMP(5);
+      // ---------------- VC: d3 = (md + c3) * out_scale^2 Dk / N for the actions this lane half owns (0 past the batch end)
+      float d3r[RA];
+      {
+        const float vmask = valid ? 1.0f : 0.0f;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+          const int g0 = 2 * (r >> 2), c = r & 3;
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(og[g0][c]), __float_as_uint(og[g0 + 1][c]), false, false);
+          const float mdr = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+          d3r[r] = (mdr + kc3r[r]) * (kcsr[r] * vmask);
+        }
+#pragma unroll
+        for (int r = 0; r < RA; ++r) { LDS_ST(&d3T[unit_of(r, hi) * ST + j], d3r[r]); sb3r[r] += d3r[r]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      MJX_STAMP(6);
+      // ---------------- R6: delta2 (lane = sample) = W3^T d3 ; R7: gW3[a][k] += sum_s d3[s][a] h2[s][k] on 4x4x1 blocks (see the
+      // VPG branch below; two persistent accumulator sets = 4 chains) right behind it, filling R6's drain
+      f32x16 dl2s[MT2];
+#pragma unroll
+      for (int mt = 0; mt < MT2; ++mt) dl2s[mt] = (f32x16)(0.f);
+#pragma unroll
+      for (int sidx = 0; sidx < RA; ++sidx)
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) dl2s[mt] = MJX_MFMA(w6[sidx][mt], d3r[sidx], dl2s[mt]);
+      float wc8[4][MT1];
+      {
+        const int blk = lane >> 2, g3 = blk / QPI3, uq3 = blk % QPI3;
+        const float* arow = &d3T[(4 * g3 + (lane & 3)) * ST];
+        const float* brow = &bufA[(4 * uq3 + (lane & 3)) * ST];
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+          const f32x4 av = *(const f32x4*)(arow + 4 * s4);
+          f32x4 bv[NT3];
+#pragma unroll
+          for (int nt = 0; nt < NT3; ++nt) bv[nt] = *(const f32x4*)(brow + UPI3 * nt * ST + 4 * s4);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT3; ++nt) {
+              if (s4 & 1) gW3b[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[t], bv[nt][t], gW3b[nt], 0, 0, 0);
+              else gW3[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[t], bv[nt][t], gW3[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < MT1; ++nt) wc8[t][nt] = LDS_LD(&slotA[L.oW2 + (4 * hi + t) * S2 + 32 * nt + j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      MJX_STAMP(7);
+      // ---------------- VD: delta2 *= f2
+#pragma unroll
+      for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dl2s[mt][r] *= f2s[mt][r];
+      // ---------------- R8: delta1 (lane = unit) = W2^T delta2 ; delta2^T -> bufA -> lane = unit registers in its shadow
+      // (LDS executes one wave's operations in order and the compiler keeps may-alias accesses in program order)
+      f32x16 dl1u[MT1];
+      float dl2u[MT2][16];
+#pragma unroll
+      for (int nt = 0; nt < MT1; ++nt) dl1u[nt] = (f32x16)(0.f);
+      {
+        constexpr int NG = MT2 * 4;                 // groups of 4 k-steps over the h2 units
+        constexpr int NGH = NG / 2;
+        float wc[4][MT1], wn[4][MT1];
+        __builtin_amdgcn_sched_barrier(0);
+        // h1 / h2 / the operand image are dead since R4: request the next tile's copies under these MFMAs, two weight-gradient
+        // phases ahead of their first use (branch-free -- the last tile of a wave fetches its own lines again -- so that the
+        // loads stay inside this scheduling region)
+        load_h(ptile((tile + tstride < ntiles) ? tile + tstride : tile));
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < MT1; ++nt) wc[t][nt] = wc8[t][nt];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int kb = g >> 2, q = g & 3;
+          if (g + 1 < NG) {
+            const int kb1 = (g + 1) >> 2, q1 = (g + 1) & 3;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int nt = 0; nt < MT1; ++nt) wn[t][nt] = LDS_LD(&slotA[L.oW2 + (32 * kb1 + 8 * q1 + 4 * hi + t) * S2 + 32 * nt + j]);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < MT1; ++nt) dl1u[nt] = MJX_MFMA(dl2s[kb][4 * q + t], wc[t][nt], dl1u[nt]);
+          if (g < NGH) {
+            // this group's share of the transposed copy: 16 MT2 / NGH registers of delta2
+            constexpr int RS = 16 * MT2 / NGH;
+#pragma unroll
+            for (int e = 0; e < RS; ++e) {
+              const int idx = g * RS + e, mt = idx >> 4, r = idx & 15;
+              LDS_ST(&bufA[(32 * mt + unit_of(r, hi)) * ST + j], dl2s[mt][r]);
+            }
+          } else {
+            // ... and of the read-back: delta2[sample unit_of(4 qq + t, hi)][unit 32 nt + j], one ds_read_b128 per (nt, qq)
+            constexpr int RQ = (4 * MT2 + NGH - 1) / NGH;
+#pragma unroll
+            for (int e = 0; e < RQ; ++e) {
+              const int idx = (g - NGH) * RQ + e;
+              if (idx < 4 * MT2) {
+                const int nt = idx >> 2, qq = idx & 3;
+                const f32x4 v = *(const f32x4*)&bufA[(32 * nt + j) * ST + 8 * qq + 4 * hi];
+                dl2u[nt][4 * qq] = v.x; dl2u[nt][4 * qq + 1] = v.y; dl2u[nt][4 * qq + 2] = v.z; dl2u[nt][4 * qq + 3] = v.w;
+              }
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < MT1; ++nt) wc[t][nt] = wn[t][nt];
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT1, 0);      // (the ds_read_b32 pair up as ds_read2_b32)
+#pragma unroll
+          for (int i = 0; i < 4 * MT1; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (g < NGH) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            else if (i < (4 * MT2 + NGH - 1) / NGH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+      }
+      // ---------------- R9: gW2[u2][u1] += sum_s delta2[s][u2] h1[s][u1]   (B operand: h1^T from bufB, kept for the burst below)
+      f32x4 bcs[4][MT1];
+#pragma unroll
+      for (int nt = 0; nt < MT1; ++nt) bcs[0][nt] = *(const f32x4*)&bufB[(32 * nt + j) * ST + 4 * hi];
+      __builtin_amdgcn_sched_barrier(0);
+      MJX_STAMP(8);
+      {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q + 1 < 4) {
+#pragma unroll
+            for (int nt = 0; nt < MT1; ++nt) bcs[q + 1][nt] = *(const f32x4*)&bufB[(32 * nt + j) * ST + 8 * (q + 1) + 4 * hi];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < MT1; ++nt) gW2[mt][nt] = MJX_MFMA(dl2u[mt][4 * q + t], bcs[q][nt][t], gW2[mt][nt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      MJX_STAMP(9);
+      // ---------------- VE: delta1 *= 1 - h1^2 (h1^T values of R9's fetches) ; grad b2[32 nt + j] += sum over the tile's samples
+      // (16 registers x 2 lane halves; the halves are added after the tile loop)
+#pragma unroll
+      for (int nt = 0; nt < MT1; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dl1u[nt][4 * q + t] *= fmaf(-bcs[q][nt][t], bcs[q][nt][t], 1.0f);
+#pragma unroll
+      for (int nt = 0; nt < MT2; ++nt) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += dl2u[nt][r];
+        sb2[nt] += sacc;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- R10: gW1a[u1][f] += sum_s delta1[s][u1] x~a[s][f]   (column n = bias gradient)
+      if constexpr (NPC != 0) {
+        const float* xrow = &xT[(lane & 3) * ST + 4 * hi];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 bx[NFQ];
+#pragma unroll
+          for (int fq = 0; fq < NFQ; ++fq) bx[fq] = *(const f32x4*)(xrow + 4 * fq * ST + 8 * q);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int fq = 0; fq < NFQ; ++fq)
+#pragma unroll
+              for (int mt = 0; mt < MT1; ++mt)
+                gW1q[mt][fq] = __builtin_amdgcn_mfma_f32_4x4x1f32(dl1u[mt][4 * q + t], bx[fq][t], gW1q[mt][fq], 0, 0, 0);
+        }
+      } else {
+        f32x4 bc[NT1], bn[NT1];
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) { int f = 32 * nt + j; bc[nt] = *(const f32x4*)&xT[(f < NP ? f : 0) * ST + 4 * hi]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q + 1 < 4) {
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt) { int f = 32 * nt + j; bn[nt] = *(const f32x4*)&xT[(f < NP ? f : 0) * ST + 8 * (q + 1) + 4 * hi]; }
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt) {
+            f32x4 b4 = (32 * nt + j < NP) ? bc[nt] : (f32x4)(0.f);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int mt = 0; mt < MT1; ++mt) gW1[mt][nt] = MJX_MFMA(dl1u[mt][4 * q + t], b4[t], gW1[mt][nt]);
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt) bc[nt] = bn[nt];
+        }
+      }
+      MJX_STAMP(13);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     // ---- 0. stage the tile's observations: xs is the raw memory image (sample-major, row stride n),
     // written with the same float4 granules it was fetched in.  Rows past the batch end are masked when read.
     // this tile's actions / advantage: requested now, consumed by the likelihood head two layers later
@@ -1071,6 +1523,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
     }
     MJX_STAMP(13);
     wave_sync();                                  // everything read before the next tile's staging
+    }   // !XCACHED
   }
   };
   if constexpr (MODE == MODE_EVAL && NPC != 0) {
@@ -1135,7 +1588,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int blk = lane >> 2, a = 4 * (blk / QPI3) + r, u = 4 * (blk % QPI3) + (lane & 3) + UPI3 * nt;
-        if (a < m) mine[fo.W3 + a * H2 + u] = gW3[nt][r];
+        if (a < m) mine[fo.W3 + a * H2 + u] = XCACHED ? gW3[nt][r] + gW3b[XCACHED ? nt : 0][r] : gW3[nt][r];
       }
     float sb2f[MT2];
 #pragma unroll
@@ -1165,6 +1618,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
     }
   }
   MJX_GSTAMP(20);
+  if (A.clk && blockIdx.x == 0 && threadIdx.x == 0) { A.clk[2] = (long long)__builtin_readcyclecounter(); A.clk[3] = (long long)__builtin_amdgcn_s_memrealtime(); }
   if (MODE != MODE_FVP) {
     // scalar partials: wave reduce (fp64) -> LDS -> one thread
 #pragma unroll

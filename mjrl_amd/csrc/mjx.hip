@@ -79,6 +79,8 @@ struct mjx_ctx {
   float *cg_x = nullptr, *cg_r = nullptr, *cg_p = nullptr, *cg_z = nullptr, *cg_Ap = nullptr;
   double* cg_scal = nullptr;       // 8 doubles
   float* dbg = nullptr;
+  long long* clk = nullptr;        // launch clock stamps (mjx_set_clock_buffer)
+  unsigned fvp_seq = 0;            // products since the cache was filled / the last solve began: alternate sweep direction
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;   // pairs
   size_t prof_used = 0;
@@ -98,7 +100,7 @@ using namespace mjx;
 template <int H1, int H2, int NT1, int MP, bool DBG = false, int NPC = 0>
 int launch_fused(mjx_ctx* c, int mode, const FusedArgs& a, hipStream_t st) {
   const bool ev2 = (mode == MODE_EVAL) && MP <= 8;   // MODE_EVAL (always the non-debug instance): small layout, two workgroups per CU (fused_policy.h)
-  FusedLayout<H1, H2, NT1, MP> L(c->n, ev2);
+  FusedLayout<H1, H2, NT1, MP> L(NPC ? NPC - 1 : c->n, ev2);       // (the kernel's rule: fused_policy.h)
   size_t bytes = L.bytes();
   void (*k)(FusedArgs) = nullptr;
   const bool cached = (mode == MODE_FVP) && a.hcache != nullptr && !DBG;
@@ -182,6 +184,8 @@ FusedArgs make_args(mjx_ctx* c, const float* thetaB) {
   a.old_is_new = c->old_is_new;
   a.partials = c->partials; a.spartials = c->spartials;
   a.dbg = c->dbg;
+  a.clk = c->clk;
+  a.reverse = 0;
   a.hcache = nullptr; a.ocache = nullptr; a.snap = nullptr; a.snap_out = nullptr;
   a.n = c->n; a.m = c->m;
   return a;
@@ -554,6 +558,12 @@ int mjx_set_debug_buffer(mjx_ctx* c, float* dbg, int64_t floats) {
   return MJX_OK;
 }
 
+int mjx_set_clock_buffer(mjx_ctx* c, int64_t* clk) {
+  if (!c) return fail(MJX_ERR_ARG, "null context");
+  c->clk = (long long*)clk;
+  return MJX_OK;
+}
+
 int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
   if (int rc = check_bound(c, true)) return rc;
   if (!grad_out || !scal_out) return fail(MJX_ERR_ARG, "null output");
@@ -571,6 +581,7 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
   FusedArgs a = make_args(c, c->theta_old);
   c->hcache_valid = false;
   c->ximg_ok = false;
+  c->fvp_seq = 0;
   if (c->use_hcache && c->old_is_new && c->hidden.size() == 2) {
     // keep h1 / h2 of every sample for the Fisher-vector products of this update (theta is fixed during CG)
     // per 32-sample tile: h1, h2 (sample-lane accumulator image) + the normalised observations (layer-1 operand image)
@@ -634,6 +645,11 @@ int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
   }
   FusedArgs a = make_args(c, v);
   if (c->hcache_valid && c->N_local <= c->hcache_rows) a.hcache = c->hcache;
+  // alternate sweep direction: K1 filled the cache front to back, so the first product of a solve starts at the back, the
+  // next at the front, ... -- the lines the previous sweep touched last are the ones most likely still held by the
+  // memory-side cache (the 592 MB image does not fit; a one-directional walk would evict every line before its reuse)
+  static const bool sweep_on = [] { const char* e = getenv("MJX_FVP_SWEEP"); return !(e && e[0] == '0'); }();
+  a.reverse = (a.hcache && sweep_on) ? (int)((c->fvp_seq++ & 1u) ^ 1u) : 0;
   if (int rc = dispatch_fused(c, MODE_FVP, a, st)) return rc;
   if (prof) { HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], st)); c->prof_used += 2; }
   if ((c->d & 3) == 0)
@@ -670,6 +686,7 @@ int mjx_eval_surr_kl(mjx_ctx* c, double* scal_out, void* stream) {
 
 int mjx_cg_init(mjx_ctx* c, const float* b, void* stream) {
   if (!c || !b) return fail(MJX_ERR_ARG, "bad arguments");
+  c->fvp_seq = 0;                              // every solve walks the cache in the same sequence of directions (reproducible bits)
   hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1024), 0, (hipStream_t)stream, b, c->cg_x, c->cg_r, c->cg_p, c->cg_scal, (int)c->d);
   HIPCHK(hipGetLastError());
   return MJX_OK;

@@ -1,0 +1,42 @@
+"""Average launch time of the cached Fisher-vector-product kernel on bench.py's 1M-timestep batch (HIP events around blocks of
+back-to-back products): the quick A/B probe for kernel variants -- MJX_LIB=<build> python tools/fvp_time.py [reps]."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from mjrl_amd import _lib
+_lib.LIB_PATH = os.environ.get("MJX_LIB", _lib.LIB_PATH)
+from mjrl_amd.engine import UpdateEngine
+import bench
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+theta0 = bench.initial_params()
+obs, act, adv = bench.synth_shard(0, 1)
+adv = (adv - adv.mean()) / (adv.std() + 1e-6)
+eng = UpdateEngine(bench.N_OBS, bench.N_ACT, bench.HIDDEN)
+ident = np.concatenate([np.zeros(bench.N_OBS), np.ones(bench.N_OBS), np.zeros(bench.N_ACT), np.ones(bench.N_ACT)]).astype(np.float32)
+eng.set_policy(theta0, theta0, ident, ident)
+eng.set_batch(obs, act, adv)
+g = eng.surr_vpg()[0].clone()
+for _ in range(5):
+    eng.fvp(g)
+torch.cuda.synchronize()
+best = []
+for _ in range(reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        eng.backend.fvp(g, eng.Ap)
+    e1.record(); torch.cuda.synchronize()
+    best.append(e0.elapsed_time(e1) / 20)
+clk = torch.zeros(4, dtype=torch.int64, device=eng.device)
+import ctypes
+_lib.check(eng.lib.mjx_set_clock_buffer(eng.ctx, ctypes.c_void_p(clk.data_ptr())))
+cyc, ghz = [], []
+for _ in range(10):
+    eng.backend.fvp(g, eng.Ap)
+    torch.cuda.synchronize()
+    c = clk.cpu().numpy()
+    cyc.append(int(c[2] - c[0])); ghz.append((c[2] - c[0]) / ((c[3] - c[1]) * 10.0))
+_lib.check(eng.lib.mjx_set_clock_buffer(eng.ctx, None))
+print("%s  fvp+reduce ms: min %.4f median %.4f | workgroup 0: %d cycles, %.3f GHz" % (os.environ.get("MJX_LIB", "product"), min(best), sorted(best)[len(best) // 2],
+                                                                             int(np.median(cyc)), float(np.median(ghz))))

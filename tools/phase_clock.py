@@ -23,11 +23,18 @@ for _ in range(3):
     eng.fvp(v)
 torch.cuda.synchronize()
 st = dbg.cpu().numpy().view(np.int64)[:14]
-names = ["0 stage x", "1 L1 fwd+tan MFMAs (40)", "2 (tanh z1, sunk)", "3 tanh z1 + bias init + pass A (128)", "4 pass B (64) + tanh z2 + transposes", "5 -", "6 out_small (128 x 4x4)",
-         "7 out_finish + d3", "8 delta2 (16)", "9 gW3 (32) + factor", "10 delta1u (64)", "11 gW2 (64) + factor", "12 gW1 (32)"]
-st[5] = st[4]  # stamp 5 no longer exists
+if os.environ.get('CACHED', '1') == '1':
+    # the cached instance's own schedule (fused_policy.h, "cached-forward Fisher-vector product")
+    names = ["R1 t1 = V1a x~ (20 MFMA = 1280)", "R2 t2 = c2 + V2 h1 (64 = 4096)", "R3 t2 += W2 t1 (64 = 4096)", "R4 output layer (128 x 4x4x1 = 1024)",
+             "R5 d3 epilogue", "R6 delta2 (8 = 512)", "R7 gW3 (64 x 4x4x1 = 512)", "R8 delta1 + delta2^T trip (64 = 4096)", "R9 gW2 (64 = 4096)",
+             "R10 gW1 (160 x 4x4x1 = 1280)"]
+    st = np.concatenate([st[:10], st[13:14]])
+else:
+    names = ["0 stage x", "1 L1 fwd+tan MFMAs (40)", "2 (tanh z1, sunk)", "3 tanh z1 + bias init + pass A (128)", "4 pass B (64) + tanh z2 + transposes", "5 -", "6 out_small (128 x 4x4)",
+             "7 out_finish + d3", "8 delta2 (16)", "9 gW3 (32) + factor", "10 delta1u (64)", "11 gW2 (64) + factor", "12 gW1 (32)"]
+    st[5] = st[4]  # stamp 5 no longer exists
 d = np.diff(st)
-tot = st[13] - st[0]
+tot = st[-1] - st[0]
 for i, x in enumerate(d):
     print("%-28s %7d cycles  %5.1f%%" % (names[i] if i < len(names) else i, x, 100.0 * x / tot))
 print("tile total", tot)
