@@ -68,6 +68,17 @@ struct FusedArgs {
 #define MJX_GSTAMP(k) do {} while (0)
 #endif
 #define MJX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// Accumulators that live across ALL tiles of a wave (the weight gradients of the cached Fisher-vector product) stay in the
+// accumulation registers: with -amdgpu-mfma-vgpr-form the builtins put every MFMA result in an architectural VGPR and hipcc then
+// shuttles the persistent ones to AGPRs and back around each use (120 v_accvgpr moves per tile, 6 cycles each: probe_fill.hip).
+// Written as inline assembly with an "a" constraint they are AGPR operands of the instruction itself.  The compiler does not see an
+// MFMA in them, so it inserts none of the wait states MFMA hazards need: (i) their results are only read after the tile loop;
+// (ii) `volatile` keeps them in program order, which walks the accumulators round-robin -- measured (r03): with the statements
+// free to move, hipcc grouped the 4x4x1 ones by accumulator, back to back with one s_nop, and the sums came out wrong (a
+// dependent 4x4x1 needs more wait states than that; the builtin form gets them from the hazard recogniser).  Used only where
+// >= 4 accumulators alternate (gW2, the 4x4x1 form of gW1) or the chain is made of 64-cycle 32x32x2 instructions.
+#define MJX_MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define MJX_MFMA4_ACC(acc, a, b) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 // 4- and 8-byte LDS accesses of the cached Fisher-vector product.  (Measured, r03: making them volatile LDS-space accesses keeps
 // hipcc from pairing them into ds_read2 / ds_write2 -- whose 8-bit offset fields cost a vector add per pair to re-base the
 // address, 48 per tile -- and saves 2.5 % of the kernel's cycles, but the chip gives the same 2.5 % back in clock: no
@@ -112,6 +123,35 @@ __device__ __forceinline__ float half_select(uint32_t mask, float a, float b) {
 __device__ __forceinline__ float half_sum(float p) {
   auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
   return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+
+// packed fp32 element-wise helpers on 16-register tiles (register pairs -> v_pk_fma_f32 / v_pk_mul_f32)
+__device__ __forceinline__ f32x16 pk_1mh2(const f32x16& h) {                      // 1 - h^2
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 hh = {h[r], h[r + 1]};
+    const f32x2 ff = __builtin_elementwise_fma(-hh, hh, (f32x2)(1.0f));
+    o[r] = ff.x; o[r + 1] = ff.y;
+  }
+  return o;
+}
+__device__ __forceinline__ void pk_mul(f32x16& t, const f32x16& f) {              // t *= f
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    f32x2 tt = {t[r], t[r + 1]};
+    tt *= f32x2{f[r], f[r + 1]};
+    t[r] = tt.x; t[r + 1] = tt.y;
+  }
+}
+__device__ __forceinline__ void pk_mul_1mh2(f32x16& t, const f32x16& h) {         // t *= 1 - h^2
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 hh = {h[r], h[r + 1]};
+    f32x2 tt = {t[r], t[r + 1]};
+    tt *= __builtin_elementwise_fma(-hh, hh, (f32x2)(1.0f));
+    t[r] = tt.x; t[r + 1] = tt.y;
+  }
 }
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
@@ -500,7 +540,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       f32x16 (&h1)[MT1] = hn1;
       f32x16 (&h2)[MT2] = hn2;
       f32x16 t1[MT1], t2[MT2];
-      float f2s[MT2][16];
+      f32x16 f2s[MT2];
       // ---------------- R1
 #pragma unroll
       for (int mt = 0; mt < MT1; ++mt) t1[mt] = (f32x16)(0.f);
@@ -594,14 +634,11 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       for (int mt = 0; mt < MT2; ++mt) wc3[mt] = *(const f32x4*)&slotA[L.oW2 + (32 * mt + j) * S2 + 4 * hi];
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- VA: t1 *= 1 - h1^2 ; f2 = 1 - h2^2   (one burst; R1 retired long ago, R2 does not touch t1)
+      // (packed: v_pk_fma_f32 / v_pk_mul_f32 handle two registers per instruction at the price of one in a burst -- probe_fill.hip)
 #pragma unroll
-      for (int mt = 0; mt < MT1; ++mt)
+      for (int mt = 0; mt < MT1; ++mt) pk_mul_1mh2(t1[mt], h1[mt]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t1[mt][r] *= fmaf(-h1[mt][r], h1[mt][r], 1.0f);
-#pragma unroll
-      for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) f2s[mt][r] = fmaf(-h2[mt][r], h2[mt][r], 1.0f);
+      for (int mt = 0; mt < MT2; ++mt) f2s[mt] = pk_1mh2(h2[mt]);
       __builtin_amdgcn_sched_barrier(0);
       MJX_STAMP(3);
       // ---------------- R3: t2 += W2 t1
@@ -661,9 +698,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         });
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) t2[mt][r] *= f2s[mt][r];
+        for (int mt = 0; mt < MT2; ++mt) pk_mul(t2[mt], f2s[mt]);
         __builtin_amdgcn_sched_barrier(0);
         static_for<MT2 * 4>([&](auto st) {
           constexpr int mt = decltype(st)::value >> 2, q = decltype(st)::value & 3, c = decltype(st)::value % CH;
@@ -739,9 +774,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       MJX_STAMP(7);
       // ---------------- VD: delta2 *= f2
 #pragma unroll
-      for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dl2s[mt][r] *= f2s[mt][r];
+      for (int mt = 0; mt < MT2; ++mt) pk_mul(dl2s[mt], f2s[mt]);
       // ---------------- R8: delta1 (lane = unit) = W2^T delta2 ; delta2^T -> bufA -> lane = unit registers in its shadow
       // (LDS executes one wave's operations in order and the compiler keeps may-alias accesses in program order)
       f32x16 dl1u[MT1];
@@ -820,17 +853,17 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       MJX_STAMP(8);
       {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (q + 1 < 4) {
+        for (int q = 1; q < 4; ++q)
 #pragma unroll
-            for (int nt = 0; nt < MT1; ++nt) bcs[q + 1][nt] = *(const f32x4*)&bufB[(32 * nt + j) * ST + 8 * (q + 1) + 4 * hi];
-          }
+          for (int nt = 0; nt < MT1; ++nt) bcs[q][nt] = *(const f32x4*)&bufB[(32 * nt + j) * ST + 8 * q + 4 * hi];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
-              for (int nt = 0; nt < MT1; ++nt) gW2[mt][nt] = MJX_MFMA(dl2u[mt][4 * q + t], bcs[q][nt][t], gW2[mt][nt]);
+              for (int nt = 0; nt < MT1; ++nt) MJX_MFMA_ACC(gW2[mt][nt], dl2u[mt][4 * q + t], bcs[q][nt][t]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -842,7 +875,12 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) dl1u[nt][4 * q + t] *= fmaf(-bcs[q][nt][t], bcs[q][nt][t], 1.0f);
+          for (int t = 0; t < 4; t += 2) {
+            const f32x2 hh = {bcs[q][nt][t], bcs[q][nt][t + 1]};
+            f32x2 dd = {dl1u[nt][4 * q + t], dl1u[nt][4 * q + t + 1]};
+            dd *= __builtin_elementwise_fma(-hh, hh, (f32x2)(1.0f));
+            dl1u[nt][4 * q + t] = dd.x; dl1u[nt][4 * q + t + 1] = dd.y;
+          }
 #pragma unroll
       for (int nt = 0; nt < MT2; ++nt) {
         float sacc = 0.f;
@@ -865,7 +903,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
             for (int fq = 0; fq < NFQ; ++fq)
 #pragma unroll
               for (int mt = 0; mt < MT1; ++mt)
-                gW1q[mt][fq] = __builtin_amdgcn_mfma_f32_4x4x1f32(dl1u[mt][4 * q + t], bx[fq][t], gW1q[mt][fq], 0, 0, 0);
+                MJX_MFMA4_ACC(gW1q[mt][fq], dl1u[mt][4 * q + t], bx[fq][t]);
         }
       } else {
         f32x4 bc[NT1], bn[NT1];

@@ -65,6 +65,55 @@ __global__ __launch_bounds__(256, 1) void k_fill(float* out, long long* cyc, int
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// bursts: 8 MFMAs, then B vector-ALU instructions in a row (what the Fisher-vector-product kernel does since r03)
+template <int KIND, int B>
+__global__ __launch_bounds__(256, 1) void k_burst(float* out, long long* cyc, int iters) {
+  const int lane = threadIdx.x & 63;
+  f32x16 acc[2];
+  for (int a = 0; a < 2; ++a) acc[a] = (f32x16)(0.f);
+  float a0 = 1.0f + lane * 1e-3f, b0 = 0.5f;
+  float x[32];
+  for (int i = 0; i < 32; ++i) x[i] = 0.1f * i + lane;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 y[16];
+  for (int i = 0; i < 16; ++i) y[i] = f32x2{0.1f * i, 1.0f + lane};
+  long long t0 = 0, t1 = 0;
+  for (int it = 0; it < iters + 1; ++it) {
+    if (it == 1) { SB; t0 = __builtin_readcyclecounter(); SB; }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) { acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[m & 1], 0, 0, 0); SB; }
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        if (KIND == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[k & 31]) : "v"(a0), "v"(b0));
+        if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(y[k & 15]) : "v"(y[(k + 1) & 15]));
+        if (KIND == 2) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(y[k & 15]) : "v"(y[(k + 1) & 15]));
+        if (KIND == 3) asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_read_b32 %0, a0" : "+v"(x[k & 31]) :: "a0");
+        SB;
+      }
+    }
+  }
+  SB; t1 = __builtin_readcyclecounter(); SB;
+  float s = 0.f;
+  for (int a = 0; a < 2; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+  for (int i = 0; i < 32; ++i) s += x[i];
+  for (int i = 0; i < 16; ++i) s += y[i].x + y[i].y;
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int KIND, int B>
+void runb(const char* name, float* out, long long* cyc) {
+  const int iters = 100;
+  hipLaunchKernelGGL((k_burst<KIND, B>), dim3(256), dim3(256), 0, 0, out, cyc, iters);
+  CK(hipDeviceSynchronize());
+  long long c;
+  CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+  const double per_group = (double)c / (iters * 8.0);
+  printf("burst of %3d %-28s after 8 MFMAs: %8.1f cycles / group = 512 + %.1f  (%.2f per instruction)\n", B, name, per_group, per_group - 512.0, B ? (per_group - 512.0) / B : 0.0);
+}
+
 template <int KIND, int K, int NACC>
 void run(const char* name, float* out, long long* cyc) {
   const int iters = 200;
@@ -106,5 +155,13 @@ int main() {
   run<F_SALU, 2, 2>("s_add_u32", out, cyc);
   run<F_M4x4, 1, 2>("v_mfma_f32_4x4x1 (8 cycles each)", out, cyc);
   run<F_M4x4, 4, 2>("v_mfma_f32_4x4x1 (8 cycles each)", out, cyc);
+  runb<0, 0>("(none)", out, cyc);
+  runb<0, 8>("v_fma_f32", out, cyc);
+  runb<0, 32>("v_fma_f32", out, cyc);
+  runb<0, 64>("v_fma_f32", out, cyc);
+  runb<1, 16>("v_pk_fma_f32 (2 per lane)", out, cyc);
+  runb<1, 32>("v_pk_fma_f32 (2 per lane)", out, cyc);
+  runb<2, 32>("v_pk_mul_f32 (2 per lane)", out, cyc);
+  runb<3, 32>("accvgpr write + read pair", out, cyc);
   return 0;
 }
