@@ -58,7 +58,9 @@ int64_t mjx_num_params(const mjx_ctx* ctx);
  * layer-wise path does */
 int mjx_uses_fused_path(const mjx_ctx* ctx);
 
-/* ---- plain device-memory helpers (so a C / cgo / JNI caller needs no torch) -- */
+/* ---- plain device-memory helpers (so a C / cgo / JNI caller needs no torch; tests/c/c_caller.c) -- */
+/* hipMalloc of bytes + 16: an observation block allocated here can never fault on the up-to-12-byte tail read documented at
+ * mjx_bind_batch */
 int mjx_malloc(void** dev_ptr, int64_t bytes);
 int mjx_free(void* dev_ptr);
 int mjx_memcpy_h2d(void* dst_dev, const void* src_host, int64_t bytes, void* stream);

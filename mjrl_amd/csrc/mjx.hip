@@ -268,7 +268,11 @@ void mjx_destroy(mjx_ctx* c) {
 int64_t mjx_num_params(const mjx_ctx* c) { return c ? c->d : -1; }
 int mjx_uses_fused_path(const mjx_ctx* c) { return c ? (c->fused != 0) : 0; }
 
-int mjx_malloc(void** p, int64_t bytes) { if (!p || bytes < 0) return fail(MJX_ERR_ARG, "bad arguments"); HIPCHK(hipMalloc(p, (size_t)bytes)); return MJX_OK; }
+int mjx_malloc(void** p, int64_t bytes) {
+  if (!p || bytes < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  HIPCHK(hipMalloc(p, (size_t)bytes + 16));      // + one 16-byte granule: the tail reads of mjx_bind_batch's observation block stay inside
+  return MJX_OK;
+}
 int mjx_free(void* p) { HIPCHK(hipFree(p)); return MJX_OK; }
 int mjx_memcpy_h2d(void* dst, const void* src, int64_t bytes, void* stream) {
   HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream)); return MJX_OK; }
