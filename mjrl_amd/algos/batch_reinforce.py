@@ -96,20 +96,21 @@ class BatchREINFORCE:
         if self.seed is not None:
             self.seed = self.seed + N
 
-        process_samples.compute_returns(paths, gamma)
-        process_samples.compute_advantages(paths, self.baseline, gamma, gae_lambda)
-        eval_statistics = self.train_from_paths(paths)
-        eval_statistics.append(N)
-        if self.save_logs:
-            self.logger.log_kv('num_samples', int(np.sum([p["rewards"].shape[0] for p in paths])))
-            t0 = timer.time()
-            error_before, error_after = self.baseline.fit(paths, return_errors=True)
-            self.logger.log_kv('time_VF', timer.time() - t0)
-            self.logger.log_kv('VF_error_before', error_before)
-            self.logger.log_kv('VF_error_after', error_after)
-        else:
-            self.baseline.fit(paths)
-        from ..utils.ingest import drop_shared_batch
+        from ..utils.ingest import drop_shared_batch, trusted_iteration
+        with trusted_iteration():               # nothing but this package touches `paths` from here to the baseline fit
+            process_samples.compute_returns(paths, gamma)
+            process_samples.compute_advantages(paths, self.baseline, gamma, gae_lambda)
+            eval_statistics = self.train_from_paths(paths)
+            eval_statistics.append(N)
+            if self.save_logs:
+                self.logger.log_kv('num_samples', int(np.sum([p["rewards"].shape[0] for p in paths])))
+                t0 = timer.time()
+                error_before, error_after = self.baseline.fit(paths, return_errors=True)
+                self.logger.log_kv('time_VF', timer.time() - t0)
+                self.logger.log_kv('VF_error_before', error_before)
+                self.logger.log_kv('VF_error_after', error_after)
+            else:
+                self.baseline.fit(paths)
         drop_shared_batch()                     # the iteration's one upload served predict, update and fit; nothing may outlive it
         return eval_statistics
 

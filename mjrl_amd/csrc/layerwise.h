@@ -17,6 +17,8 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "fused_policy.h"
@@ -49,6 +51,42 @@ struct GemmArgs {
 #endif
 };
 
+// Per-DEVICE one-time state of the layer-wise launchers (function-static flags configured only the device that
+// happened to be current at first use -- a second context on another GPU of the same process launched > 64 KB-LDS kernels
+// without the attribute and read a foreign device's ticket counter).
+inline int lw_cur_device() { int dev = 0; (void)hipGetDevice(&dev); return dev; }
+inline void lw_set_dyn_lds(const void* kern, int bytes) {                   // hipFuncAttributeMaxDynamicSharedMemorySize, once per (device, kernel)
+  static std::mutex mu;
+  static std::vector<std::pair<int, const void*>> done;
+  const int dev = lw_cur_device();
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& e : done) if (e.first == dev && e.second == kern) return;
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.push_back({dev, kern});
+}
+inline int lw_ncu() {                                                        // compute units of the current device
+  static std::mutex mu;
+  static std::vector<std::pair<int, int>> cache;
+  const int dev = lw_cur_device();
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& e : cache) if (e.first == dev) return e.second;
+  int c = 256;
+  (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+  cache.push_back({dev, c});
+  return c;
+}
+inline int* lw_ticket_ring() {                                               // 256 ticket counters on the current device; nullptr if the allocation fails
+  static std::mutex mu;
+  static std::vector<std::pair<int, int*>> rings;
+  const int dev = lw_cur_device();
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& e : rings) if (e.first == dev) return e.second;
+  int* p = nullptr;
+  if (hipMalloc(&p, 256 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+  rings.push_back({dev, p});
+  return p;
+}
+
 #ifdef MJX_PHASE_CLOCK
 // timing build (-DMJX_PHASE_CLOCK): every workgroup of a k_gemm launch leaves its entry / first-MFMA / loop-end / exit
 // times (s_memrealtime, 100 MHz) and the CU it ran on; mjx_set_debug_buffer hands the buffer over and resets the slot
@@ -62,6 +100,7 @@ inline int& lw_clk_slot() { static int s = 0; return s; }
   __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define LW_STAMP(k) do {} while (0)
+
 #endif
 
 constexpr int GBN = 128, GBK = 32, GLD = GBK + 4;
@@ -945,11 +984,7 @@ struct LayerwiseWS {
   template <int BM, int BN, int NTH = gemm_threads<BN>()>
   static void launch_tile(const GemmArgs& g, int splits, hipStream_t st) {
     void (*const kern)(GemmArgs) = k_gemm<BM, BN, NTH>;
-    static const bool attr_set = [kern] {             // double-buffered operand tiles: dynamic LDS beyond the 64 KB default
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<BM, BN>());
-      return true;
-    }();
-    (void)attr_set;
+    lw_set_dyn_lds((const void*)kern, (int)gemm_lds_bytes<BM, BN>());      // double-buffered operand tiles: dynamic LDS beyond the 64 KB default
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
     constexpr size_t lds = gemm_lds_bytes<BM, BN>();
     static const bool fast_on = [] { const char* e = getenv("MJX_LW_FAST"); return !(e && e[0] == '0'); }();   // MJX_LW_FAST=0: A/B
@@ -1003,7 +1038,7 @@ struct LayerwiseWS {
     return on && ncols > 32 && ncols <= 128 && tile_mode() == 1;
   }
   static int pick_splits(int64_t N, int row_tiles, int ncols, int cap) {
-    static const int ncu = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c; }();
+    const int ncu = lw_ncu();
     static const bool on = [] { const char* e = getenv("MJX_LW_SPLITS"); return !(e && e[0] == '0'); }();
     if (cap < 4 || !on) return cap;
     int cb = 1;                                        // column blocks of the main launch (launch_gemm)
@@ -1026,6 +1061,7 @@ struct LayerwiseWS {
   // MJX_LW_PERSIST=0 keeps everything on the general kernel.
   static int persistent_lb(const GemmArgs& g, int splits) {        // -> 0 / 1: the B layout it can run with, -1: not eligible
     static const bool on = [] { const char* e = getenv("MJX_LW_PERSIST"); return !(e && e[0] == '0'); }();
+    if (on && lw_ticket_ring() == nullptr) return -1;               // no ticket counters on this device: the general kernel serves the product
     if (!on || splits != 1 || tile_mode() != 1 || g.M < 2 * GP_BM || g.N < GP_BN || (g.N % GP_BN) != 0) return -1;
     if ((g.M % GP_BM) != 0 && !g.rows_padded) return -1;
     if ((g.epi != EPI_TANGENT && g.epi != EPI_BACK && g.epi != EPI_BIAS_TANH) || (g.c_cs != 0 && g.c_cs != 1) || g.c_zs != 0) return -1;
@@ -1048,15 +1084,12 @@ struct LayerwiseWS {
   template <int LB, int EPI>
   static void launch_p(const GemmArgs& g, int row_tiles, hipStream_t st) {
     void (*const kern)(GemmArgs, int, int, int*) = k_gemm_p<LB, EPI, GemmArgs>;
-    static const bool attr_set = [kern] {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gp_lds_bytes<LB>());
-      return true;
-    }();
-    (void)attr_set;
-    static const int ncu = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c; }();
+    lw_set_dyn_lds((const void*)kern, (int)gp_lds_bytes<LB>());
+    const int ncu = lw_ncu();
     const int cbs = g.N / GP_BN, ntiles = row_tiles * cbs;
-    // (a ring of counters, one per launch in turn: launches on different streams do not share one)
-    static int* ring = [] { int* p = nullptr; (void)hipMalloc(&p, 256 * sizeof(int)); return p; }();
+    // (a ring of counters per device, one per launch in turn: launches on different streams do not share one;
+    //  persistent_lb() has checked that the ring exists)
+    int* ring = lw_ticket_ring();
     static std::atomic<unsigned> turn{0};
     int* ticket = ring + (turn.fetch_add(1) & 255u);
     (void)hipMemsetAsync(ticket, 0, sizeof(int), st);
@@ -1267,12 +1300,12 @@ struct LayerwiseWS {
       // the output layer's tangent goes straight to d3 = out_scale D mudot / N in the GEMM epilogue (no pass over N x m)
       if (last) { g.C = d3; g.ldc = m; g.epi = EPI_FVP_HEAD; g.osc = tr + 2 * n + m; g.ls = theta + oS; g.inv_N = (float)(1.0 / (double)Ng); }
       else { g.C = T[l]; g.ldc = sizes[l + 1]; g.epi = EPI_TANGENT; g.aux = H[l]; g.ld_aux = sizes[l + 1]; g.rows_padded = 1; }
-      if (last && head_fused()) break;
+      if (last && head_fused(theta, v)) break;
       launch_gemm(g, 1, st);
       tin = last ? nullptr : T[l];
     }
     hipLaunchKernelGGL(k_fvp_logstd, dim3(1), dim3(64), 0, st, theta + oS, v + oS, m, (float)((double)N / (double)Ng), out + oS);
-    if (head_fused()) {
+    if (head_fused(theta, v)) {
       if (int rc = fvp_head(theta, tr, v, N, Ng, out, st)) return rc;
       return backward(theta, N, out, st, nL() - 2, T[nL() - 2]);
     }
@@ -1280,16 +1313,18 @@ struct LayerwiseWS {
   }
 
   // the output layer of the product as one pass over the last hidden layer (lw_head.h); MJX_LW_HEAD=0 keeps the generic chain
-  bool head_fused() const {
+  // (the pass reads theta / v with 16-byte loads: a direction that is a view at an odd offset of a larger tensor takes the
+  //  generic chain instead of failing -- the fast path is an optimisation, not a precondition)
+  bool head_fused(const float* theta, const float* v) const {
     static const bool on = [] { const char* e = getenv("MJX_LW_HEAD"); return !(e && e[0] == '0'); }();
     if (!on || nL() < 2 || m > 32) return false;
+    if ((((uintptr_t)theta | (uintptr_t)v) & 15) != 0) return false;
     const int hl = sizes[nL() - 1];
     return (hl % 128) == 0 && hl <= 512 && (oW[nL() - 1] % 4) == 0;
   }
   int fvp_head(const float* theta, const float* tr, const float* v, int64_t N, int64_t Ng, float* out, hipStream_t st) {
     const int L = nL() - 1, hl = sizes[L];
-    if ((((uintptr_t)theta | (uintptr_t)v) & 15) != 0) return -3;
-    static const int ncu = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c; }();
+    const int ncu = lw_ncu();
     const int64_t ntile = (N + LH_R - 1) / LH_R;
     const int grid = (int)(ntile < ncu ? ntile : ncu);             // one workgroup per CU (the kernel takes the whole register file: lw_head.h)
     if (ensure_part((int64_t)grid * ((int64_t)m * hl + 32 + hl))) return 2;
@@ -1301,21 +1336,13 @@ struct LayerwiseWS {
     auto launch = [&](auto ch) {
       constexpr int CH = decltype(ch)::value;
       void (*const kern)(HeadArgs) = k_lw_head<CH>;
-      static const bool attr_set = [kern] {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw_head_lds_bytes());
-        return true;
-      }();
-      (void)attr_set;
+      lw_set_dyn_lds((const void*)kern, (int)lw_head_lds_bytes());
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lw_head_lds_bytes(), st, a);
     };
     auto launch8 = [&](auto ch) {             // 256 / 512 units: the eight-wave build (two waves per SIMD)
       constexpr int CH = decltype(ch)::value;
       void (*const kern)(HeadArgs) = k_lw_head8<CH>;
-      static const bool attr_set = [kern] {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw_head8_lds_bytes());
-        return true;
-      }();
-      (void)attr_set;
+      lw_set_dyn_lds((const void*)kern, (int)lw_head8_lds_bytes());
       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lw_head8_lds_bytes(), st, a);
     };
     static const bool eight = [] { const char* e = getenv("MJX_LW_HEAD8"); return !(e && e[0] == '0'); }();

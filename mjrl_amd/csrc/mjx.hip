@@ -628,7 +628,7 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
 int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
   if (int rc = check_bound(c, false)) return rc;
   if (!v || !out) return fail(MJX_ERR_ARG, "null vector");
-  if (((uintptr_t)v) & 15) return fail(MJX_ERR_ARG, "v must be 16-byte aligned");
+  if (c->fused && (((uintptr_t)v) & 15)) return fail(MJX_ERR_ARG, "v must be 16-byte aligned (fused path)");   // (the layer-wise path takes any 4-byte aligned v)
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->device));
   if (c->N_local == 0) { HIPCHK(hipMemsetAsync(out, 0, c->d * sizeof(float), st)); return MJX_OK; }

@@ -361,6 +361,18 @@ class UpdateEngine:
             except Exception as e:                   # pragma: no cover - depends on the host's RCCL
                 import warnings
                 warnings.warn("mjrl_amd: rank sums inside libmjx unavailable (%s); using torch.distributed collectives" % (e,))
+        if d is not None and d.get_world_size() > 1 and hasattr(self.backend, "comm_init"):
+            # every rank must take the same path -- RCCL inside libmjx and the one-call loops on some ranks, torch.distributed
+            # calls on others would issue different collectives and hang: all or none
+            flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.device if d.get_backend() == "nccl" else "cpu")
+            d.all_reduce(flag, op=d.ReduceOp.MIN)
+            if ok and int(flag.item()) == 0:
+                ok = False
+                try:
+                    check(self.lib.mjx_comm_destroy(self.ctx))
+                    check(self.lib.mjx_comm_set_callback(self.ctx, _lib.REDUCE_FN(0), None, 0))
+                except Exception:                    # pragma: no cover
+                    pass
         self._comm_state = ok
         return ok
 

@@ -11,6 +11,7 @@ group k.  No concatenated host array is ever built for observations / actions.
 A sampler that wants to overlap ingestion with sampling calls ``begin / add_paths / finish``
 as trajectories complete; ``stage`` does the three steps for a finished list.
 """
+import contextlib
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
@@ -315,10 +316,36 @@ def _probes(arrays):
     return [_probe(arrays[i]) for i in _probed(len(arrays))]
 
 
+# Who may have touched the per-path arrays between two uses of a batch?  Inside BatchREINFORCE.train_step nothing but this
+# package runs between compute_returns and baseline.fit -- identity of the objects plus a few probe values is enough there
+# (`trusted_iteration`).  A caller that drives compute_returns / compute_advantages / train_from_paths itself may edit arrays in
+# place in between (np.clip(..., out=p["rewards"]), per-path reweighting): outside the trusted scope a reuse must therefore be
+# EXACT -- user-owned arrays (rewards, observations, actions: uploaded by stage_shared) are compared element by
+# element with the page-locked host copy they were sent from, and blocks this package computed on the device (returns,
+# baseline values, advantages: publish) are handed to the paths as READ-ONLY views, so an in-place edit raises instead of
+# being silently ignored (assigning a new array to path[key] is always fine: the identity check sees it).
+_TRUST = threading.local()
+
+
+@contextlib.contextmanager
+def trusted_iteration():
+    """scope in which no foreign code can run between the uses of a batch (train_step)"""
+    _TRUST.depth = getattr(_TRUST, "depth", 0) + 1
+    try:
+        yield
+    finally:
+        _TRUST.depth -= 1
+
+
+def _trusted():
+    return getattr(_TRUST, "depth", 0) > 0
+
+
 def _same_batch(ent, paths, key):
     """is `paths` the very batch `ent` uploaded?  Identity of the list AND of every per-path array, against STRONG
     references the entry holds (an id() can be recycled once the objects are freed; a held object's cannot), plus a
-    few probe values of a sample of the arrays against in-place edits."""
+    few probe values of a sample of the arrays against in-place edits -- and, outside train_step, an exact comparison
+    with the staged host copy (see above)."""
     arrays = ent["arrays"]
     if ent["paths"] is not paths or len(arrays) != len(paths):
         return False
@@ -328,6 +355,17 @@ def _same_batch(ent, paths, key):
     for i, pr in zip(_probed(len(arrays)), ent["probes"]):
         if _probe(arrays[i]) != pr:
             return False
+    if not _trusted() and ent.get("f32") is not None and ent.get("stager") is not None:
+        st = ent["stager"]
+        slot = st._slots.get(key)
+        if slot is None:
+            return False
+        host, o = slot["pin_np"], 0
+        for a in arrays:
+            T = len(a)
+            if not np.array_equal(a if a.ndim == 2 else a.reshape(T, -1), host[o:o + T]):
+                return False
+            o += T
     return True
 
 

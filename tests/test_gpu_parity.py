@@ -757,6 +757,32 @@ def test_persistent_gemm_bitwise_equals_general_kernel(tmp_path, n, m, h1, h2, N
     assert rel(res["persistent"]["hv2"], res["general"]["hv2"]) < 1e-6      # (a product of the slightly different g)
 
 
+def test_layerwise_fvp_takes_a_direction_at_any_4_byte_offset():
+    """on the layer-wise path (256 / 512-wide policies) a direction that is a view at an odd offset of a larger
+    tensor is served by the generic output-layer chain instead of being refused by the one-pass output layer (which reads
+    it with 16-byte loads): same product as with an aligned copy of the same values."""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    n, m, hid, N = 40, 5, (256, 256), 1500
+    rng = np.random.RandomState(4)
+    th = synth.perturbed_params(synth.init_params(n, m, hid), scale=0.05)
+    ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    eng = UpdateEngine(n, m, hid)
+    assert not eng.fused
+    eng.set_policy(th, th, ident, ident)
+    eng.set_batch(rng.randn(N, n), rng.randn(N, m), rng.randn(N))
+    eng.surr_vpg()
+    big = torch.from_numpy(rng.randn(th.size + 8).astype(np.float32)).to(eng.device)
+    view = big[1:1 + th.size]
+    assert view.data_ptr() % 16 != 0
+    out_view = eng.fvp(view).clone()
+    out_copy = eng.fvp(view.clone()).clone()
+    assert rel(out_view.cpu().numpy(), out_copy.cpu().numpy()) < 1e-6
+    hvo = O.fvp(th.astype(np.float64), eng.obs.cpu().numpy().astype(np.float64), view.cpu().numpy().astype(np.float64), n, m, hid, O.Transforms(n, m))
+    assert rel(out_view.cpu().numpy(), hvo) < 1e-5
+    eng.close()
+
+
 def test_empty_shard_contributes_zero():
     """a rank that holds no trajectories (N_local == 0, N_global > 0) must produce zeros on both paths"""
     import torch

@@ -217,6 +217,43 @@ def test_path_stager_matches_concatenate_cpu():
         st.close()
 
 
+def test_in_place_edits_between_uses_are_never_silently_ignored():
+    """outside BatchREINFORCE.train_step an in-place edit of a per-path array between two uses of a batch
+    must not be missed because it falls between the probed positions: user-owned arrays (rewards, observations) are
+    compared exactly with the staged host copy, device-computed blocks (returns, advantages) come back as read-only
+    views.  Inside train_step (ingest.trusted_iteration) the cheap identity + probe check applies."""
+    import torch
+    from mjrl_amd.utils import ingest
+    ingest.drop_shared()
+    h = ingest.DeviceHandle(torch, torch.device("cpu"), None)
+    rng = np.random.RandomState(1)
+    paths = [dict(observations=rng.randn(40, 3), rewards=rng.randn(40)) for _ in range(50)]     # > 32 paths: probes are sampled
+    a = ingest.stage_shared(h, paths, ("rewards",))["rewards"]
+    # path 1 is not among the probed paths (0, 2, 4, ...), element 5 not among the probed positions
+    assert 1 not in list(ingest._probed(len(paths)))
+    paths[1]["rewards"][5] += 3.0
+    with ingest.trusted_iteration():
+        assert ingest.lookup(h, paths, "rewards") is a["raw"]                    # (the cheap rule does not see it)
+    assert ingest.lookup(h, paths, "rewards") is None                              # the exact rule does
+    b = ingest.stage_shared(h, paths, ("rewards",))["rewards"]
+    assert b["raw"][45].item() == paths[1]["rewards"][5]
+    assert ingest.lookup(h, paths, "rewards") is b["raw"]
+    # device-computed blocks: per-path views of one read-back, read-only
+    from mjrl_amd.utils import process_samples as ps
+    blk = torch.arange(2000, dtype=torch.float64)
+    off = np.arange(0, 2001, 40)
+    views = ps._hand_out(h, paths, "returns", blk, off)
+    ingest.publish(h, paths, "returns", blk, views)
+    assert ingest.lookup(h, paths, "returns") is blk
+    with pytest.raises(ValueError):
+        paths[3]["returns"][7] = 0.0
+    with pytest.raises(ValueError):
+        np.clip(paths[3]["returns"], -1, 1, out=paths[3]["returns"])
+    paths[3]["returns"] = np.clip(paths[3]["returns"], -1, 1)                      # the way to edit: a new array -> the block is stale
+    assert ingest.lookup(h, paths, "returns") is None
+    ingest.drop_shared()
+
+
 def test_staged_batch_registry_identity_rules():
     """utils/ingest: a batch is recognised by the IDENTITY of the path list and of every per-path array, held by
     strong references (ids of freed objects are recycled), plus probe values against in-place edits; device-computed
