@@ -105,6 +105,22 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return copysignf((1.0f - t) * r, x);
 }
 
+// the same on a 16-register tile, two registers per packed instruction where the operation has a packed form (the scale, the
+// 1 + t / 1 - t sums, the Newton step and the final product; v_exp_f32 / v_rcp_f32 / the sign transfer stay per register)
+__device__ __forceinline__ void fast_tanh16(f32x16& o, const f32x16& x) {
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 xx = {x[r], x[r + 1]};
+    const f32x2 s = xx * (f32x2)(2.885390081777927f);
+    const f32x2 t = {__builtin_amdgcn_exp2f(-fabsf(s.x)), __builtin_amdgcn_exp2f(-fabsf(s.y))};
+    const f32x2 d = t + (f32x2)(1.0f);
+    f32x2 rr = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    rr = rr * __builtin_elementwise_fma(-d, rr, (f32x2)(2.0f));
+    const f32x2 y = ((f32x2)(1.0f) - t) * rr;
+    o[r] = copysignf(y.x, xx.x); o[r + 1] = copysignf(y.y, xx.y);
+  }
+}
+
 // a / b with v_rcp_f32 + one Newton step (<= 2 ulp; exact for b == 1): the per-sample divisions of the likelihood
 // head and of the input normalisation cost 4 VALU ops instead of the ~12 of the IEEE sequence
 __device__ __forceinline__ float fast_div(float a, float b) {
@@ -1024,12 +1040,10 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       MJX_STAMP(2);
       if (XI && tile + tstride < ntiles) load_xi(tile + tstride);      // xc is dead: the next tile's image flies under the rest of this one
 #pragma unroll
-      for (int mt = 0; mt < MT1; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (FWD) h1[mt][r] = fast_tanh(z1[mt][r]);
-          if (TAN) t1[mt][r] *= fmaf(-h1[mt][r], h1[mt][r], 1.0f);
-        }
+      for (int mt = 0; mt < MT1; ++mt) {
+        if (FWD) fast_tanh16(h1[mt], z1[mt]);
+        if (TAN) pk_mul_1mh2(t1[mt], h1[mt]);
+      }
       if (MODE == MODE_VPG && writeT && A.hcache) {
         // keep h1 for the Fisher-vector products of this update (theta is fixed during CG); issued here so that the
         // stores drain under the layer-2 MFMAs
@@ -1136,9 +1150,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
           for (int r = 0; r < 16; ++r) t2[mt][r] *= fmaf(-h2[mt][r], h2[mt][r], 1.0f);
       } else {
 #pragma unroll
-        for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) h2[mt][r] = fast_tanh(z2[mt][r]);
+        for (int mt = 0; mt < MT2; ++mt) fast_tanh16(h2[mt], z2[mt]);
       }
     };
 
@@ -1497,7 +1509,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
             for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
-              for (int nt = 0; nt < MT1; ++nt) gW2[mt][nt] = MJX_MFMA(dl2u[mt][4 * q + t], bc[nt][t], gW2[mt][nt]);
+              for (int nt = 0; nt < MT1; ++nt) MJX_MFMA_ACC(gW2[mt][nt], dl2u[mt][4 * q + t], bc[nt][t]);
 #pragma unroll
           for (int nt = 0; nt < MT1; ++nt)
 #pragma unroll
@@ -1534,7 +1546,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
             for (int fq = 0; fq < NFQ; ++fq)
 #pragma unroll
               for (int mt = 0; mt < MT1; ++mt)
-                gW1q[mt][fq] = __builtin_amdgcn_mfma_f32_4x4x1f32(dl1u[mt][4 * q + t], bx[fq][t], gW1q[mt][fq], 0, 0, 0);
+                MJX_MFMA4_ACC(gW1q[mt][fq], dl1u[mt][4 * q + t], bx[fq][t]);
         }
       } else {
         f32x4 bc[NT1], bn[NT1];

@@ -28,6 +28,22 @@ for _ in range(reps):
         eng.backend.fvp(g, eng.Ap)
     e1.record(); torch.cuda.synchronize()
     best.append(e0.elapsed_time(e1) / 20)
+def timed(fn, n=10):
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / n)
+    return min(ts)
+k1 = timed(lambda: eng.backend.surr_vpg(eng.grad, eng.scal_vpg))
+eng.theta_new.add_(1e-3); eng.old_is_new = False; eng._bind_policy()        # K3 at theta_new != theta_old (as after a step)
+k3 = timed(lambda: eng.backend.eval_surr_kl(eng.scal))
+eng.theta_new.copy_(eng.theta_old); eng.old_is_new = True; eng._bind_policy()
+eng.surr_vpg()
+print("%s  K1 (+ reduce) %.4f ms   K3 (+ reduce) %.4f ms" % (os.environ.get("MJX_LIB", "product"), k1, k3))
 clk = torch.zeros(4, dtype=torch.int64, device=eng.device)
 import ctypes
 _lib.check(eng.lib.mjx_set_clock_buffer(eng.ctx, ctypes.c_void_p(clk.data_ptr())))
