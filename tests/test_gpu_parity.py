@@ -533,6 +533,47 @@ def test_mlp_baseline_vs_reference():
     np.testing.assert_array_equal(bl2.predict(paths[0]), bl.predict(paths[0]))
 
 
+def test_mlp_baseline_fit_quality_at_iteration_scale_vs_reference():
+    """The persistent minibatch-Adam trainer against the UNMODIFIED reference at iteration scale (300 000 timesteps, 2 epochs =
+    9 372 Adam steps on the same NumPy permutations; tests/golden/make_golden_mlpfit.py): after thousands of chaotic ReLU / Adam
+    steps the parameters of two correct fp32 implementations differ, the QUALITY of the fit does not -- the reference's own
+    error measures (mlp_baseline.py:83,94) and the mean squared error on held-out paths agree to a few per cent.  (Bit-level
+    parity of the same trainer on short chains: test_mlp_baseline_vs_reference.)"""
+    import torch
+    from mjrl_amd.baselines.mlp_baseline import MLPBaseline
+    from mjrl_amd.utils import process_samples
+    g = load("mlpfit_300k")
+    n, n_traj, T = int(g["n"]), int(g["n_traj"]), int(g["T"])
+
+    def make_paths(k, seed):
+        rng = np.random.RandomState(seed)
+        w = np.random.RandomState(1234).randn(n) / np.sqrt(n)
+        paths = []
+        for _ in range(k):
+            obs = np.cumsum(0.1 * rng.randn(T, n), axis=0) + rng.randn(n)
+            rew = np.tanh(obs @ w) - 0.05 * np.sum(obs[:, :3] ** 2, axis=1) + 0.1 * rng.randn(T)
+            paths.append(dict(observations=obs, rewards=rew, terminated=False))
+        process_samples.compute_returns(paths, 0.995)
+        return paths
+    paths, held = make_paths(n_traj, int(g["path_seed"])), make_paths(20, int(g["held_seed"]))
+    y = np.concatenate([p["returns"] for p in held])
+    assert abs(y.mean() - float(g["ret_mean"])) < 1e-9 * abs(float(g["ret_mean"]))          # the same data as the reference saw
+    spec = type("Spec", (), dict(observation_dim=n, action_dim=6, horizon=T))
+    torch.manual_seed(int(g["init_seed"])); np.random.seed(int(g["init_seed"]))
+    bl = MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3)
+    np.random.seed(int(g["fit_seed"]))
+    e0, e1 = bl.fit(paths, return_errors=True)
+    assert bl.adam_steps == int(g["steps"])
+    pred = np.concatenate([np.asarray(bl.predict(p)) for p in held])
+    mse = float(np.mean((pred - y) ** 2))
+    print("mlp fit at scale: err_before %.6f (ref %.6f)  err_after %.5f (ref %.5f)  held-out mse %.1f (ref %.1f)  pred mean %.2f (ref %.2f)"
+          % (e0, float(g["err_before"]), e1, float(g["err_after"]), mse, float(g["held_mse"]), pred.mean(), float(g["pred_mean"])))
+    assert abs(e0 - float(g["err_before"])) < 1e-5
+    assert abs(e1 - float(g["err_after"])) < 0.02 * float(g["err_after"])            # measured 0.34 %
+    assert abs(mse - float(g["held_mse"])) < 0.02 * float(g["held_mse"])            # measured 0.23 %
+    assert abs(pred.std() - float(g["pred_std"])) < 0.02 * float(g["pred_std"])
+
+
 def test_train_step_plumbing_numpy_env():
     """cfg1-style end-to-end train_step: NumPy point-mass stand-in env -> sampler -> returns/GAE ->
     NPG update -> baseline fit, all through the mjrl-shaped classes."""
