@@ -203,6 +203,27 @@ def secondary_measurements(eng, theta0, theta0_dev, ref=None):
                     "flop_per_fvp": flop, "kernels": "k_gemm_p (persistent tangent / delta products, csrc/lw_gemm_p.h) + k_gemm<128,256> / <128,128> weight gradients + k_lw_head (one-pass output layer, csrc/lw_head.h)",
                     "timed": "4 products, HIP events around the whole chain of one product",
                     "npg_update_ms": upd_ms, "cg_iters": cg_iters}
+        if hid[0] == 512:
+            # ... and the algorithm configs[4] names: one DAPG update (mjrl/algos/dapg.py:92-121) of the same shard with 25 x 200
+            # demonstration steps appended, through the one-call entry point mjx_dapg_update (K1 over [on-policy ; demos],
+            # gradient x N_all / N_on, Fisher / surrogate / KL on the on-policy prefix, 10 CG iterations, step, K3)
+            Nd = 5000
+            obs_all = torch.cat([e.obs, torch.randn((Nd, n), generator=gen, device="cuda")])
+            act_all = torch.cat([e.act, torch.randn((Nd, m), generator=gen, device="cuda")])
+            adv_on = e.adv.clone()
+            all_adv = 1e-2 * torch.cat([adv_on / (adv_on.std(unbiased=False) + 1e-8), 1e-2 * torch.ones(Nd, device="cuda")])
+            dapg_ms = []
+            for rep in range(2):
+                e.set_policy(th, th, ident, ident)
+                e.set_batch(obs_all, act_all, all_adv)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = e.dapg_update(cg_iters, 1e-4, 2.0 * 0.025, -3.0, N, adv_on, N_on_global=N)
+                torch.cuda.synchronize()
+                dapg_ms.append(1e3 * (time.perf_counter() - t0))
+            assert res is not None and np.isfinite(res[1]) and res[1] > 0
+            lw[name].update(dapg_update_ms=dapg_ms[-1], dapg_kl=res[1], dapg_demo_rows=Nd,
+                            dapg="one mjx_dapg_update call: [1M on-policy ; 5 000 demonstration] rows, kl_dist 0.025")
         e.close()
         del e
         torch.cuda.empty_cache()
