@@ -704,25 +704,27 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         for (int gp = 0; gp < NGRP; ++gp)
 #pragma unroll
           for (int c = 0; c < CH; ++c) { oa[gp][c] = (f32x4)(0.f); ob[gp][c] = (f32x4)(0.f); }
+        // (chains alternate by k-step: with NGRP = 2 an accumulator recurs every 4th instruction -- a dependent 4x4x1 two
+        //  instructions behind its producer still stalls)
         static_for<MT2 * 4>([&](auto st) {
-          constexpr int mt = decltype(st)::value >> 2, q = decltype(st)::value & 3, c = decltype(st)::value % CH;
+          constexpr int mt = decltype(st)::value >> 2, q = decltype(st)::value & 3;
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int gp = 0; gp < NGRP; ++gp)
-              oa[gp][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[gp][t], h2[mt][4 * q + t], oa[gp][c], 3, mt * 4 + q, 0);
+              oa[gp][t % CH] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[gp][t], h2[mt][4 * q + t], oa[gp][t % CH], 3, mt * 4 + q, 0);
         });
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) pk_mul(t2[mt], f2s[mt]);
         __builtin_amdgcn_sched_barrier(0);
         static_for<MT2 * 4>([&](auto st) {
-          constexpr int mt = decltype(st)::value >> 2, q = decltype(st)::value & 3, c = decltype(st)::value % CH;
+          constexpr int mt = decltype(st)::value >> 2, q = decltype(st)::value & 3;
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int gp = 0; gp < NGRP; ++gp)
-              ob[gp][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[gp][t], t2[mt][4 * q + t], ob[gp][c], 3, mt * 4 + q, 0);
+              ob[gp][t % CH] = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[gp][t], t2[mt][4 * q + t], ob[gp][t % CH], 3, mt * 4 + q, 0);
         });
         // (R6's weight operands: requested before the epilogue burst)
 #pragma unroll
@@ -768,17 +770,17 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         const float* arow = &d3T[(4 * g3 + (lane & 3)) * ST];
         const float* brow = &bufA[(4 * uq3 + (lane & 3)) * ST];
 #pragma unroll
-        for (int s4 = 0; s4 < 8; ++s4) {
-          const f32x4 av = *(const f32x4*)(arow + 4 * s4);
-          f32x4 bv[NT3];
+        for (int sp = 0; sp < 4; ++sp) {                 // sample quads 2 sp (-> gW3) and 2 sp + 1 (-> gW3b), instruction by instruction
+          const f32x4 ave = *(const f32x4*)(arow + 8 * sp), avo = *(const f32x4*)(arow + 8 * sp + 4);
+          f32x4 bve[NT3], bvo[NT3];
 #pragma unroll
-          for (int nt = 0; nt < NT3; ++nt) bv[nt] = *(const f32x4*)(brow + UPI3 * nt * ST + 4 * s4);
+          for (int nt = 0; nt < NT3; ++nt) { bve[nt] = *(const f32x4*)(brow + UPI3 * nt * ST + 8 * sp); bvo[nt] = *(const f32x4*)(brow + UPI3 * nt * ST + 8 * sp + 4); }
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT3; ++nt) {
-              if (s4 & 1) gW3b[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[t], bv[nt][t], gW3b[nt], 0, 0, 0);
-              else gW3[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[t], bv[nt][t], gW3[nt], 0, 0, 0);
+              gW3[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(ave[t], bve[nt][t], gW3[nt], 0, 0, 0);
+              gW3b[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(avo[t], bvo[nt][t], gW3b[nt], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -899,10 +901,10 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
           }
 #pragma unroll
       for (int nt = 0; nt < MT2; ++nt) {
-        float sacc = 0.f;
+        f32x2 s2 = {dl2u[nt][0], dl2u[nt][1]};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc += dl2u[nt][r];
-        sb2[nt] += sacc;
+        for (int r = 2; r < 16; r += 2) s2 += f32x2{dl2u[nt][r], dl2u[nt][r + 1]};
+        sb2[nt] += s2.x + s2.y;
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- R10: gW1a[u1][f] += sum_s delta1[s][u1] x~a[s][f]   (column n = bias gradient)

@@ -56,32 +56,43 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
                                            // static stride would end in a 16th round that only 67 workgroups run (+4.7 %)
   const int KT0 = g.K[0] / GP_BK, KT = KT0 + (g.npairs > 1 ? g.K[1] / GP_BK : 0);
 
-  // per-thread operand pointers of the k-tile that is loaded next (bumped by one k-tile per load)
-  const float* pa[CA];
-  const float* pb[CB];
+  // Operand addresses of the k-tile that is loaded next: ONE wave-uniform base per operand (scalar registers, bumped by one
+  // k-tile per load on the scalar unit) + per-thread 32-bit byte offsets that stay put for a whole tile.  (r03: six 64-bit
+  // per-thread pointers cost 12 vector adds per k-tile and wave -- fp32 MFMAs do not hide vector-ALU instructions,
+  // tools/probe_fill.hip.  Tried on top and dropped: making the LDS buffer index a compile-time constant, to fold the
+  // remaining 17 LDS-address adds into immediates -- the kernel sits at its 256-register limit, the duplicated k-tile bodies
+  // spilled 324 bytes.)
+  typedef const char __attribute__((address_space(1)))* gptr;
+  gptr ua = nullptr, ub = nullptr;
+  uint32_t oa[CA], ob[CB];
   int64_t sb = 0;
   auto rebase = [&](int tile, int p) {
     const int m0 = (tile / col_blocks) * GP_BM, n0 = (tile % col_blocks) * GP_BN;
     const float* __restrict__ Ap = g.A[p];
     const float* __restrict__ Bp = g.B[p];
+    ua = (gptr)(Ap + (int64_t)m0 * g.a_rs[p]);
 #pragma unroll
     for (int c = 0; c < CA; ++c) {
       const int idx = tid + GP_NTH * c;
-      pa[c] = Ap + (int64_t)(m0 + (idx >> 3)) * g.a_rs[p] + 4 * (idx & 7);
+      oa[c] = (uint32_t)(((int64_t)(idx >> 3) * g.a_rs[p] + 4 * (idx & 7)) * 4);
     }
+    ub = LB ? (gptr)(Bp + n0) : (gptr)(Bp + (int64_t)n0 * g.b_cs[p]);
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
       const int idx = tid + GP_NTH * c;
-      pb[c] = LB ? Bp + (int64_t)(idx / (GP_BN / 4)) * g.b_ks[p] + n0 + 4 * (idx % (GP_BN / 4)) : Bp + (int64_t)(n0 + (idx >> 3)) * g.b_cs[p] + 4 * (idx & 7);
+      ob[c] = LB ? (uint32_t)(((int64_t)(idx / (GP_BN / 4)) * g.b_ks[p] + 4 * (idx % (GP_BN / 4))) * 4)
+                 : (uint32_t)(((int64_t)(idx >> 3) * g.b_cs[p] + 4 * (idx & 7)) * 4);
     }
-    sb = LB ? (int64_t)GP_BK * g.b_ks[p] : GP_BK;
+    sb = (LB ? (int64_t)GP_BK * g.b_ks[p] : (int64_t)GP_BK) * 4;
   };
   f32x4 ra[CA], rb[CB];
   auto gload = [&]() {
 #pragma unroll
-    for (int c = 0; c < CA; ++c) { ra[c] = *(const f32x4*)pa[c]; pa[c] += GP_BK; }
+    for (int c = 0; c < CA; ++c) ra[c] = *(const f32x4 __attribute__((address_space(1)))*)(ua + oa[c]);
+    ua += GP_BK * 4;
 #pragma unroll
-    for (int c = 0; c < CB; ++c) { rb[c] = *(const f32x4*)pb[c]; pb[c] += sb; }
+    for (int c = 0; c < CB; ++c) rb[c] = *(const f32x4 __attribute__((address_space(1)))*)(ub + ob[c]);
+    ub += sb;
   };
   auto lstore = [&](int buf) {
     float* Ad = As + buf * GP_ASZ;
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
              }
          });
     ++kt;
-    tn = s_next;
+    tn = __builtin_amdgcn_readfirstlane(s_next);      // (wave-uniform: the tile's operand bases stay scalar)
     body(kt, false, [&] { if (tn < ntiles) { kl = 0; rebase(tn, 0); gload(); kl = 1; } }, nop);
     GP_STAMP(1); GP_STAMP(2);
     // (every wave is past the last k-tile's barrier and had all its fragments in registers before it: both operand buffers are free)
