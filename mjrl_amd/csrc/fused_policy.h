@@ -191,7 +191,7 @@ struct FusedLayout {
   int oW1, oW2, oW3, oB2, oB3, SLOT;            // weight slot (one per parameter set)
   int oXS, oXT, oD3, oBA, oBB, WAVE;            // per-wave scratch
   int oTR, oCST, oWAVES, TOTAL;
-  static constexpr int NCST = 11;               // osc, osh, sigma, log_std (new) ; the same for old ; Dk = 2/(2 sigma^2 + 1e-8) ; {c3, osc^2 Dk / N} pairs
+  static constexpr int NCST = 13;               // osc, osh, sigma, log_std (new) ; the same for old ; Dk = 2/(2 sigma^2 + 1e-8) ; {c3, osc^2 Dk / N} pairs ; 1/sigma new, old
   // eval_only: the layout of MODE_EVAL launches -- no backward pass, so a wave's scratch is just the raw image of its
   // observation tile (3.2 KB instead of 25 KB at HalfCheetah shapes); the workgroup then needs ~64 KB and TWO of them
   // share a CU, i.e. two waves per SIMD: one wave's tanh / likelihood VALU work runs under the other's MFMAs
@@ -347,13 +347,16 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
     if (tid < H2) slot[L.oB2 + tid] = b2r[s];
     if (tid < m) slot[L.oB3 + tid] = b3r[s];
   }
-  if (tid < n) { trs[tid] = trr[0]; trs[NP + tid] = trr[1]; trs[2 * NP + tid] = trr[2]; trs[3 * NP + tid] = trr[3]; }
+  // (input transforms as shift and RECIPROCAL scale, 1 / (scale + 1e-8): x~ = (x - shift) * inv is two vector-ALU instructions
+  //  per value where the division sequence was six -- vector-ALU time is not hidden by fp32 MFMAs; exact for the identity
+  //  transform like the reference's division, <= 1.5 ulp otherwise.  Entries past the n features stay 0: padding columns read 0)
+  if (tid < n) { trs[tid] = trr[0]; trs[NP + tid] = 1.0f / (trr[1] + 1e-8f); trs[2 * NP + tid] = trr[2]; trs[3 * NP + tid] = 1.0f / (trr[3] + 1e-8f); }
   // constant "ones" feature (bias column) of every wave's staging buffers
   if (!EV2 && lane < 32) xT[n * ST + lane] = 1.0f;
 
   // ---------------- per-action constants (LDS, broadcast reads) ----------------
   float* cst = lds + L.oCST;
-  enum { C_OSC = 0, C_OSH = 1, C_SG = 2, C_LS = 3, C_OSCB = 4, C_OSHB = 5, C_SGB = 6, C_LSB = 7, C_DK = 8 };
+  enum { C_OSC = 0, C_OSH = 1, C_SG = 2, C_LS = 3, C_OSCB = 4, C_OSHB = 5, C_SGB = 6, C_LSB = 7, C_DK = 8, C_ISG = 11, C_ISGB = 12 };   // (9, 10: the FVP's {c3, scale} pairs)
   if (tid < MP) {
     const int a = tid;
     const bool ok = a < m;
@@ -370,6 +373,8 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
     cst[C_SGB * MP + a] = ok ? expf(lsb) : 1.0f;
     cst[C_LSB * MP + a] = lsb;
     cst[C_DK * MP + a] = dk;
+    cst[C_ISG * MP + a] = 1.0f / sga;
+    cst[C_ISGB * MP + a] = 1.0f / cst[C_SGB * MP + a];
     if (MODE == MODE_FVP) {                       // FVP epilogue: d3 = (md + c3) * osc^2 * Dk / N
       const float osc = ok ? csr[2] : 0.f;
       cst[9 * MP + 2 * a] = ok ? csr[6] : 0.f;
@@ -986,9 +991,9 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         // x~[j][f] = (x - shift)/(scale + 1e-8) for f < n (fc_network.py:46); the bias column f == n reads 1, the
         // pad reads 0; rows past the batch end read 0.  Computed one group ahead, so the divide overlaps the MFMAs.
         auto xnorm = [&](int f) {
-          const int fc = (f < n) ? f : 0;
-          float v = fast_div(xs[j * n + fc] - tsh[fc], tsc[fc] + 1e-8f);
-          return (f < n) ? (valid ? v : 0.0f) : (f == n ? 1.0f : 0.0f);
+          // (f >= n: shift and reciprocal scale are 0, the value read -- a neighbouring row's / the zeroed slack -- drops out)
+          const float v = (xs[j * n + f] - tsh[f]) * tsc[f];
+          return (f == n) ? 1.0f : (valid ? v : 0.0f);
         };
         const float* ximg = A.hcache + tile * HC_TILE + HC_H + lane * 2;
         // group q's pair of features for this lane: computed, or (cached FVP) read back as K1 stored it
@@ -1296,7 +1301,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         const bool ok = valid && (a < m);
         av[a] = ok ? actr[a] : 0.f;
         muv[a] = (oa[a] + slotA[L.oB3 + a]) * cst[C_OSC * MP + a] + cst[C_OSH * MP + a];
-        z[a] = fast_div(av[a] - muv[a], cst[C_SG * MP + a]);
+        z[a] = (av[a] - muv[a]) * cst[C_ISG * MP + a];
         llA = fmaf(-0.5f * z[a], z[a], llA);
       }
       llA = llA - sum_lsA - llc;
@@ -1326,7 +1331,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
         for (int a = 0; a < MP; ++a) {
           muB[a] = (ob[a] + slotB[L.oB3 + a]) * cst[C_OSCB * MP + a] + cst[C_OSHB * MP + a];
-          float zb = fast_div(av[a] - muB[a], cst[C_SGB * MP + a]);
+          float zb = (av[a] - muB[a]) * cst[C_ISGB * MP + a];
           llB = fmaf(-0.5f * zb, zb, llB);
         }
         llB = llB - sum_lsB - llc;
@@ -1350,8 +1355,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         float d3a[MP];
 #pragma unroll
         for (int a = 0; a < MP; ++a) {
-          float sg = cst[C_SG * MP + a];
-          d3a[a] = cst[C_OSC * MP + a] * fast_div(w * z[a], sg);
+          d3a[a] = cst[C_OSC * MP + a] * ((w * z[a]) * cst[C_ISG * MP + a]);
         }
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
