@@ -249,6 +249,9 @@ def main():
     ap.add_argument("--rehearse-world", type=int, default=0,
                     help="diagnostic, 1 GPU: run rank 0's share of an R-rank job (1/R of the batch, global N, "
                          "RCCL collectives on a 1-rank group); the line is tagged 'rehearsal' and is not the metric")
+    ap.add_argument("--rehearse-transport", choices=["rccl", "peer"], default="rccl",
+                    help="--rehearse-world: the rank sums on a 1-rank RCCL group, or on libmjx's peer exchange in loop-back (the stores "
+                         "to R buffers, counter updates, stream wait and R-slot sums of an R-rank exchange, all onto this rank's buffer)")
     args = ap.parse_args()
 
     import torch
@@ -274,6 +277,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ["MJX_COLLECTIVES_AT_WORLD1"] = "1"
+        if args.rehearse_transport == "peer":
+            os.environ["MJX_PEER_COMM"] = "1"
+            os.environ["MJX_PEER_LOOPBACK_WORLD"] = str(args.rehearse_world)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         shards = args.rehearse_world
 
@@ -379,7 +385,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: HalfCheetah-v2 shapes (obs=17, act=6), 64x64 tanh MLP, "
                                    "NPG 10 CG iters, 1M timesteps/batch (1000 traj x 1000), device-resident update",
-                       "global_batch": N_TRAJ * T, "parallelism": "dp%d (trajectory shards, RCCL all-reduce per CG iter)" % world,
+                       "global_batch": N_TRAJ * T, "parallelism": "dp%d (trajectory shards, one rank sum per CG iteration: %s)"
+                                      % (world, {"rccl": "RCCL all-reduce inside libmjx", "peer": "libmjx peer exchange over HIP IPC",
+                                                 "hook": "transport hook", None: "none at one rank"}.get(eng.comm_kind, str(eng.comm_kind))),
                        "cg_iters": CG_ITERS, "damping": DAMPING},
             "roofline": {"bound": "mfma", "kernel": "k_fused<64,64,1,8,MODE_FVP,NP=20,CACHED>",
                          "achieved": achieved_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -423,7 +431,8 @@ def main():
                 print(json.dumps({"error": "update differs from the reference beyond 1e-5", "drift": drift, "check": last}), file=sys.stderr, flush=True)
                 failed = True
         if args.rehearse_world > 1:
-            out["rehearsal"] = "rank 0 of %d on one GPU, 1-rank RCCL group: NOT the metric" % args.rehearse_world
+            out["rehearsal"] = "rank 0 of %d on one GPU, %s: NOT the metric" % (
+                args.rehearse_world, "1-rank RCCL group" if eng.comm_kind == "rccl" else "peer exchange in loop-back" if eng.comm_kind == "peer" else eng.comm_kind)
             out["roofline"]["traffic"] = None
         if world == 1 and not args.no_secondary and args.rehearse_world <= 1:
             out["secondary"] = secondary_measurements(eng, theta0, theta0_dev, ref)

@@ -160,6 +160,25 @@ int mjx_comm_world(const mjx_ctx* ctx);
 /* in-place sum over the ranks on `stream`; dtype 0 = fp32, 1 = fp64 */
 int mjx_comm_allreduce(mjx_ctx* ctx, void* buf, int64_t count, int dtype, void* stream);
 
+/* Peer exchange: a third transport for the same rank sums, built on HIP IPC and stream memory operations instead of RCCL --
+ * for the 5-23 KB vectors of this path a collective library's launch + protocol latency is most of the cost.  Every rank owns one
+ * uncached device buffer [2 parities][world slots] + an arrival counter; mjx_peer_export allocates it and returns its
+ * hipIpcMemHandle_t (MJX_PEER_HANDLE_BYTES bytes), the caller gathers the world's handles over any side channel (rank order) and
+ * hands them to mjx_peer_connect, which maps the peers' buffers.  From then on every rank sum of mjx_comm_allreduce /
+ * mjx_cg_solve / mjx_npg_update / mjx_trpo_update / mjx_dapg_update is: store the local vector into slot `rank` of EVERY rank's
+ * buffer and add 1 to every peer's counter (in the CG loop the Fisher product's reduction kernel does both itself); the
+ * consuming kernel (in the loop: the CG vector update) waits on the own counter -- local memory -- and sums the local slots in
+ * rank order.  All on the launch stream: no host synchronisation, no extra launch in the loop, bit-identical results on all
+ * ranks.  The wait is bounded: a peer that has not delivered within 5 s turns the result into NaN instead of hanging the GPU.  One process per rank, 2 <= world <= 16; the ranks may own different GPUs of a node (peer access over
+ * xGMI) or share one (tests).  Every rank must issue the same sequence of rank sums.  Replaces nothing in the reference (its
+ * only parallelism is the sampler pool).  mjx_comm_destroy tears it down.
+ * handles == NULL: loop-back rehearsal -- every "peer" is this rank's own buffer, so the stores, counter updates, the stream
+ * wait and the `world`-slot sums of a world-rank exchange all execute while the sums see this rank's vector only (a timing
+ * diagnostic: bench.py --rehearse-world R --rehearse-transport peer). */
+#define MJX_PEER_HANDLE_BYTES 64
+int mjx_peer_export(mjx_ctx* ctx, int rank, int world, char* handle_out);
+int mjx_peer_connect(mjx_ctx* ctx, const char* handles /* world x MJX_PEER_HANDLE_BYTES, rank order */);
+
 /* ONE device-resident NPG update enqueued without a host round trip -- what NPG.train_from_paths does between
  * process_paths and the parameter read-back (mjrl/algos/npg_cg.py:108-142):
  *   K1   grad = flat_vpg, surrogate sums                                   [rank sum: d floats + 4 doubles]

@@ -88,6 +88,15 @@ struct mjx_ctx {
   size_t prof_seen = 0;
   void* comm = nullptr; int comm_world = 0, comm_rank = 0;   // RCCL communicator (one process per GPU)
   mjx_reduce_fn reduce_cb = nullptr; void* reduce_user = nullptr;   // transport hook in its place (tests)
+  // peer exchange (mjx_peer_*): one uncached device buffer per rank [2 parities][world slots] | arrival counter, the peers' mapped
+  // through HIP IPC; every all-reduce = store the vector into slot `rank` of every buffer + bump the peers' counters, one
+  // stream-ordered wait on the own counter, rank-ordered sum of the local slots (vecops.h "Peer exchange")
+  struct Peer {
+    bool on = false; int rank = 0, world = 0;
+    char* buf = nullptr; char* map[16] = {nullptr};
+    size_t slot_bytes = 0; uint32_t seq = 0;
+  } peer;
+  unsigned* ticket = nullptr;                      // workgroup ticket of the producer kernels (ordinary device memory, zero between launches)
   mjx::LayerwiseWS lw;             // layer-wise path workspace
   mjx::LayerwiseWS lwmb;           // minibatch trainer workspace (mjx_policy_minibatch_adam)
   float *mb_x = nullptr, *mb_a = nullptr, *mb_adv = nullptr, *mb_grad = nullptr; int mb_cap = 0;
@@ -236,6 +245,7 @@ int mjx_create(mjx_ctx** out, int device, int n, int m, const int* hidden, int n
   HIPCHK(hipMalloc(&c->spartials, (size_t)2 * c->grid * 4 * sizeof(double)));       // (MODE_EVAL launches 2 workgroups per CU)
   HIPCHK(hipMalloc(&c->cg_x, d * 4)); HIPCHK(hipMalloc(&c->cg_r, d * 4)); HIPCHK(hipMalloc(&c->cg_p, d * 4));
   HIPCHK(hipMalloc(&c->cg_z, d * 4)); HIPCHK(hipMalloc(&c->cg_Ap, d * 4));
+  HIPCHK(hipMalloc((void**)&c->ticket, 256)); HIPCHK(hipMemset(c->ticket, 0, 256));
   HIPCHK(hipMalloc(&c->cg_scal, 8 * sizeof(double)));
   std::vector<float> id(2 * n + 2 * m, 0.f);
   for (int i = 0; i < n; ++i) id[n + i] = 1.f;
@@ -261,7 +271,7 @@ void mjx_destroy(mjx_ctx* c) {
   hipFree(c->ocache);
   hipFree(c->snap);
   hipFree(c->partials); hipFree(c->spartials); hipFree(c->ident_tr);
-  hipFree(c->cg_x); hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_z); hipFree(c->cg_Ap); hipFree(c->cg_scal);
+  hipFree(c->cg_x); hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_z); hipFree(c->cg_Ap); hipFree(c->ticket); hipFree(c->cg_scal);
   delete c;
 }
 
@@ -625,7 +635,8 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
   return MJX_OK;
 }
 
-int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
+// pp: peer exchange folded into the reduction kernel (fused kernels with d % 4 == 0 only; `out` is then this rank's slot)
+static int fvp_impl(mjx_ctx* c, const float* v, float* out, void* stream, const PeerPush* pp) {
   if (int rc = check_bound(c, false)) return rc;
   if (!v || !out) return fail(MJX_ERR_ARG, "null vector");
   if (c->fused && (((uintptr_t)v) & 15)) return fail(MJX_ERR_ARG, "v must be 16-byte aligned (fused path)");   // (the layer-wise path takes any 4-byte aligned v)
@@ -658,13 +669,15 @@ int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) {
   if (prof) { HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], st)); c->prof_used += 2; }
   if ((c->d & 3) == 0)
     hipLaunchKernelGGL(k_reduce_partials4, dim3((c->d + 31) / 32), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
-                       out, c->theta_new, v, c->oS, frac);
+                       out, c->theta_new, v, c->oS, frac, pp ? *pp : PeerPush{});
   else
     hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
                        out, c->theta_new, v, c->oS, frac);
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }
+
+int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) { return fvp_impl(c, v, out, stream, nullptr); }
 
 int mjx_eval_surr_kl(mjx_ctx* c, double* scal_out, void* stream) {
   if (int rc = check_bound(c, true)) return rc;
@@ -687,6 +700,46 @@ int mjx_eval_surr_kl(mjx_ctx* c, double* scal_out, void* stream) {
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }
+
+// ---------------------------------------------------------------------------- peer exchange (HIP IPC + stream memory operations)
+namespace {
+bool has_ranks(const mjx_ctx* c) { return c->comm || c->reduce_cb || c->peer.on; }
+// slot `r` (the vector rank r contributed) of parity `par` in rank q's buffer; the arrival counter and the producers' ticket
+char* peer_slot(const mjx_ctx* c, int q, int par, int r) { return c->peer.map[q] + (size_t)(par * c->peer.world + r) * c->peer.slot_bytes; }
+unsigned* peer_counter(const mjx_ctx* c, int q) { return (unsigned*)(c->peer.map[q] + (size_t)2 * c->peer.world * c->peer.slot_bytes); }
+PeerPush peer_push(const mjx_ctx* c, int par) {
+  PeerPush pp{};
+  pp.world = c->peer.world; pp.rank = c->peer.rank;
+  pp.ticket = c->ticket;
+  for (int q = 0; q < c->peer.world; ++q) { pp.dst[q] = peer_slot(c, q, par, c->peer.rank); pp.counter[q] = peer_counter(c, q); }
+  return pp;
+}
+// the consumer's view of exchange `seq`: its local slots in rank order (the surplus entries: a slot of zeros behind the counter
+// block), the own arrival counter and the value it reaches once every peer has delivered
+PeerSlots peer_slots(const mjx_ctx* c, int par, uint32_t seq) {
+  PeerSlots ps{};
+  ps.world = c->peer.world;
+  const char* zeros = (const char*)peer_counter(c, c->peer.rank) + 256;
+  for (int r = 0; r < 16; ++r) ps.slot[r] = r < c->peer.world ? peer_slot(c, c->peer.rank, par, r) : zeros;
+  ps.counter = peer_counter(c, c->peer.rank);
+  ps.target = seq * (uint32_t)(c->peer.world - 1);
+  return ps;
+}
+int peer_allreduce(mjx_ctx* c, void* buf, int64_t count, int dtype, hipStream_t st) {
+  const size_t bytes = (size_t)count * (dtype ? 8 : 4);
+  if (bytes > c->peer.slot_bytes) return fail(MJX_ERR_ARG, "peer all-reduce of %zu bytes exceeds the slot (%zu)", bytes, c->peer.slot_bytes);
+  const uint32_t seq = ++c->peer.seq;
+  const int par = (int)(seq & 1u);
+  const unsigned grid = (unsigned)((count + 255) / 256);
+  if (dtype) hipLaunchKernelGGL(k_peer_push<double>, dim3(grid), dim3(256), 0, st, (const double*)buf, peer_push(c, par), count);
+  else hipLaunchKernelGGL(k_peer_push<float>, dim3(grid), dim3(256), 0, st, (const float*)buf, peer_push(c, par), count);
+  HIPCHK(hipGetLastError());
+  if (dtype) hipLaunchKernelGGL(k_peer_sum<double>, dim3(grid), dim3(256), 0, st, peer_slots(c, par, seq), (double*)buf, count);
+  else hipLaunchKernelGGL(k_peer_sum<float>, dim3(grid), dim3(256), 0, st, peer_slots(c, par, seq), (float*)buf, count);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+}  // namespace
 
 int mjx_cg_init(mjx_ctx* c, const float* b, void* stream) {
   if (!c || !b) return fail(MJX_ERR_ARG, "bad arguments");
@@ -719,9 +772,26 @@ int mjx_cg_solve(mjx_ctx* c, const float* b, int iters, float damping, double to
   if (!c || !b || iters < 0) return fail(MJX_ERR_ARG, "bad arguments");
   if (int rc = mjx_cg_init(c, b, stream)) return rc;
   for (int i = 0; i < iters; ++i) {
+    if (!allreduce && c->peer.on && c->fused && c->old_is_new && c->N_local > 0 && (c->d & 3) == 0 && c->d <= 8 * 1024) {
+      // peer exchange, folded into the loop's own kernels: the product's reduction kernel writes this rank's vector into slot `rank` of
+      // EVERY rank's buffer and bumps the peers' arrival counters, the vector-update kernel waits on the own counter and sums its local
+      // slots (rank order): per iteration FVP -> reduction -> step -- exactly the launches of the one-rank loop, no host round trip.
+      // (A rank on another route -- empty shard -- runs the same exchange through mjx_comm_allreduce.)
+      const uint32_t seq = ++c->peer.seq;
+      const int par = (int)(seq & 1u);
+      const PeerPush pp = peer_push(c, par);
+      if (int rc = fvp_impl(c, c->cg_p, (float*)peer_slot(c, c->peer.rank, par, c->peer.rank), stream, &pp)) return rc;
+      const PeerSlots ps = peer_slots(c, par, seq);
+#define MJX_STEP_W(W) hipLaunchKernelGGL((k_cg_step_reg<8, W>), dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)nullptr, damping, tol, \
+                                         c->cg_x, c->cg_r, c->cg_p, c->cg_scal, (int)c->d, ps)
+      if (c->peer.world <= 2) MJX_STEP_W(2); else if (c->peer.world <= 4) MJX_STEP_W(4); else if (c->peer.world <= 8) MJX_STEP_W(8); else MJX_STEP_W(16);
+#undef MJX_STEP_W
+      HIPCHK(hipGetLastError());
+      continue;
+    }
     if (int rc = mjx_fvp(c, c->cg_p, c->cg_Ap, stream)) return rc;
     if (allreduce) { if (int rc = allreduce(user, c->cg_Ap, c->d, stream)) return fail(rc, "allreduce callback failed (%d)", rc); }
-    else if (c->comm || c->reduce_cb) { if (int rc = mjx_comm_allreduce(c, c->cg_Ap, c->d, 0, stream)) return rc; }
+    else if (has_ranks(c)) { if (int rc = mjx_comm_allreduce(c, c->cg_Ap, c->d, 0, stream)) return rc; }
     if (int rc = mjx_cg_step(c, c->cg_Ap, damping, tol, stream)) return rc;
   }
   return mjx_cg_finish(c, b, x_out, bdotx_out, stream);
@@ -754,6 +824,15 @@ int mjx_comm_init(mjx_ctx* c, int rank, int world, const char* id_host) {
 
 int mjx_comm_destroy(mjx_ctx* c) {
   if (!c) return fail(MJX_ERR_ARG, "null context");
+  if (c->peer.buf) {
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < c->peer.world; ++r)
+      if (r != c->peer.rank && c->peer.map[r] && c->peer.map[r] != c->peer.buf) (void)hipIpcCloseMemHandle(c->peer.map[r]);
+    (void)hipFree(c->peer.buf);
+    c->peer = mjx_ctx::Peer{};
+    c->comm_world = 0;
+  }
   if (c->comm) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
@@ -763,7 +842,44 @@ int mjx_comm_destroy(mjx_ctx* c) {
   return MJX_OK;
 }
 
-int mjx_comm_world(const mjx_ctx* c) { return (c && (c->comm || c->reduce_cb)) ? c->comm_world : 0; }
+int mjx_comm_world(const mjx_ctx* c) { return (c && (c->comm || c->reduce_cb || c->peer.on)) ? c->comm_world : 0; }
+
+int mjx_peer_export(mjx_ctx* c, int rank, int world, char* handle_out) {
+  if (!c || !handle_out || world < 2 || world > 16 || rank < 0 || rank >= world) return fail(MJX_ERR_ARG, "bad arguments (2 <= world <= 16)");
+  if (c->comm || c->reduce_cb || c->peer.buf) return fail(MJX_ERR_STATE, "a transport is already attached");
+  HIPCHK(hipSetDevice(c->device));
+  size_t slot = (size_t)c->d * sizeof(float);
+  if (slot < 64 * sizeof(double)) slot = 64 * sizeof(double);
+  slot = (slot + 255) & ~(size_t)255;
+  void* p = nullptr;
+  const size_t total = (size_t)(2 * world + 1) * slot + 256;      // [2 parities][world slots] | arrival counter (256 B) | one slot of zeros
+  HIPCHK(hipExtMallocWithFlags(&p, total, hipDeviceMallocUncached));
+  HIPCHK(hipMemset(p, 0, total));
+  HIPCHK(hipDeviceSynchronize());
+  hipIpcMemHandle_t h;
+  { hipError_t e = hipIpcGetMemHandle(&h, p); if (e != hipSuccess) { (void)hipFree(p); return fail((int)e, "hipIpcGetMemHandle: %s", hipGetErrorString(e)); } }
+  static_assert(sizeof(hipIpcMemHandle_t) == MJX_PEER_HANDLE_BYTES, "handle size");
+  memcpy(handle_out, &h, sizeof h);
+  c->peer.buf = (char*)p; c->peer.slot_bytes = slot; c->peer.rank = rank; c->peer.world = world; c->peer.seq = 0;
+  return MJX_OK;
+}
+
+int mjx_peer_connect(mjx_ctx* c, const char* handles) {
+  if (!c) return fail(MJX_ERR_ARG, "null context");
+  if (!c->peer.buf || c->peer.on) return fail(MJX_ERR_STATE, "call mjx_peer_export first (once)");
+  HIPCHK(hipSetDevice(c->device));
+  for (int r = 0; r < c->peer.world; ++r) {
+    if (r == c->peer.rank || !handles) { c->peer.map[r] = c->peer.buf; continue; }     // handles == NULL: loop-back rehearsal
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + (size_t)r * MJX_PEER_HANDLE_BYTES, sizeof h);
+    void* q = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail((int)e, "hipIpcOpenMemHandle (rank %d): %s", r, hipGetErrorString(e));
+    c->peer.map[r] = (char*)q;
+  }
+  c->peer.on = true; c->comm_world = c->peer.world; c->comm_rank = c->peer.rank;
+  return MJX_OK;
+}
 
 int mjx_comm_set_callback(mjx_ctx* c, mjx_reduce_fn fn, void* user, int world) {
   if (!c || (fn && world < 1)) return fail(MJX_ERR_ARG, "bad arguments");
@@ -775,6 +891,7 @@ int mjx_comm_set_callback(mjx_ctx* c, mjx_reduce_fn fn, void* user, int world) {
 int mjx_comm_allreduce(mjx_ctx* c, void* buf, int64_t count, int dtype, void* stream) {
   if (!c || !buf || count < 0 || (dtype != 0 && dtype != 1)) return fail(MJX_ERR_ARG, "bad arguments");
   if (count == 0) return MJX_OK;
+  if (c->peer.on) return peer_allreduce(c, buf, count, dtype, (hipStream_t)stream);
   if (!c->comm) {
     if (!c->reduce_cb) return fail(MJX_ERR_STATE, "no communicator attached (mjx_comm_init)");
     if (int rc = c->reduce_cb(c->reduce_user, buf, count, dtype, stream)) return fail(rc, "transport hook failed (%d)", rc);
@@ -801,7 +918,7 @@ int mjx_npg_update(mjx_ctx* c, int iters, float damping, double tol, double step
     const int ge = r.GroupEnd();
     if (rc) return rc;
     if (ge) return fail(1000 + ge, "ncclGroupEnd: %s", r.GetErrorString(ge));
-  } else if (c->reduce_cb) {
+  } else if (c->reduce_cb || c->peer.on) {
     if (int rc = mjx_comm_allreduce(c, grad_out, c->d, 0, stream)) return rc;
     if (int rc = mjx_comm_allreduce(c, results + 4, 4, 1, stream)) return rc;
   }
@@ -811,7 +928,7 @@ int mjx_npg_update(mjx_ctx* c, int iters, float damping, double tol, double step
   else if (int rc = mjx_apply_npg_step(c, base, x_out, results + 8, step_size, min_log_std, theta_out, results + 9, stream)) return rc;
   if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc;
   if (int rc = mjx_eval_surr_kl(c, results, stream)) return rc;
-  if (c->comm || c->reduce_cb) if (int rc = mjx_comm_allreduce(c, results, 4, 1, stream)) return rc;
+  if (has_ranks(c)) if (int rc = mjx_comm_allreduce(c, results, 4, 1, stream)) return rc;
   return MJX_OK;
 }
 
@@ -824,7 +941,7 @@ int mjx_trpo_update(mjx_ctx* c, int iters, float damping, double tol, double ste
   if (first) {
     if (!c->old_is_new) return fail(MJX_ERR_STATE, "mjx_trpo_update starts from theta_new == theta_old (mjx_bind_policy with old_is_new)");
     if (int rc = mjx_surr_vpg(c, grad_out, results + 4, stream)) return rc;
-    if (c->comm || c->reduce_cb) {
+    if (has_ranks(c)) {
       if (int rc = mjx_comm_allreduce(c, grad_out, c->d, 0, stream)) return rc;
       if (int rc = mjx_comm_allreduce(c, results + 4, 4, 1, stream)) return rc;
     }
@@ -836,7 +953,7 @@ int mjx_trpo_update(mjx_ctx* c, int iters, float damping, double tol, double ste
     HIPCHK(hipGetLastError());
     if (first && t == 0) { if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc; }
     if (int rc = mjx_eval_surr_kl(c, results, stream)) return rc;
-    if (c->comm || c->reduce_cb) if (int rc = mjx_comm_allreduce(c, results, 4, 1, stream)) return rc;
+    if (has_ranks(c)) if (int rc = mjx_comm_allreduce(c, results, 4, 1, stream)) return rc;
     hipLaunchKernelGGL(k_trpo_check, dim3(1), dim3(64), 0, st, results, kl_dist, (double)c->N_global);
     HIPCHK(hipGetLastError());
   }
@@ -852,7 +969,7 @@ int mjx_dapg_update(mjx_ctx* c, int iters, float damping, double tol, double ste
   if (theta_out == c->theta_old) return fail(MJX_ERR_ARG, "theta_out must not alias theta_old");
   if (rows_on < 0 || rows_on > c->N_local || N_on_global <= 0 || N_on_global > c->N_global) return fail(MJX_ERR_ARG, "bad on-policy row counts");
   hipStream_t st = (hipStream_t)stream;
-  const bool ranks = c->comm || c->reduce_cb;
+  const bool ranks = has_ranks(c);
   // the vanilla gradient over [on-policy ; demonstrations] (mean over N_all), then x N_all / N_on (dapg.py:97-98)
   const float coef = (float)((double)c->N_global / (double)N_on_global);
   if (int rc = mjx_surr_vpg(c, grad_out, results + 4, stream)) return rc;

@@ -87,11 +87,82 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
   }
 }
 
+// Peer exchange (mjx_peer_*).  Every rank owns one uncached buffer [2 parities][world slots] + an arrival counter; the peers'
+// buffers are mapped through hipIpcOpenMemHandle.  An all-reduce = every rank WRITES its vector into slot `rank` of every
+// buffer (posted stores over xGMI), then adds 1 to every peer's counter; the consumer kernel waits (bounded) on its OWN counter
+// -- local memory -- and sums its local slots in rank order: the same bits on every rank, no host in the loop.
+struct PeerSlots {                     // consumer: the local slots of this exchange (entries >= world point at a slot of zeros)
+  const void* slot[16]; const unsigned* counter; unsigned target; int world;
+};
+struct PeerPush { void* dst[16]; unsigned* counter[16]; unsigned* ticket; int world, rank; };  // producer: slot `rank` in every buffer; world == 0: off
+
+// tail of a producer kernel (all threads call it): once the LAST workgroup's stores are visible system-wide, one thread
+// bumps every peer's arrival counter.  The ticket lives in ordinary device memory and is left at zero for the next kernel.
+__device__ __forceinline__ void peer_signal_tail(const PeerPush& pp) {
+  // the slots are uncached (MTYPE UC) memory: a store is acknowledged by the memory (or the link) it went to, no cache holds it
+  // back -- waiting for the acknowledgements orders the stores before the counter updates without a system-scope release (which
+  // on gfx950 writes back every dirty line of the L2, here the whole partials array: +10 us per launch)
+#ifdef MJX_PEER_SYSTEM_FENCE
+  __threadfence_system();
+#else
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(pp.ticket, 1u);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(pp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int q = 0; q < pp.world; ++q)
+        if (q != pp.rank) __hip_atomic_fetch_add(pp.counter[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+// head of a consumer kernel (all threads call it): every peer adds 1 per exchange and none can be more than one exchange
+// ahead, so the counter reaches `target` = exchange number x (world - 1) exactly when all vectors have arrived.  A peer that
+// never delivers must not hang the GPU: after 5 s the wait gives up and the caller poisons its result with NaN.
+__device__ __forceinline__ bool peer_arrived(const PeerSlots& ps) {
+  __shared__ int arrived;
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();           // 100 MHz
+    int good = 1;
+    while ((int)(__hip_atomic_load(ps.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - ps.target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > 500000000ull) { good = 0; break; }
+    }
+    arrived = good;
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");              // system scope: nothing read below may predate the arrivals
+  return arrived != 0;
+}
+template <typename T>
+__global__ void k_peer_push(const T* __restrict__ src, PeerPush pp, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) {
+    const T v = src[i];
+    for (int q = 0; q < pp.world; ++q) ((T*)pp.dst[q])[i] = v;
+  }
+  peer_signal_tail(pp);
+}
+template <typename T>
+__global__ void k_peer_sum(PeerSlots ps, T* __restrict__ out, int64_t count) {       // fixed rank order: the same bits on every rank
+  const bool ok = peer_arrived(ps);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  T t[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] = ((const T*)ps.slot[r])[i];     // all loads in flight at once (uncached memory)
+  T a = t[0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) a += t[r];
+  out[i] = ok ? a : (T)__builtin_nanf("");
+}
+
 // the same for d % 4 == 0 with 16-byte loads: 32 columns (8 float4) x 32 row groups per block, i.e. 128-byte row
 // segments instead of 64-byte ones and a quarter of the load instructions (7 -> ~4.5 us for 256 x 5.7 k partials)
 __global__ __launch_bounds__(256) void k_reduce_partials4(const float* __restrict__ partials, int G, int d,
                                                            float* __restrict__ out, const float* theta,
-                                                           const float* v, int oS, float frac) {
+                                                           const float* v, int oS, float frac, PeerPush pp = PeerPush{}) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ double sh[32][33];
   const int cq = threadIdx.x & 7, rg = threadIdx.x >> 3;
@@ -117,7 +188,10 @@ __global__ __launch_bounds__(256) void k_reduce_partials4(const float* __restric
       t = (double)(frac * cc * v[c]);
     }
     out[c] = (float)t;
+    for (int q = 0; q < pp.world; ++q)                 // peer exchange: `out` is this rank's slot in its own buffer
+      if (q != pp.rank) ((float*)pp.dst[q])[c] = (float)t;
   }
+  if (pp.world) peer_signal_tail(pp);
 }
 
 __global__ void k_reduce_scalars(const double* __restrict__ sp, int G, double* __restrict__ out) {
@@ -176,17 +250,32 @@ __global__ __launch_bounds__(1024) void k_cg_step(const float* __restrict__ Ap, 
 
 // the same step for d <= 1024 * EPT with every vector element held in registers: one round of loads, two block
 // reductions, one round of stores (the looped version above pays a global round trip per phase).  Same arithmetic.
-template <int EPT>
-__global__ __launch_bounds__(1024) void k_cg_step_reg(const float* __restrict__ Ap, float damping, double tol,
-                                                       float* x, float* r, float* p, double* scal, int d) {
-  __shared__ double sh[17];
+// W > 0: the Fisher-vector product arrives as one slot per rank (peer exchange, W = slots read: world rounded up to a power
+// of two, the surplus entries point at zeros); the body waits for the arrivals and sums the slots in rank order.
+// Called by all 1024 threads of one workgroup.
+template <int EPT, int W>
+__device__ __forceinline__ void cg_step_body(const float* Ap, float damping, double tol, float* x, float* r, float* p,
+                                             double* scal, int d, const PeerSlots& ps, double* sh /* 17 doubles */) {
+  bool ok = true;
+  if (W) ok = peer_arrived(ps);
   const double done = scal[1], rr = scal[0];
   float ap[EPT], pv[EPT], xv[EPT], rv[EPT];
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int i = threadIdx.x + e * 1024;
     const int ic = i < d ? i : 0;
-    ap[e] = Ap[ic]; pv[e] = p[ic]; xv[e] = x[ic]; rv[e] = r[ic];
+    if (W) {
+      float t[W ? W : 1];
+#pragma unroll
+      for (int q = 0; q < W; ++q) t[q] = ((const float*)ps.slot[q])[ic];
+      float a = t[0];
+#pragma unroll
+      for (int q = 1; q < W; ++q) a += t[q];
+      ap[e] = ok ? a : __builtin_nanf("");
+    } else {
+      ap[e] = Ap[ic];
+    }
+    pv[e] = p[ic]; xv[e] = x[ic]; rv[e] = r[ic];
   }
   if (done != 0.0) return;                          // converged earlier: cg_solve.py:19-20 `break`
   double pz = 0.0;
@@ -216,6 +305,12 @@ __global__ __launch_bounds__(1024) void k_cg_step_reg(const float* __restrict__ 
     scal[0] = nrr; scal[2] = pz; scal[3] += 1.0;
     if (nrr < tol) scal[1] = 1.0;
   }
+}
+template <int EPT, int W = 0>
+__global__ __launch_bounds__(1024) void k_cg_step_reg(const float* __restrict__ Ap, float damping, double tol,
+                                                       float* x, float* r, float* p, double* scal, int d, PeerSlots ps = PeerSlots{}) {
+  __shared__ double sh[17];
+  cg_step_body<EPT, W>(Ap, damping, tol, x, r, p, scal, d, ps, sh);
 }
 
 __global__ __launch_bounds__(1024) void k_cg_finish(const float* __restrict__ b, const float* __restrict__ x,

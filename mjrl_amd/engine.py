@@ -161,6 +161,22 @@ class HipBackend:
         self._hook = _lib.REDUCE_FN(hook)             # keep the trampoline alive as long as the context
         check(self.lib.mjx_comm_set_callback(self.ctx, self._hook, None, int(world)))
 
+    def peer_connect_all(self, dist):
+        """the peer exchange of libmjx (include/mjx.h "Peer exchange": HIP IPC buffers + stream-ordered flags) as the rank-sum
+        transport: every rank exports its buffer, the handles travel through the process group once"""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        loop = int(os.environ.get("MJX_PEER_LOOPBACK_WORLD", "0"))
+        if world == 1 and loop > 1:               # bench.py --rehearse-world: rank 0 of `loop`, every peer mapped onto its own buffer
+            buf = ctypes.create_string_buffer(64)
+            check(self.lib.mjx_peer_export(self.ctx, 0, loop, buf))
+            check(self.lib.mjx_peer_connect(self.ctx, None))
+            return
+        buf = ctypes.create_string_buffer(64)
+        check(self.lib.mjx_peer_export(self.ctx, int(rank), int(world), buf))
+        handles = [None] * world
+        dist.all_gather_object(handles, buf.raw)
+        check(self.lib.mjx_peer_connect(self.ctx, ctypes.create_string_buffer(b"".join(handles), 64 * world)))
+
     def allreduce(self, t):
         """in-place sum over the ranks on the launch stream (fp32 / fp64 tensors)"""
         check(self.lib.mjx_comm_allreduce(self.ctx, ptr(t), t.numel(), 1 if t.dtype == self.torch.float64 else 0, self.stream()))
@@ -219,6 +235,7 @@ class UpdateEngine:
         self._block = self._prefix = None
         self.old_is_new = True
         self._dbg = None
+        self.comm_kind = None                       # "rccl" | "peer" | "hook" once _native_comm() has attached a transport
         self._comm_state = None                     # None: not tried yet; True: libmjx holds an RCCL communicator; False: torch collectives
 
     # convenience handles used by bench / tests
@@ -339,24 +356,35 @@ class UpdateEngine:
 
     # ------------------------------------------------------------------ collectives
     def _native_comm(self):
-        """True when the rank sums run inside libmjx (ncclAllReduce on the launch stream, include/mjx.h): tried once, when
-        torch.distributed runs on the nccl (= RCCL) backend -- every rank then owns its GPU.  The communicator id is made
-        by rank 0 and broadcast through the process group.  Any failure leaves the torch.distributed collectives in
-        place (MJX_NATIVE_COMM=0 forces that)."""
+        """True when the rank sums run inside libmjx (include/mjx.h), decided once.  torch.distributed on the nccl (= RCCL)
+        backend -- every rank owns its GPU: ncclAllReduce on the launch stream, the communicator id made by rank 0 and
+        broadcast through the process group; with MJX_PEER_COMM=1 libmjx's peer exchange instead (HIP IPC buffers, the
+        handles gathered through the process group).  Any other backend (gloo ranks sharing a GPU): the peer exchange, or
+        with MJX_PEER_COMM=0 the transport hook over dist.all_reduce.  ``comm_kind`` names the choice.  Any failure
+        leaves the torch.distributed collectives in place (MJX_NATIVE_COMM=0 forces that)."""
         if self._comm_state is not None:
             return self._comm_state
         d = _dist()
         ok = False
         if d is not None and hasattr(self.backend, "comm_init") and os.environ.get("MJX_NATIVE_COMM", "1") != "0":
             try:
-                if d.get_backend() == "nccl":
+                # MJX_PEER_COMM=1: libmjx's own peer exchange (HIP IPC + stream-ordered flags) instead of RCCL; it is also what a
+                # process group that is not RCCL gets (gloo ranks sharing one GPU in the tests; MJX_PEER_COMM=0: the host-side hook)
+                peer = os.environ.get("MJX_PEER_COMM")
+                if (d.get_world_size() > 1 or int(os.environ.get("MJX_PEER_LOOPBACK_WORLD", "0")) > 1) and (
+                        peer == "1" or (d.get_backend() != "nccl" and peer != "0")):
+                    self.backend.peer_connect_all(d)
+                    self.comm_kind = "peer"
+                elif d.get_backend() == "nccl":
                     box = [self.backend.comm_unique_id() if d.get_rank() == 0 else None]
                     if d.get_world_size() > 1:
                         d.broadcast_object_list(box, src=0)
                     with _stdout_to_stderr():         # RCCL prints a version banner to stdout when a communicator is created
                         self.backend.comm_init(d.get_rank(), d.get_world_size(), box[0])
-                else:                                # e.g. gloo ranks sharing one GPU (tests): same C loops, hooked transport
+                    self.comm_kind = "rccl"
+                else:                                # same C loops, transport hooked to dist.all_reduce (a host synchronisation per sum)
                     self.backend.comm_set_callback(d, d.get_world_size())
+                    self.comm_kind = "hook"
                 ok = True
             except Exception as e:                   # pragma: no cover - depends on the host's RCCL
                 import warnings

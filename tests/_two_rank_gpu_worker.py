@@ -1,6 +1,7 @@
-"""Worker of test_two_ranks_on_one_gpu_equal_one_rank: one of two ranks (torch.distributed.run, gloo backend -- RCCL
-refuses two ranks on one device) that share the GPU.  Each rank binds its trajectory shard, the engine all-reduces
-device tensors exactly as it does over RCCL; rank 0 writes the update's results."""
+"""Worker of test_two_ranks_on_one_gpu_equal_one_rank: one of two ranks (torch.distributed.run; the process group is gloo
+-- RCCL refuses two ranks on one device -- and only carries set-up traffic) that share the GPU.  Each rank binds its
+trajectory shard; the rank sums run inside libmjx over its peer exchange (HIP IPC buffers + stream-ordered waits; with
+MJX_PEER_COMM=0 over the transport hook); rank 0 writes the update's results."""
 import os
 import sys
 
@@ -37,8 +38,9 @@ def main():
     late = eng.deferred()
     res = dict(grad=g.cpu().numpy(), x=eng.x.cpu().numpy(), theta=eng.theta_new.cpu().numpy(),
                scal=np.array([late["surr_before"], late["gdotx"], late["alpha"], surr_after, kl]))
-    # the rank sums ran inside libmjx's C loops (transport hook over gloo; over RCCL on a real multi-GPU node) ...
+    # the rank sums ran inside libmjx's C loops (peer exchange / transport hook here; RCCL on a real multi-GPU node) ...
     res["native_comm"] = np.array([bool(eng._native_comm()), eng.backend.comm_world() == world])
+    res["comm_kind"] = np.array([eng.comm_kind])
     # ... and the whole update as ONE call (mjx_npg_update) gives the same bits as the call-by-call sequence
     eng.set_policy(th, th, ident, ident)
     sa2, kl2 = eng.npg_update(10, 1e-4, 0.05, -3.0)

@@ -271,19 +271,23 @@ def test_shard_sum_parity():
     eng.close()
 
 
-def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
-    """The multi-rank control flow on real kernels: two processes (torch.distributed.run, gloo collectives on device
-    tensors -- RCCL refuses two ranks on one device) share the GPU, each binds a ragged trajectory shard and runs the
-    engine's update sequence (K1 + all-reduce, the per-iteration FVP / all-reduce / CG-step loop, device-side step
-    length, K3 + all-reduce, one read-back).  Result == the one-process update on the whole batch; all ranks hold
-    bit-identical vectors."""
+@pytest.mark.parametrize("transport", ["peer", "hook"])
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport):
+    """The multi-rank control flow on real kernels: two processes (torch.distributed.run) share the GPU, each binds a ragged
+    trajectory shard and runs the engine's update sequence (K1 + rank sum, the per-iteration FVP / rank sum / CG-step loop,
+    device-side step length, K3 + rank sum, one read-back).  transport "peer": libmjx's peer exchange for real -- each process
+    maps the other's buffer through HIP IPC, the Fisher product's reduction kernel stores into both and the stream waits on the
+    arrival counter (no host synchronisation, no gloo in the data path); "hook": the same C loops with the sums handed to
+    dist.all_reduce over gloo (RCCL refuses two ranks on one device).  Result == the one-process update on the whole batch;
+    all ranks hold bit-identical vectors."""
     import subprocess
     import sys
     import torch
     from mjrl_amd.engine import UpdateEngine
     out = str(tmp_path / "two_rank.npz")
     port = 29600 + (os.getpid() % 300)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MJX_PEER_COMM="1" if transport == "peer" else "0")
+    port += 7 if transport == "peer" else 0
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "_two_rank_gpu_worker.py"), out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
@@ -291,6 +295,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     two = np.load(out)
     assert bool(two["ranks_identical"][0])
     assert two["native_comm"].all(), "the rank sums must run inside libmjx's C loops (mjx_cg_solve / mjx_npg_update)"
+    assert str(two["comm_kind"][0]) == transport
     assert bool(two["one_call_equal"][0]), "mjx_npg_update != the call-by-call sequence on two ranks"
     n, m, hid, N = 17, 6, (64, 64), 60000
     rng = np.random.RandomState(5)
