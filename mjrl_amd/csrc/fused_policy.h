@@ -169,6 +169,35 @@ __device__ __forceinline__ void pk_mul_1mh2(f32x16& t, const f32x16& h) {       
     t[r] = tt.x; t[r + 1] = tt.y;
   }
 }
+// The same two as ONE packed FMA per register pair with the negation in the instruction's modifiers: left to the compiler, -h
+// becomes a v_xor_b32 per register (32 extra vector-ALU instructions per cached Fisher-vector-product tile) or the pair is split
+// into scalar v_fma_f32 / v_mul_f32.  Inline asm is invisible to the compiler's hazard recogniser: NO wait states are inserted
+// between an MFMA and an asm instruction that reads its result -- use these only on registers whose producing MFMA retired long
+// ago (a whole MFMA phase in between), never directly behind the producer (the non-cached tile body does that: 2 % wrong and
+// nondeterministic when it was tried there).
+__device__ __forceinline__ f32x2 pk_1mh2_pair_far(f32x2 hh) {
+  f32x2 ff;
+  asm("v_pk_fma_f32 %0, %1, %1, 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(ff) : "v"(hh));
+  return ff;
+}
+__device__ __forceinline__ f32x16 pk_1mh2_far(const f32x16& h) {
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 ff = pk_1mh2_pair_far(f32x2{h[r], h[r + 1]});
+    o[r] = ff.x; o[r + 1] = ff.y;
+  }
+  return o;
+}
+__device__ __forceinline__ void pk_mul_1mh2_far(f32x16& t, const f32x16& h) {
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    f32x2 tt = {t[r], t[r + 1]};
+    const f32x2 ff = pk_1mh2_pair_far(f32x2{h[r], h[r + 1]});
+    asm("v_pk_mul_f32 %0, %0, %1" : "+v"(tt) : "v"(ff));
+    t[r] = tt.x; t[r + 1] = tt.y;
+  }
+}
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
 template <int N, int I = 0, class F>
@@ -657,9 +686,9 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       // ---------------- VA: t1 *= 1 - h1^2 ; f2 = 1 - h2^2   (one burst; R1 retired long ago, R2 does not touch t1)
       // (packed: v_pk_fma_f32 / v_pk_mul_f32 handle two registers per instruction at the price of one in a burst -- probe_fill.hip)
 #pragma unroll
-      for (int mt = 0; mt < MT1; ++mt) pk_mul_1mh2(t1[mt], h1[mt]);
+      for (int mt = 0; mt < MT1; ++mt) pk_mul_1mh2_far(t1[mt], h1[mt]);     // (t1: R1's result, the 64 MFMAs of R2 ago; h1 / h2: loaded)
 #pragma unroll
-      for (int mt = 0; mt < MT2; ++mt) f2s[mt] = pk_1mh2(h2[mt]);
+      for (int mt = 0; mt < MT2; ++mt) f2s[mt] = pk_1mh2_far(h2[mt]);
       __builtin_amdgcn_sched_barrier(0);
       MJX_STAMP(3);
       // ---------------- R3: t2 += W2 t1

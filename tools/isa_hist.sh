@@ -1,7 +1,7 @@
 #!/bin/bash
 # instruction histogram of the tile loop of the cached FVP instance (the largest backward branch span)
 cd /tmp && mkdir -p exp && cd exp
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value --cuda-device-only -S -o mjx.s /root/repo/mjrl_amd/csrc/mjx.hip 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form --cuda-device-only -S -o mjx.s /root/repo/mjrl_amd/csrc/mjx.hip 2>/dev/null
 awk '/^_ZN3mjx7k_fusedILi64ELi64ELi1ELi8ELi1ELb0ELi20ELb1EEEvNS_9FusedArgsE:/,/s_endpgm/' mjx.s > fvp.s
 python3 - <<'PY'
 import re, collections
@@ -21,6 +21,6 @@ for l in body:
     if not l or l.startswith(';') or l.startswith('.') or l.endswith(':'): continue
     c[l.split()[0]]+=1
 print("loop body: %d instructions"%sum(c.values()))
-print(", ".join("%d %s"%(v,k) for k,v in c.most_common(24)))
+print(", ".join("%d %s"%(v,k) for k,v in c.most_common(40)))
 PY
 grep -E "vgpr_count|vgpr_spill|scratch" fvp.s | head -5
