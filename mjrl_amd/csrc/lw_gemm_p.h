@@ -129,7 +129,7 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
   load_next();                             // k-tile 1 (KT >= 2)
   __syncthreads();
 
-  const uint32_t laneC = (uint32_t)(4 * hi) * (uint32_t)g.ldc + (uint32_t)j, laneA = (uint32_t)(4 * hi) * (uint32_t)g.ld_aux + (uint32_t)j;
+  const uint32_t laneC4 = ((uint32_t)(4 * hi) * (uint32_t)g.ldc + (uint32_t)j) * 4u, laneA4 = ((uint32_t)(4 * hi) * (uint32_t)g.ld_aux + (uint32_t)j) * 4u;
   auto rowof = [](int r) { return (r & 3) + 8 * (r >> 2); };
 
 #ifdef MJX_PHASE_CLOCK
@@ -146,6 +146,14 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
 #endif
   for (;;) {
     const int m0 = (t / col_blocks) * GP_BM, n0 = (t % col_blocks) * GP_BN;
+    // buffer resources at this tile's corner of C and of the epilogue's activation operand (raw buffers: stride 0, no bound)
+    const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc((void*)(g.C + (int64_t)m0 * g.ldc + n0), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_aux = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(EPI == EPI_BIAS_TANH ? g.C : g.aux + (int64_t)m0 * g.ld_aux + n0), 0, -1, 0x00020000);
+    // (the scalar offsets below do not depend on the tile: hoisted out of the tile loop they would occupy 128 scalar registers and
+    //  come back as v_readlane spills -- laundering the strides keeps them recomputed per tile on the scalar unit, which is idle)
+    uint32_t ldc4 = (uint32_t)g.ldc * 4u, lda4 = (uint32_t)g.ld_aux * 4u;
+    asm volatile("" : "+s"(ldc4), "+s"(lda4));
     GP_STAMP(0);
 #ifdef MJX_PHASE_CLOCK
     if (g.clk && tid == 0 && t < 16384) { g.clk[8 + 8 * t + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g.clk[8 + 8 * t + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }
@@ -226,9 +234,12 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
              for (int nt = 0; nt < NT; ++nt) {
-               const float* __restrict__ ab = g.aux + (int64_t)(m0 + wm * TM + mt * 32) * g.ld_aux + (n0 + wn * TN + nt * 32);
+               // buffer addressing: resource base (this tile's corner, scalar) + scalar row / block offset + ONE 32-bit lane offset --
+               // no vector-ALU instruction per access (as global_load with 64-bit lane addresses: 137 v_lshl_add_u64 per tile and wave)
+               const uint32_t so = (uint32_t)(wm * TM + mt * 32) * lda4 + (uint32_t)(wn * TN + nt * 32) * 4u;
 #pragma unroll
-               for (int r = 0; r < 16; ++r) yall[(mt * NT + nt) * 16 + r] = (ab + (int64_t)rowof(r) * g.ld_aux)[laneA];
+               for (int r = 0; r < 16; ++r)
+                 yall[(mt * NT + nt) * 16 + r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_aux, laneA4, so + (uint32_t)rowof(r) * lda4, 0));
              }
          });
     ++kt;
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
       for (int nt = 0; nt < NT; ++nt) {
         const int col = n0 + wn * TN + nt * 32 + j;
         const float bias = (EPI == EPI_TANGENT || EPI == EPI_BIAS_TANH) ? g.bias[col] : 0.f;
-        float* __restrict__ cb = g.C + (int64_t)(m0 + wm * TM + mt * 32) * g.ldc + (n0 + wn * TN + nt * 32);
+        const uint32_t so = (uint32_t)(wm * TM + mt * 32) * ldc4 + (uint32_t)(wn * TN + nt * 32) * 4u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float y = (EPI == EPI_BIAS_TANH) ? 0.f : yall[(mt * NT + nt) * 16 + r];
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
           if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
           else if (EPI == EPI_TANGENT) v = (v + bias) * fmaf(-y, y, 1.0f);
           else v = v * fmaf(-y, y, 1.0f);
-          (cb + (int64_t)rowof(r) * g.ldc)[laneC] = v;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r_c, laneC4, so + (uint32_t)rowof(r) * ldc4, 0);
           if (EPI == EPI_BACK) csum[nt] += (m0 + wm * TM + mt * 32 + unit_of(r, hi) < g.M) ? v : 0.f;    // (padding rows of the last tile)
         }
       }

@@ -170,7 +170,7 @@ __device__ __forceinline__ void fit_layer(const float* __restrict__ in, int IS, 
     for (int rr = 0; rr < 4; ++rr) v[rr] = acc[rr] + bu;
     if (act) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) v[rr] = fast_tanh(v[rr]);          // (the fused kernels' tanh: branch-free, 6e-8)
+      for (int rr = 0; rr < 4; ++rr) v[rr] = fast_tanh(v[rr]);          // (the fused kernels' tanh: branch-free, 1.2e-7)
     }
     float* o = out + s0 * OS + u;
 #pragma unroll
