@@ -287,6 +287,12 @@ int mjx_policy_minibatch_adam(mjx_ctx* ctx, int loss, const float* obs, const fl
  * normally page-locked memory that is then sent with one asynchronous copy per group.  No device work. */
 int mjx_host_gather(void* dst, const void* const* src, const int64_t* offsets, int64_t first, int64_t count,
                     int64_t row_bytes, int n_threads);
+/* The same gather for fp64 blocks that the device only needs in fp32 (the policy's observations and actions;
+ * mjrl/algos/batch_reinforce.py:180-181 concatenates fp64, mjrl/policies/gaussian_mlp.py casts to float32 on entry): converts
+ * while copying -- round to nearest even, the bits of ndarray.astype(float32) and of mjx_cast_f64_f32 -- so the block leaves the
+ * host at half its size and needs no device-side cast.  src[i] is rows(i) x row_elems doubles, dst the fp32 staging block. */
+int mjx_host_gather_f64_f32(float* dst, const double* const* src, const int64_t* offsets, int64_t first, int64_t count,
+                            int64_t row_elems, int n_threads);
 
 /* ---- K6: value baselines --------------------------------------------------- */
 /* Feature maps of the reference baselines over the concatenated fp64 observation block

@@ -201,12 +201,17 @@ class BatchREINFORCE:
         allocations must not initialise a context on GPU 0 from a rank that owns another GPU)."""
         eng = self.engine
         torch, dev = eng.torch, eng.device
+        from ..utils.ingest import carried_trust
+        trust = carried_trust()                 # (thread-local too: inside train_step the worker re-uses the staged batch by identity)
         if dev.type != "cuda":
-            return eng.stage_paths
+            def run_cpu(paths, keys):
+                with trust():
+                    return eng.stage_paths(paths, keys)
+            return run_cpu
         cur = torch.cuda.current_stream(dev)
 
         def run(paths, keys):
-            with torch.cuda.device(dev), torch.cuda.stream(cur):
+            with torch.cuda.device(dev), torch.cuda.stream(cur), trust():
                 return eng.stage_paths(paths, keys)
         return run
 

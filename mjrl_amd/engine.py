@@ -331,9 +331,9 @@ class UpdateEngine:
         concatenated host copy, chunked transfers overlapped with the staging copies.  One upload per batch and
         process: the value baselines (predict before, fit after the update) share it (utils/ingest.stage_shared)."""
         if getattr(self, "_stager", None) is not None:             # a caller-supplied stager (tools, tests)
-            return self._stager.stage(paths, keys)
+            return self._stager.stage(paths, keys, hostcast=True)
         from .utils.ingest import stage_shared
-        return {k: v["f32"] for k, v in stage_shared(self.backend, paths, keys).items()}
+        return {k: v["f32"] for k, v in stage_shared(self.backend, paths, keys, raw=()).items()}
 
     def bind_rows(self, rows, adv=None, N_global=None):
         """(re)bind the first `rows` samples of the uploaded block (DAPG runs the Fisher on the

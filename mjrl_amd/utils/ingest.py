@@ -45,16 +45,20 @@ class PathStager:
         self._lock = threading.Lock()
 
     # ------------------------------------------------------------------ buffers
-    def _slot(self, key, width, dtype, rows):
+    def _slot(self, key, width, dtype, rows, hostcast=False):
         """the page-locked staging block is kept across batches; the device tensors are allocated per batch (torch's
-        caching allocator recycles the memory), so tensors handed out for an earlier batch stay valid while referenced"""
+        caching allocator recycles the memory), so tensors handed out for an earlier batch stay valid while referenced.
+        hostcast: fp64 paths are converted to fp32 by the gather itself (mjx_host_gather_f64_f32) -- the staging block and the
+        upload are fp32, there is no raw fp64 device block"""
         torch = self.torch
         s = self._slots.get(key)
-        tdt = torch.float64 if dtype == np.float64 else torch.float32
-        if s is None or s["width"] != width or s["dtype"] != dtype or s["cap"] < rows:
-            cap = max(rows, int(1.25 * (s["cap"] if s and s["width"] == width and s["dtype"] == dtype else 0)))
+        hostcast = bool(hostcast and dtype == np.float64 and self.native)
+        tdt = torch.float64 if (dtype == np.float64 and not hostcast) else torch.float32
+        if s is None or s["width"] != width or s["dtype"] != dtype or s["cap"] < rows or s.get("hostcast", False) != hostcast:
+            same = s and s["width"] == width and s["dtype"] == dtype and s.get("hostcast", False) == hostcast
+            cap = max(rows, int(1.25 * (s["cap"] if same else 0)))
             pin = torch.empty((cap, width), dtype=tdt, pin_memory=self.on_gpu)
-            s = dict(pin=pin, pin_np=pin.numpy(), width=width, dtype=dtype, cap=cap)
+            s = dict(pin=pin, pin_np=pin.numpy(), width=width, dtype=dtype, cap=cap, hostcast=hostcast)
             self._slots[key] = s
         if self.on_gpu:
             s["dev_raw"] = torch.empty((rows, width), dtype=tdt, device=self.device)
@@ -65,13 +69,14 @@ class PathStager:
         return s
 
     # ------------------------------------------------------------------ incremental interface
-    def begin(self, keys, widths, dtypes, capacity):
-        """start a batch of at most `capacity` rows; keys e.g. ("observations", "actions")"""
+    def begin(self, keys, widths, dtypes, capacity, hostcast=()):
+        """start a batch of at most `capacity` rows; keys e.g. ("observations", "actions"); hostcast: the keys whose fp64
+        arrays only have to reach the device as fp32 (no raw block)"""
         if self.on_gpu:
             self.side.synchronize()             # the previous batch's transfers have left the staging block
         self._keys = tuple(keys)
         for k, w, dt in zip(keys, widths, dtypes):
-            self._slot(k, int(w), np.dtype(dt).type, int(capacity))
+            self._slot(k, int(w), np.dtype(dt).type, int(capacity), hostcast=(hostcast is True or k in hostcast))
         self._rows = 0
         self._pending = []
         if self.on_gpu:
@@ -143,7 +148,10 @@ class PathStager:
                 s = self._slots[k]
                 row_bytes = s["width"] * s["pin"].element_size()
                 dst = ctypes.c_void_p(s["pin"].data_ptr() + row0 * row_bytes)
-                check(self.lib.mjx_host_gather(dst, srcs[k], offp, first, last - first, row_bytes, self.native_threads))
+                if s["hostcast"]:
+                    check(self.lib.mjx_host_gather_f64_f32(dst, srcs[k], offp, first, last - first, s["width"], self.native_threads))
+                else:
+                    check(self.lib.mjx_host_gather(dst, srcs[k], offp, first, last - first, row_bytes, self.native_threads))
             self._send(row0 + int(offs[first]), row0 + int(offs[last]))
             first = last
         self._rows += total
@@ -187,16 +195,18 @@ class PathStager:
         return {k: self._slots[k]["dev_f32"][:self._rows] for k in self._keys}
 
     def raw(self, key):
-        """the batch as it was uploaded (fp64 when the paths are fp64): what the value baselines' feature kernels read"""
-        return self._slots[key]["dev_raw"][:self._rows]
+        """the batch as it was uploaded (fp64 when the paths are fp64): what the value baselines' feature kernels read.
+        None for a key staged with hostcast (its fp64 values never reached the device)."""
+        s = self._slots[key]
+        return None if s["hostcast"] else s["dev_raw"][:self._rows]
 
     # ------------------------------------------------------------------ one-shot
-    def stage(self, paths, keys=("observations", "actions"), wait=True):
+    def stage(self, paths, keys=("observations", "actions"), wait=True, hostcast=()):
         first = paths[0]
         widths = [first[k].shape[1] if first[k].ndim == 2 else 1 for k in keys]
         dtypes = [np.float64 if first[k].dtype == np.float64 else np.float32 for k in keys]
         rows = sum(len(p[keys[0]]) for p in paths)
-        self.begin(keys, widths, dtypes, rows)
+        self.begin(keys, widths, dtypes, rows, hostcast=hostcast)
         self.add_paths(paths)
         return self.finish(wait)
 
@@ -341,6 +351,12 @@ def _trusted():
     return getattr(_TRUST, "depth", 0) > 0
 
 
+def carried_trust():
+    """the scope of the CALLING thread for a helper thread working on its behalf (the flag is thread-local): call it where the
+    job is submitted, enter the returned context inside the job"""
+    return trusted_iteration if _trusted() else contextlib.nullcontext
+
+
 def _same_batch(ent, paths, key):
     """is `paths` the very batch `ent` uploaded?  Identity of the list AND of every per-path array, against STRONG
     references the entry holds (an id() can be recycled once the objects are freed; a held object's cannot), plus a
@@ -355,42 +371,62 @@ def _same_batch(ent, paths, key):
     for i, pr in zip(_probed(len(arrays)), ent["probes"]):
         if _probe(arrays[i]) != pr:
             return False
-    if not _trusted() and ent.get("f32") is not None and ent.get("stager") is not None:
-        st = ent["stager"]
+    if not _trusted() and ent.get("f32") is not None and ent.get("active") is not None:
+        st = ent["active"]
         slot = st._slots.get(key)
         if slot is None:
             return False
         host, o = slot["pin_np"], 0
         for a in arrays:
             T = len(a)
-            if not np.array_equal(a if a.ndim == 2 else a.reshape(T, -1), host[o:o + T]):
+            a2 = a if a.ndim == 2 else a.reshape(T, -1)
+            if slot["hostcast"]:                       # staged as fp32: compare what the conversion of today's values gives
+                a2 = a2.astype(np.float32)
+            if not np.array_equal(a2, host[o:o + T]):
                 return False
             o += T
     return True
 
 
-def stage_shared(backend, paths, keys):
+_RAW_STICKY = set()          # (device type, index, key): some consumer asked for the raw block of this key before
+
+
+def stage_shared(backend, paths, keys, raw=None):
     """-> dict key -> dict(f32=(N, w) fp32 device tensor, raw=(N, w) tensor in the paths' dtype).  Re-uses the upload
     of the same `paths` list (the same list object holding the same array objects, see _same_batch) made earlier in
-    this process on this device; train_step drops the entries when its iteration ends (drop_shared_batch)."""
+    this process on this device; train_step drops the entries when its iteration ends (drop_shared_batch).
+    raw: the keys whose block the caller needs in the paths' own dtype (None: all of them).  A key nobody has ever asked the
+    raw block of is converted to fp32 by the host gather and uploaded at half its size (raw = None in the result); the first
+    raw request for such a key stages it again in full -- and is remembered, so later batches go up raw at once and serve both."""
     dev = backend.device
     out = {}
     for k in keys:
+        need_raw = raw is None or k in raw
+        tag = (dev.type, dev.index, k)
         with _key_lock(dev, k):
             with _SHARED_LOCK:
                 reg = _SHARED.setdefault((dev.type, dev.index), {})
                 ent = reg.get(k)
-            if ent is None or ent.get("paths") is None or not _same_batch(ent, paths, k):
-                st = ent.get("stager") if ent is not None else None
+                if need_raw:
+                    _RAW_STICKY.add(tag)
+                as_raw = tag in _RAW_STICKY
+            stale = ent is None or ent.get("paths") is None or not _same_batch(ent, paths, k)
+            if stale or (need_raw and ent["raw"] is None):
+                # one stager per mode and key: their page-locked blocks persist, a flow that alternates never re-allocates
+                skey = "stager" if as_raw else "stager32"
+                st = ent.get(skey) if ent is not None else None
                 if st is None:
                     st = PathStager(backend)
-                f32 = st.stage(paths, (k,), wait=False)[k]
+                f32 = st.stage(paths, (k,), wait=False, hostcast=() if as_raw else True)[k]
                 ready = None
                 if st.on_gpu:
                     ready = backend.torch.cuda.Event()
                     ready.record(st.side)
                 arrays = [p[k] for p in paths]
-                ent = dict(stager=st, f32=f32, raw=st.raw(k), paths=paths, arrays=arrays, probes=_probes(arrays), ready=ready)
+                new = dict(stager=ent.get("stager") if ent else None, stager32=ent.get("stager32") if ent else None, f32=f32,
+                           raw=st.raw(k), paths=paths, arrays=arrays, probes=_probes(arrays), ready=ready)
+                new[skey] = new["active"] = st
+                ent = new
                 with _SHARED_LOCK:
                     reg[k] = ent
             _order_after(backend, ent)
@@ -401,7 +437,7 @@ def stage_shared(backend, paths, keys):
 _PREFETCH_POOL = None
 
 
-def prefetch(backend, paths, keys):
+def prefetch(backend, paths, keys, raw=()):
     """start staging paths[.][key] for `keys` on a helper thread (native gather threads + asynchronous copies on the
     stagers' side streams, no GIL for the bulk of it) and return at once: whoever asks for those blocks later in the
     iteration (stage_shared / lookup) finds them staged or waits for exactly the block it needs.  The helper adopts
@@ -414,11 +450,12 @@ def prefetch(backend, paths, keys):
     if _PREFETCH_POOL is None:
         _PREFETCH_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mjx-prefetch")
     cur = torch.cuda.current_stream(dev)
+    trust = carried_trust()
 
     def run():
         try:
-            with torch.cuda.device(dev), torch.cuda.stream(cur):
-                stage_shared(backend, paths, keys)
+            with torch.cuda.device(dev), torch.cuda.stream(cur), trust():
+                stage_shared(backend, paths, keys, raw=raw)     # (keys with a raw consumer earlier in the process go up raw: _RAW_STICKY)
         except Exception:                     # pragma: no cover
             pass
     return _PREFETCH_POOL.submit(run)
@@ -441,8 +478,8 @@ def publish(backend, paths, key, raw, arrays):
     with _SHARED_LOCK:
         reg = _SHARED.setdefault((dev.type, dev.index), {})
         old = reg.get(key)
-        reg[key] = dict(stager=old.get("stager") if old else None, f32=None, raw=raw, paths=paths, arrays=list(arrays),
-                        probes=_probes(arrays))
+        reg[key] = dict(stager=old.get("stager") if old else None, stager32=old.get("stager32") if old else None, active=None,
+                        f32=None, raw=raw, paths=paths, arrays=list(arrays), probes=_probes(arrays))
 
 
 def lookup(backend, paths, key):
@@ -465,9 +502,11 @@ def host_block(backend, paths, key):
     with _key_lock(dev, key):
         with _SHARED_LOCK:
             ent = _SHARED.get((dev.type, dev.index), {}).get(key)
-        if ent is None or ent.get("paths") is None or ent.get("stager") is None or ent.get("f32") is None or not _same_batch(ent, paths, key):
+        if ent is None or ent.get("paths") is None or ent.get("active") is None or ent.get("f32") is None or not _same_batch(ent, paths, key):
             return None
-        st = ent["stager"]
+        st = ent["active"]
+        if st._slots[key]["hostcast"]:                 # staged as fp32: no host copy in the paths' dtype
+            return None
         return st._slots[key]["pin_np"][:st._rows]
 
 
@@ -495,7 +534,7 @@ def drop_shared_batch():
         for reg in _SHARED.values():
             for ent in reg.values():
                 ent["paths"] = ent["arrays"] = ent["probes"] = None
-                ent["f32"] = ent["raw"] = None
+                ent["f32"] = ent["raw"] = ent["active"] = None
                 ent.pop("derived", None)
 
 
@@ -504,6 +543,8 @@ def drop_shared():
     with _SHARED_LOCK:
         for reg in _SHARED.values():
             for ent in reg.values():
-                if ent.get("stager") is not None:
-                    ent["stager"].close()
+                for sk in ("stager", "stager32"):
+                    if ent.get(sk) is not None:
+                        ent[sk].close()
         _SHARED.clear()
+        _RAW_STICKY.clear()

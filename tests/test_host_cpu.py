@@ -209,6 +209,18 @@ def test_path_stager_matches_concatenate_cpu():
         st.add_paths(p32[2:])
         out = st.finish()
         np.testing.assert_array_equal(out["observations"].numpy(), np.concatenate([p["observations"] for p in p32]))
+        # host-cast mode: the gather converts fp64 -> fp32 itself (mjx_host_gather_f64_f32): same bits as astype, no raw block
+        if native:
+            big = [dict(observations=rng.randn(T, 17) * 10.0 ** rng.randint(-30, 30, size=(T, 17)), actions=rng.randn(T, 6)) for T in (50000, 3, 70000)]
+            big[0]["observations"][0, :4] = [np.inf, -np.inf, 1e-46, 3.4028235677973366e38]     # overflow / denormal / rounds-to-inf edge values
+            out = st.stage(big, hostcast=True)
+            np.testing.assert_array_equal(out["observations"].numpy(), np.concatenate([p["observations"] for p in big]).astype(np.float32))
+            np.testing.assert_array_equal(out["actions"].numpy(), np.concatenate([p["actions"] for p in big]).astype(np.float32))
+            assert st.raw("observations") is None and st._slots["observations"]["pin"].dtype == torch.float32
+            out = st.stage(big, hostcast=("actions",))                # per key: observations keep their fp64 block
+            assert st.raw("observations").dtype == torch.float64 and st.raw("actions") is None
+            np.testing.assert_array_equal(st.raw("observations").numpy(), np.concatenate([p["observations"] for p in big]))
+            np.testing.assert_array_equal(out["observations"].numpy(), np.concatenate([p["observations"] for p in big]).astype(np.float32))
         # capacity is enforced
         st.begin(("observations", "actions"), (5, 2), (np.float64, np.float64), 10)
         with pytest.raises(ValueError):
@@ -297,4 +309,55 @@ def test_staged_batch_registry_identity_rules():
     assert ingest.lookup(h, paths, "observations") is None
     f = ingest.stage_shared(h, paths, ("observations",))["observations"]       # after the drop everything is staged afresh
     np.testing.assert_array_equal(f["raw"].numpy(), np.concatenate([p["observations"] for p in paths]))
+    ingest.drop_shared()
+
+
+def test_trusted_scope_reaches_the_helper_threads():
+    """train_step's trusted scope is thread-local; the staging helper of _process_and_bind and the prefetch thread work on the
+    caller's behalf and must inherit it (left untrusted they re-verified 184 MB element by element per iteration: 15 ms at 1M)."""
+    import threading
+    from mjrl_amd.utils import ingest
+    seen = {}
+
+    def job(trust):
+        with trust():
+            seen["helper"] = ingest._trusted()
+    with ingest.trusted_iteration():
+        t = threading.Thread(target=job, args=(ingest.carried_trust(),)); t.start(); t.join()
+    assert seen["helper"] is True
+    t = threading.Thread(target=job, args=(ingest.carried_trust(),)); t.start(); t.join()
+    assert seen["helper"] is False
+
+
+def test_raw_blocks_are_uploaded_on_demand():
+    """utils/ingest.stage_shared(raw=...): a key whose raw (fp64) block nobody asked for goes up as fp32 only (converted by the
+    native gather); the first raw request stages it again in full and is remembered for later batches; the in-place-edit
+    rule holds for fp32-staged blocks too."""
+    import torch
+    from mjrl_amd import _lib
+    from mjrl_amd.utils import ingest
+    ingest.drop_shared()
+    h = ingest.DeviceHandle(torch, torch.device("cpu"), _lib.load())
+    rng = np.random.RandomState(2)
+    paths = [dict(observations=rng.randn(T, 5), actions=rng.randn(T, 2)) for T in (40, 3, 11)]
+    cat = lambda k: np.concatenate([p[k] for p in paths])
+    a = ingest.stage_shared(h, paths, ("observations", "actions"), raw=())
+    assert a["observations"]["raw"] is None and a["actions"]["raw"] is None
+    np.testing.assert_array_equal(a["observations"]["f32"].numpy(), cat("observations").astype(np.float32))
+    assert ingest.host_block(h, paths, "observations") is None                     # no host copy in the paths' dtype
+    b = ingest.stage_shared(h, paths, ("observations",), raw=())["observations"]
+    assert b["f32"] is a["observations"]["f32"]                                   # same batch: one upload
+    c = ingest.stage_shared(h, paths, ("observations",))["observations"]          # a consumer of the raw block: staged again, in full
+    np.testing.assert_array_equal(c["raw"].numpy(), cat("observations"))
+    np.testing.assert_array_equal(c["f32"].numpy(), cat("observations").astype(np.float32))
+    d = ingest.stage_shared(h, paths, ("observations",), raw=())["observations"]
+    assert d["raw"] is c["raw"] and d["f32"] is c["f32"]                          # ... and serves the fp32 consumers from then on
+    paths2 = [dict(observations=rng.randn(T, 5), actions=rng.randn(T, 2)) for T in (5, 6)]
+    e = ingest.stage_shared(h, paths2, ("observations", "actions"), raw=())
+    assert e["observations"]["raw"] is not None and e["actions"]["raw"] is None   # remembered per key
+    # an in-place edit of an fp32-staged array is caught by the exact rule
+    paths2[1]["actions"][2, 1] += 0.5
+    f = ingest.stage_shared(h, paths2, ("actions",), raw=())["actions"]
+    assert f["f32"] is not e["actions"]["f32"]
+    assert f["f32"][5 + 2, 1].item() == np.float32(paths2[1]["actions"][2, 1])
     ingest.drop_shared()

@@ -1,5 +1,7 @@
 """Device-side cost of one training iteration at 1M timesteps (everything train_step does after sampling,
-mjrl/algos/batch_reinforce.py:93-114): returns, baseline prediction + GAE, the NPG update, the baseline fit."""
+mjrl/algos/batch_reinforce.py:93-114): returns, baseline prediction + GAE, the NPG update, the baseline fit -- under
+ingest.trusted_iteration() like train_step itself (outside it every reuse of a staged block is re-verified against the host
+arrays element by element, the rule for callers who may edit paths in place: tens of ms per iteration at this size)."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,7 +10,7 @@ from mjrl_amd.algos.npg_cg import NPG
 from mjrl_amd.baselines.mlp_baseline import MLPBaseline
 from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
 from mjrl_amd.policies.gaussian_mlp import MLP
-from mjrl_amd.utils import process_samples
+from mjrl_amd.utils import ingest, process_samples
 spec = type("Spec", (), dict(observation_dim=17, action_dim=6, horizon=1000))
 rng = np.random.RandomState(0)
 out = {}
@@ -20,10 +22,12 @@ for name in ("quadratic", "mlp"):
     for it in range(7):
         paths = [dict(observations=rng.randn(1000, 17), actions=rng.randn(1000, 6), rewards=rng.randn(1000), terminated=False) for _ in range(1000)]
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        process_samples.compute_returns(paths, 0.995); t1 = time.perf_counter()
-        process_samples.compute_advantages(paths, bl, 0.995, 0.97); t2 = time.perf_counter()
-        agent.train_from_paths(paths); torch.cuda.synchronize(); t3 = time.perf_counter()
-        bl.fit(paths); torch.cuda.synchronize(); t4 = time.perf_counter()
+        with ingest.trusted_iteration():
+            process_samples.compute_returns(paths, 0.995); t1 = time.perf_counter()
+            process_samples.compute_advantages(paths, bl, 0.995, 0.97); t2 = time.perf_counter()
+            agent.train_from_paths(paths); torch.cuda.synchronize(); t3 = time.perf_counter()
+            bl.fit(paths); torch.cuda.synchronize(); t4 = time.perf_counter()
+        ingest.drop_shared_batch()
         ts.append([t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0])
     best = min(ts[1:], key=lambda r: r[-1])
     out[name] = dict(zip(["returns_ms", "advantages_ms", "update_ms", "baseline_fit_ms", "total_ms"], [round(1e3 * x, 2) for x in best]))
