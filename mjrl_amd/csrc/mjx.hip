@@ -964,7 +964,7 @@ int mjx_dapg_update(mjx_ctx* c, int iters, float damping, double tol, double ste
                     int64_t N_on_global, const float* adv_on, float* grad_out, float* x_out, float* theta_out, double* results,
                     void* stream) {
   if (int rc = check_bound(c, true)) return rc;
-  if (!grad_out || !x_out || !theta_out || !results || !adv_on || iters < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (!grad_out || !x_out || !theta_out || !results || (!adv_on && rows_on > 0) || iters < 0) return fail(MJX_ERR_ARG, "bad arguments");   // (a rank without on-policy rows has no advantages)
   if (!c->old_is_new) return fail(MJX_ERR_STATE, "mjx_dapg_update starts from theta_new == theta_old (mjx_bind_policy with old_is_new)");
   if (theta_out == c->theta_old) return fail(MJX_ERR_ARG, "theta_out must not alias theta_old");
   if (rows_on < 0 || rows_on > c->N_local || N_on_global <= 0 || N_on_global > c->N_global) return fail(MJX_ERR_ARG, "bad on-policy row counts");

@@ -23,7 +23,7 @@ def main():
     n, m, hid, N = 17, 6, (64, 64), 60000
     rng = np.random.RandomState(5)                       # identical on all ranks
     obs, act, adv = rng.randn(N, n).astype(np.float32), rng.randn(N, m).astype(np.float32), rng.randn(N).astype(np.float32)
-    cut = 23456                                          # ragged shards
+    cut = int(os.environ.get("MJX_TEST_CUT", "23456"))   # ragged shards (0: rank 0 holds NO trajectories)
     lo, hi = (0, cut) if rank == 0 else (cut, N)
     th = synth.perturbed_params(synth.init_params(n, m, hid))
     ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
@@ -53,9 +53,21 @@ def main():
     tr = eng.trpo_update(10, 1e-4, 0.02, 0.002, -3.0)
     res["trpo"] = np.array([tr["alpha"], tr["trials"], tr["kl"], tr["surr_after"], float(tr["accepted"])])
     res["trpo_theta"] = eng.theta_new.cpu().numpy()
+    # DAPG as one call (mjx_dapg_update): K1 over [on-policy ; demonstrations] of this rank, the Fisher / surrogate on the on-policy
+    # prefix; every rank appends its share of the demonstrations (here: the last 500 rows of its shard play that part)
+    n_demo = min(500, hi - lo)
+    n_on = (hi - lo) - n_demo
+    eng.set_policy(th, th, ident, ident)
+    adv_all = np.concatenate([adv[lo:lo + n_on], 0.01 * np.ones(n_demo, np.float32)])
+    eng.set_batch(obs[lo:hi], act[lo:hi], adv_all)
+    n_on_global, n_all_global = eng.global_count(n_on), eng.N_global
+    dres = eng.dapg_update(10, 1e-4, 0.05, -3.0, n_on, adv[lo:lo + n_on], N_on_global=n_on_global)
+    res["dapg"] = np.array([np.nan, np.nan] if dres is None else list(dres))
+    res["dapg_theta"] = eng.theta_new.cpu().numpy()
+    res["dapg_counts"] = np.array([n_on_global, n_all_global])
     # every rank must hold identical results (the CG scalars are recomputed redundantly from the reduced vectors)
     t = torch.from_numpy(np.concatenate([res["x"], res["theta"], res["scal"].astype(np.float32), res["trpo_theta"],
-                                         res["trpo"].astype(np.float32)])).cuda()
+                                         res["trpo"].astype(np.float32), res["dapg_theta"], res["dapg"].astype(np.float32)])).cuda()
     lo_t, hi_t = t.clone(), t.clone()
     dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)

@@ -271,23 +271,26 @@ def test_shard_sum_parity():
     eng.close()
 
 
-@pytest.mark.parametrize("transport", ["peer", "hook"])
-def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport):
+@pytest.mark.parametrize("transport,cut", [("peer", 23456), ("hook", 23456), ("peer", 0)])
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport, cut):
     """The multi-rank control flow on real kernels: two processes (torch.distributed.run) share the GPU, each binds a ragged
     trajectory shard and runs the engine's update sequence (K1 + rank sum, the per-iteration FVP / rank sum / CG-step loop,
     device-side step length, K3 + rank sum, one read-back).  transport "peer": libmjx's peer exchange for real -- each process
     maps the other's buffer through HIP IPC, the Fisher product's reduction kernel stores into both and the stream waits on the
     arrival counter (no host synchronisation, no gloo in the data path); "hook": the same C loops with the sums handed to
-    dist.all_reduce over gloo (RCCL refuses two ranks on one device).  Result == the one-process update on the whole batch;
-    all ranks hold bit-identical vectors."""
+    dist.all_reduce over gloo (RCCL refuses two ranks on one device).  cut = 0: rank 0 holds no trajectories at all -- it runs the
+    exchange through the generic path (zeros into every buffer) while rank 1 runs it folded into its reduction / vector-update
+    kernels.  Result == the one-process update on the whole batch (NPG call by call and as one call, TRPO with the device-side
+    line search, DAPG as one call); all ranks hold bit-identical vectors."""
     import subprocess
     import sys
     import torch
     from mjrl_amd.engine import UpdateEngine
     out = str(tmp_path / "two_rank.npz")
     port = 29600 + (os.getpid() % 300)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MJX_PEER_COMM="1" if transport == "peer" else "0")
-    port += 7 if transport == "peer" else 0
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MJX_PEER_COMM="1" if transport == "peer" else "0",
+               MJX_TEST_CUT=str(cut))
+    port += (7 if transport == "peer" else 0) + (13 if cut == 0 else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "_two_rank_gpu_worker.py"), out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
@@ -321,6 +324,21 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport):
     assert two["trpo"][4] == 1.0 and tr["accepted"] and int(two["trpo"][1]) == tr["trials"] and tr["trials"] > 3
     np.testing.assert_allclose(two["trpo"][[0, 2, 3]], [tr["alpha"], tr["kl"], tr["surr_after"]], rtol=2e-5, atol=1e-7)
     assert rel(two["trpo_theta"], eng.theta_new.cpu().numpy()) < 1e-6
+    # DAPG: the ranks' blocks are [on-policy ; demonstrations] each; one rank sees the same rows as [all on-policy ; all demonstrations]
+    los, his = (0, cut), (cut, N)
+    on_idx, demo_idx = [], []
+    for lo, hi in (los, his):
+        n_demo = min(500, hi - lo)
+        on_idx += list(range(lo, hi - n_demo)); demo_idx += list(range(hi - n_demo, hi))
+    idx = np.array(on_idx + demo_idx)
+    n_on = len(on_idx)
+    assert list(two["dapg_counts"]) == [n_on, N]
+    adv_all = np.concatenate([adv[on_idx], 0.01 * np.ones(len(demo_idx), np.float32)])
+    eng.set_policy(th, th, ident, ident)
+    eng.set_batch(obs[idx], act[idx], adv_all)
+    dres = eng.dapg_update(10, 1e-4, 0.05, -3.0, n_on, adv[on_idx])
+    np.testing.assert_allclose(two["dapg"], list(dres), rtol=2e-5, atol=1e-7)
+    assert rel(two["dapg_theta"], eng.theta_new.cpu().numpy()) < 1e-6
     eng.close()
 
 
