@@ -394,6 +394,49 @@ def test_rccl_inside_libmjx_one_rank_group():
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1:] == res[1][1:]
 
 
+@pytest.mark.parametrize("world", [2, 8, 16])
+def test_peer_exchange_in_loop_back_gives_the_single_rank_bits(world):
+    """libmjx's peer exchange with every "peer" mapped onto this rank's own buffer (mjx_peer_connect(NULL)): the stores into
+    `world` buffers, the arrival counters, the bounded waits and the `world`-slot sums (2 / 8 / 16-slot instances of the folded
+    vector update) all execute, the sums see this rank's vector + zeros -> NPG, TRPO and plain all-reduces give the bits of a
+    context without a transport.  Also the call-order rules of mjx_peer_export / mjx_peer_connect."""
+    import ctypes
+    import torch
+    from mjrl_amd import _lib
+    from mjrl_amd.engine import UpdateEngine
+    c = NpgCase("npg_cfg2_small")
+    tr = np.concatenate([np.zeros(c.n), np.ones(c.n), np.zeros(c.m), np.ones(c.m)]).astype(np.float32)
+    res = []
+    for with_peer in (False, True):
+        eng = UpdateEngine(c.n, c.m, c.hidden)
+        lib, ctx = eng.backend.lib, eng.backend.ctx
+        if with_peer:
+            h = ctypes.create_string_buffer(64)
+            assert lib.mjx_peer_connect(ctx, None) != 0                       # connect before export
+            assert lib.mjx_peer_export(ctx, 0, 1, h) != 0 and lib.mjx_peer_export(ctx, 0, 17, h) != 0 and lib.mjx_peer_export(ctx, 3, 2, h) != 0
+            _lib.check(lib.mjx_peer_export(ctx, 0, world, h))
+            assert lib.mjx_peer_export(ctx, 0, world, h) != 0                 # a transport is already attached
+            _lib.check(lib.mjx_peer_connect(ctx, None))
+            assert lib.mjx_peer_connect(ctx, None) != 0                       # once
+            assert eng.backend.comm_world() == world
+            t = torch.arange(7, dtype=torch.float32, device=eng.device) + 0.5
+            t64 = torch.arange(5, dtype=torch.float64, device=eng.device) - 2.25
+            for _ in range(3):                                                # (both parities of the slot pairs)
+                eng.backend.allreduce(t); eng.backend.allreduce(t64)
+            torch.cuda.synchronize()
+            assert torch.equal(t.cpu(), torch.arange(7, dtype=torch.float32) + 0.5) and torch.equal(t64.cpu(), torch.arange(5, dtype=torch.float64) - 2.25)
+        eng.set_policy(c.theta0, c.theta0, tr, tr)
+        eng.set_batch(c.obs, c.act, c.adv_w)
+        sa, kl = eng.npg_update(c.cg_iters, 1e-4, float(c.g["step"]), -3.0)
+        th_npg = eng.theta_new.cpu().numpy().copy()
+        eng.set_policy(c.theta0, c.theta0, tr, tr)
+        t2 = eng.trpo_update(c.cg_iters, 1e-4, 0.02, 0.002, -3.0)
+        res.append((th_npg, sa, kl, eng.theta_new.cpu().numpy().copy(), t2["trials"], t2["alpha"], t2["kl"]))
+        eng.close()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1:3] == res[1][1:3]
+    assert np.array_equal(res[0][3], res[1][3]) and res[0][4:] == res[1][4:]
+
+
 def test_upload_download_never_touch_pageable_memory_and_round_trip():
     """utils/ingest.upload / download: host <-> device through page-locked bounce buffers (pageable
     hipMemcpy of ~1 MB and more leaves userptr registrations behind that later stall the GPU queues), bit-exact for the
