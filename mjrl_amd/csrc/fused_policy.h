@@ -83,6 +83,16 @@ struct FusedArgs {
 // hipcc from pairing them into ds_read2 / ds_write2 -- whose 8-bit offset fields cost a vector add per pair to re-base the
 // address, 48 per tile -- and saves 2.5 % of the kernel's cycles, but the chip gives the same 2.5 % back in clock: no
 // change in time, and hipcc 7.2 crashes on the volatile form in one instance.  Plain accesses it is.)
+typedef __attribute__((address_space(3))) float lds_float;
+// LDS byte address of a shared-memory pointer as an opaque 32-bit value: the compiler must keep it in a register (it would
+// otherwise re-derive `base + constant` with a v_add_u32 next to every ds_write2 / ds_read2 whose 8-bit offsets do not reach --
+// ~25 single vector-ALU instructions inside the MFMA phases of a cached Fisher-vector-product tile, 12 cycles each there)
+__device__ __forceinline__ uint32_t lds_pin(const float* p) {
+  uint32_t a = (uint32_t)(uintptr_t)(const lds_float*)p;
+  asm volatile("" : "+v"(a));
+  return a;
+}
+#define LDS_AT(addr) ((lds_float*)(uintptr_t)(addr))
 #define LDS_ST(p, v) (*(p) = (v))
 #define LDS_LD(p) (*(p))
 #define LDS_LD2(p) (*(const f32x2*)(p))
@@ -549,6 +559,20 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   };
 
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  // cached FVP: this lane's address in row group g (rows 8 g + 4 hi .. + 3) of the two transposed tiles, pinned in registers
+  uint32_t pinA[XCACHED ? 4 * MT2 : 1], pinB[XCACHED ? 4 * MT1 : 1];
+  if constexpr (XCACHED) {
+#pragma unroll
+    for (int g = 0; g < 4 * MT2; ++g) pinA[g] = lds_pin(&bufA[(8 * g + 4 * hi) * ST + j]);
+#pragma unroll
+    for (int g = 0; g < 4 * MT1; ++g) pinB[g] = lds_pin(&bufB[(8 * g + 4 * hi) * ST + j]);
+  }
+  // ... and in the k-groups of W2's rows the delta1 phase reads (rows 8 g + 4 hi .. + 3 of the NEW parameters' slot, columns j, 32 + j)
+  uint32_t pinW[XCACHED ? 4 * MT2 : 1];
+  if constexpr (XCACHED) {
+#pragma unroll
+    for (int g = 0; g < 4 * MT2; ++g) pinW[g] = lds_pin(&slotA[L.oW2 + (8 * g + 4 * hi) * S2 + j]);
+  }
   const bool rev = XCACHED && A.reverse;
   auto ptile = [&](int64_t t) { return rev ? ntiles - 1 - t : t; };          // logical -> physical tile of this launch
   if (!XCACHED && !use_xi && tile < ntiles) load_x(tile);
@@ -652,12 +676,12 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
           for (int e = 0; e < R1; ++e) {
             const int idx = st * R1 + e, mt = idx >> 4, r = idx & 15;
-            LDS_ST(&bufB[(32 * mt + unit_of(r, hi)) * ST + j], h1[mt][r]);
+            LDS_AT(pinB[4 * mt + (r >> 2)])[(r & 3) * ST] = h1[mt][r];          // row 32 mt + unit_of(r, hi) = 8 (4 mt + r / 4) + 4 hi + r % 4
           }
 #pragma unroll
           for (int e = 0; e < R2; ++e) {
             const int idx = st * R2 + e, mt = idx >> 4, r = idx & 15;
-            LDS_ST(&bufA[(32 * mt + unit_of(r, hi)) * ST + j], h2[mt][r]);
+            LDS_AT(pinA[4 * mt + (r >> 2)])[(r & 3) * ST] = h2[mt][r];
           }
 #pragma unroll
           for (int mt = 0; mt < MT2; ++mt) vc[mt] = vn[mt];
@@ -818,7 +842,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int nt = 0; nt < MT1; ++nt) wc8[t][nt] = LDS_LD(&slotA[L.oW2 + (4 * hi + t) * S2 + 32 * nt + j]);
+          for (int nt = 0; nt < MT1; ++nt) wc8[t][nt] = LDS_AT(pinW[0])[t * S2 + 32 * nt];
       }
       __builtin_amdgcn_sched_barrier(0);
       MJX_STAMP(7);
@@ -852,7 +876,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-              for (int nt = 0; nt < MT1; ++nt) wn[t][nt] = LDS_LD(&slotA[L.oW2 + (32 * kb1 + 8 * q1 + 4 * hi + t) * S2 + 32 * nt + j]);
+              for (int nt = 0; nt < MT1; ++nt) wn[t][nt] = LDS_AT(pinW[4 * kb1 + q1])[t * S2 + 32 * nt];
           }
 #pragma unroll
           for (int t = 0; t < 4; ++t)
@@ -864,7 +888,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
             for (int e = 0; e < RS; ++e) {
               const int idx = g * RS + e, mt = idx >> 4, r = idx & 15;
-              LDS_ST(&bufA[(32 * mt + unit_of(r, hi)) * ST + j], dl2s[mt][r]);
+              LDS_AT(pinA[4 * mt + (r >> 2)])[(r & 3) * ST] = dl2s[mt][r];
             }
           } else {
             // ... and of the read-back: delta2[sample unit_of(4 qq + t, hi)][unit 32 nt + j], one ds_read_b128 per (nt, qq)
