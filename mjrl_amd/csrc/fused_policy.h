@@ -559,17 +559,19 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   };
 
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  // cached FVP: this lane's address in row group g (rows 8 g + 4 hi .. + 3) of the two transposed tiles, pinned in registers
-  uint32_t pinA[XCACHED ? 4 * MT2 : 1], pinB[XCACHED ? 4 * MT1 : 1];
-  if constexpr (XCACHED) {
+  // cached FVP and K1 (the instances with registers to spare): this lane's address in row group g (rows 8 g + 4 hi .. + 3) of
+  // the two transposed tiles, pinned in registers
+  constexpr bool PINNED = XCACHED || (MODE == MODE_VPG && !DBG);
+  uint32_t pinA[PINNED ? 4 * MT2 : 1], pinB[PINNED ? 4 * MT1 : 1];
+  if constexpr (PINNED) {
 #pragma unroll
     for (int g = 0; g < 4 * MT2; ++g) pinA[g] = lds_pin(&bufA[(8 * g + 4 * hi) * ST + j]);
 #pragma unroll
     for (int g = 0; g < 4 * MT1; ++g) pinB[g] = lds_pin(&bufB[(8 * g + 4 * hi) * ST + j]);
   }
   // ... and in the k-groups of W2's rows the delta1 phase reads (rows 8 g + 4 hi .. + 3 of the NEW parameters' slot, columns j, 32 + j)
-  uint32_t pinW[XCACHED ? 4 * MT2 : 1];
-  if constexpr (XCACHED) {
+  uint32_t pinW[PINNED ? 4 * MT2 : 1];
+  if constexpr (PINNED) {
 #pragma unroll
     for (int g = 0; g < 4 * MT2; ++g) pinW[g] = lds_pin(&slotA[L.oW2 + (8 * g + 4 * hi) * S2 + j]);
   }
@@ -1179,12 +1181,14 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
           for (int e = 0; e < R2; ++e) {
             const int idx = st * R2 + e, mt = idx >> 4, r = idx & 15;
             if (FWD) h2[mt][r] = fast_tanh(z2[mt][r]);
-            bufA[(32 * mt + unit_of(r, hi)) * ST + j] = h2[mt][r];
+            if constexpr (PINNED) LDS_AT(pinA[4 * mt + (r >> 2)])[(r & 3) * ST] = h2[mt][r];
+            else bufA[(32 * mt + unit_of(r, hi)) * ST + j] = h2[mt][r];
           }
 #pragma unroll
           for (int e = 0; e < R1; ++e) {
             const int idx = st * R1 + e, mt = idx >> 4, r = idx & 15;
-            bufB[(32 * mt + unit_of(r, hi)) * ST + j] = h1[mt][r];
+            if constexpr (PINNED) LDS_AT(pinB[4 * mt + (r >> 2)])[(r & 3) * ST] = h1[mt][r];
+            else bufB[(32 * mt + unit_of(r, hi)) * ST + j] = h1[mt][r];
           }
 #pragma unroll
           for (int mt = 0; mt < MT2; ++mt) vc[mt] = vn[mt];
@@ -1438,11 +1442,17 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) bufA[(32 * mt + unit_of(r, hi)) * ST + j] = h2[mt][r];
+          for (int r = 0; r < 16; ++r) {
+            if constexpr (PINNED) LDS_AT(pinA[4 * mt + (r >> 2)])[(r & 3) * ST] = h2[mt][r];
+            else bufA[(32 * mt + unit_of(r, hi)) * ST + j] = h2[mt][r];
+          }
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) bufB[(32 * mt + unit_of(r, hi)) * ST + j] = h1[mt][r];
+          for (int r = 0; r < 16; ++r) {
+            if constexpr (PINNED) LDS_AT(pinB[4 * mt + (r >> 2)])[(r & 3) * ST] = h1[mt][r];
+            else bufB[(32 * mt + unit_of(r, hi)) * ST + j] = h1[mt][r];
+          }
       }
       MJX_STAMP(8);
       // delta2 in both layouts: K = actions, the W3 column fragment serves as A (-> lane = sample) and as B (-> lane = unit)
@@ -1521,7 +1531,10 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int nt = 0; nt < MT1; ++nt) wc[t][nt] = slotA[L.oW2 + (4 * hi + t) * S2 + 32 * nt + j];
+          for (int nt = 0; nt < MT1; ++nt) {
+            if constexpr (PINNED) wc[t][nt] = LDS_AT(pinW[0])[t * S2 + 32 * nt];
+            else wc[t][nt] = slotA[L.oW2 + (4 * hi + t) * S2 + 32 * nt + j];
+          }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           const int kb = g >> 2, q = g & 3;
@@ -1530,7 +1543,10 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-              for (int nt = 0; nt < MT1; ++nt) wn[t][nt] = slotA[L.oW2 + (32 * kb1 + 8 * q1 + 4 * hi + t) * S2 + 32 * nt + j];
+              for (int nt = 0; nt < MT1; ++nt) {
+                if constexpr (PINNED) wn[t][nt] = LDS_AT(pinW[4 * kb1 + q1])[t * S2 + 32 * nt];
+                else wn[t][nt] = slotA[L.oW2 + (32 * kb1 + 8 * q1 + 4 * hi + t) * S2 + 32 * nt + j];
+              }
           }
 #pragma unroll
           for (int t = 0; t < 4; ++t)
