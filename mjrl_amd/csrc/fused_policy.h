@@ -569,6 +569,14 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
     for (int g = 0; g < 4 * MT1; ++g) pinB[g] = lds_pin(&bufB[(8 * g + 4 * hi) * ST + j]);
   }
+  // ... of the transposed observation tile (rows 8 g + 2 hi: the cached FVP stores rows 4 q + 2 hi, + 1 per layer-1 k-step)
+  // (instances with a compile-time observation width)
+  constexpr bool PINX = XCACHED && NPC != 0;
+  uint32_t pinX[PINX ? (NPC / 4 + 1) / 2 : 1];
+  if constexpr (PINX) {
+#pragma unroll
+    for (int g = 0; g < (NPC / 4 + 1) / 2; ++g) pinX[g] = lds_pin(&xT[(8 * g + 2 * hi) * ST + j]);
+  }
   // ... and in the k-groups of W2's rows the delta1 phase reads (rows 8 g + 4 hi .. + 3 of the NEW parameters' slot, columns j, 32 + j)
   uint32_t pinW[PINNED ? 4 * MT2 : 1];
   if constexpr (PINNED) {
@@ -637,7 +645,8 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
           const f32x2 xnx = xpair((q + 1 < NP / 4) ? q + 1 : q);
 #pragma unroll
           for (int mt = 0; mt < MT1; ++mt) vn[mt] = LDS_LD2(&slotB[L.oW1 + (32 * mt + j) * S1 + f1]);
-          LDS_ST(&xT[f0 * ST + j], xb0); LDS_ST(&xT[(f0 + 1) * ST + j], xb1);
+          if constexpr (PINX) { LDS_AT(pinX[q >> 1])[(4 * (q & 1)) * ST] = xb0; LDS_AT(pinX[q >> 1])[(4 * (q & 1) + 1) * ST] = xb1; }     // rows f0 = 4 q + 2 hi, f0 + 1
+          else { LDS_ST(&xT[f0 * ST + j], xb0); LDS_ST(&xT[(f0 + 1) * ST + j], xb1); }
 #pragma unroll
           for (int mt = 0; mt < MT1; ++mt) t1[mt] = MJX_MFMA(vc[mt].x, xb0, t1[mt]);
 #pragma unroll
