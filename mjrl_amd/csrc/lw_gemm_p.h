@@ -94,26 +94,36 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
     for (int c = 0; c < CB; ++c) rb[c] = *(const f32x4 __attribute__((address_space(1)))*)(ub + ob[c]);
     ub += sb;
   };
+  // LDS addresses: ONE pinned per-lane byte address per operand and use (store / fragment read), formed once per k-tile from
+  // the buffer parity; everything else is an immediate offset.  (Left to the compiler, every fragment read re-derived
+  // `lane offset * 4 + buffer base` with its own v_lshl_add_u32 between two MFMAs -- ~20 isolated vector-ALU instructions per
+  // k-tile and wave at ~12 cycles each, tools/probe_fill.hip.)
+  typedef __attribute__((address_space(3))) f32x4 lds_f4;
+  typedef __attribute__((address_space(3))) float lds_f1;
+  auto pin = [](const float* p) { uint32_t a = (uint32_t)(uintptr_t)(const lds_f1*)p; asm volatile("" : "+v"(a)); return a; };
   auto lstore = [&](int buf) {
-    float* Ad = As + buf * GP_ASZ;
-    float* Bd = Bs + buf * BSZ;
+    const uint32_t ad = pin(As + buf * GP_ASZ + (tid >> 3) * GP_LD + 4 * (tid & 7));
+    const uint32_t bd = LB ? pin(Bs + buf * BSZ + (tid / (GP_BN / 4)) * (GP_BN + 4) + 4 * (tid % (GP_BN / 4)))
+                           : pin(Bs + buf * BSZ + (tid >> 3) * GP_LD + 4 * (tid & 7));
 #pragma unroll
-    for (int c = 0; c < CA; ++c) { const int idx = tid + GP_NTH * c; *(f32x4*)&Ad[(idx >> 3) * GP_LD + 4 * (idx & 7)] = ra[c]; }
+    for (int c = 0; c < CA; ++c) *(lds_f4*)(uintptr_t)(ad + (uint32_t)((GP_NTH / 8) * c * GP_LD * 4)) = ra[c];
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
-      const int idx = tid + GP_NTH * c;
-      if (LB) *(f32x4*)&Bd[(idx / (GP_BN / 4)) * (GP_BN + 4) + 4 * (idx % (GP_BN / 4))] = rb[c];
-      else *(f32x4*)&Bd[(idx >> 3) * GP_LD + 4 * (idx & 7)] = rb[c];
+      if (LB) *(lds_f4*)(uintptr_t)(bd + (uint32_t)((GP_NTH / (GP_BN / 4)) * c * (GP_BN + 4) * 4)) = rb[c];
+      else *(lds_f4*)(uintptr_t)(bd + (uint32_t)((GP_NTH / 8) * c * GP_LD * 4)) = rb[c];
     }
   };
   // operand fragments of k-group q (k-slot `hi` of step t carries k = 8 q + 4 hi + t for A and B alike)
-  auto fragA = [&](const float* S, int row0, int q) { return *(const f32x4*)&S[(row0 + j) * GP_LD + 8 * q + 4 * hi]; };
-  auto fragB = [&](const float* S, int col0, int q) {
+  // (pa / pb: this wave's pinned fragment addresses in the buffer read -- row block `a` / column block `b`, k-group q)
+  auto pinA = [&](int buf) { return pin(As + buf * GP_ASZ + (wm * TM + j) * GP_LD + 4 * hi); };
+  auto pinB = [&](int buf) { return LB ? pin(Bs + buf * BSZ + (4 * hi) * (GP_BN + 4) + wn * TN + j) : pin(Bs + buf * BSZ + (wn * TN + j) * GP_LD + 4 * hi); };
+  auto fragA = [&](uint32_t pa, int a, int q) { return *(const lds_f4*)(uintptr_t)(pa + (uint32_t)((32 * a * GP_LD + 8 * q) * 4)); };
+  auto fragB = [&](uint32_t pb, int b, int q) {
     if (LB) {
-      const float* p = &S[(8 * q + 4 * hi) * (GP_BN + 4) + col0 + j];
+      const lds_f1* p = (const lds_f1*)(uintptr_t)(pb + (uint32_t)((8 * q * (GP_BN + 4) + 32 * b) * 4));
       return f32x4{p[0], p[GP_BN + 4], p[2 * (GP_BN + 4)], p[3 * (GP_BN + 4)]};
     }
-    return *(const f32x4*)&S[(col0 + j) * GP_LD + 8 * q + 4 * hi];
+    return *(const lds_f4*)(uintptr_t)(pb + (uint32_t)((32 * b * GP_LD + 8 * q) * 4));
   };
 
   // `kl` counts the k-tiles of the current output tile that have been REQUESTED so far (the loader runs two ahead)
@@ -176,33 +186,29 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
     // k-tile in the other buffer.
     f32x4 a4[MT], b4[NT];
     auto first_frags = [&](int kt) {
-      const float* Ac = As + (kt & 1) * GP_ASZ;
-      const float* Bc = Bs + (kt & 1) * BSZ;
+      const uint32_t Ac = pinA(kt & 1), Bc = pinB(kt & 1);
 #pragma unroll
-      for (int a = 0; a < MT; ++a) a4[a] = fragA(Ac, wm * TM + 32 * a, 0);
+      for (int a = 0; a < MT; ++a) a4[a] = fragA(Ac, a, 0);
 #pragma unroll
-      for (int b = 0; b < NT; ++b) b4[b] = fragB(Bc, wn * TN + 32 * b, 0);
+      for (int b = 0; b < NT; ++b) b4[b] = fragB(Bc, b, 0);
     };
     auto body = [&](int kt, bool more, auto&& mid0, auto&& mid1) {
-      const float* Ac = As + (kt & 1) * GP_ASZ;
-      const float* Bc = Bs + (kt & 1) * BSZ;
-      const float* An = As + ((kt + 1) & 1) * GP_ASZ;
-      const float* Bn = Bs + ((kt + 1) & 1) * BSZ;
+      const uint32_t Ac = pinA(kt & 1), Bc = pinB(kt & 1), An = pinA((kt + 1) & 1), Bn = pinB((kt + 1) & 1);
       f32x4 an[MT], bn[NT];
 #pragma unroll
       for (int q = 0; q < GP_BK / 8; ++q) {
         if (q + 1 < GP_BK / 8) {
 #pragma unroll
-          for (int a = 0; a < MT; ++a) an[a] = fragA(Ac, wm * TM + 32 * a, q + 1);
+          for (int a = 0; a < MT; ++a) an[a] = fragA(Ac, a, q + 1);
 #pragma unroll
-          for (int b = 0; b < NT; ++b) bn[b] = fragB(Bc, wn * TN + 32 * b, q + 1);
+          for (int b = 0; b < NT; ++b) bn[b] = fragB(Bc, b, q + 1);
         } else {
           __syncthreads();
           if (more) {
 #pragma unroll
-            for (int a = 0; a < MT; ++a) an[a] = fragA(An, wm * TM + 32 * a, 0);
+            for (int a = 0; a < MT; ++a) an[a] = fragA(An, a, 0);
 #pragma unroll
-            for (int b = 0; b < NT; ++b) bn[b] = fragB(Bn, wn * TN + 32 * b, 0);
+            for (int b = 0; b < NT; ++b) bn[b] = fragB(Bn, b, 0);
           }
         }
 #pragma unroll
