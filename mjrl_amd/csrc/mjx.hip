@@ -714,6 +714,7 @@ PeerPush peer_push(const mjx_ctx* c, int par) {
   for (int q = 0; q < c->peer.world; ++q) { pp.dst[q] = peer_slot(c, q, par, c->peer.rank); pp.counter[q] = peer_counter(c, q); }
   return pp;
 }
+// (the counter is 32 bits and compared as a signed difference: exchange numbers may wrap, a wait just must not span 2^31 arrivals)
 // the consumer's view of exchange `seq`: its local slots in rank order (the surplus entries: a slot of zeros behind the counter
 // block), the own arrival counter and the value it reaches once every peer has delivered
 PeerSlots peer_slots(const mjx_ctx* c, int par, uint32_t seq) {
