@@ -1232,7 +1232,8 @@ int mjx_host_gather_f64_f32(float* dst, const double* const* src, const int64_t*
   const int64_t total = (offsets[first + count] - offsets[first]) * row_elems;      // elements
   int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
   if (total < (int64_t)(1 << 17)) nt = 1;
-  static const bool avx2 = __builtin_cpu_supports("avx2");
+  const char* no_avx2 = getenv("MJX_NO_AVX2");             // (tests: the portable loop on an AVX2 host)
+  const bool avx2 = __builtin_cpu_supports("avx2") && !(no_avx2 && no_avx2[0] == '1');
   auto work = [&](int t) {
     const int64_t lo = total * t / nt, hi = total * (t + 1) / nt;
     const int64_t base = offsets[first] * row_elems;

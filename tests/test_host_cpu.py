@@ -215,6 +215,12 @@ def test_path_stager_matches_concatenate_cpu():
             big[0]["observations"][0, :4] = [np.inf, -np.inf, 1e-46, 3.4028235677973366e38]     # overflow / denormal / rounds-to-inf edge values
             out = st.stage(big, hostcast=True)
             np.testing.assert_array_equal(out["observations"].numpy(), np.concatenate([p["observations"] for p in big]).astype(np.float32))
+            os.environ["MJX_NO_AVX2"] = "1"                          # the portable conversion loop gives the same bits
+            try:
+                out = st.stage(big, hostcast=True)
+                np.testing.assert_array_equal(out["observations"].numpy(), np.concatenate([p["observations"] for p in big]).astype(np.float32))
+            finally:
+                del os.environ["MJX_NO_AVX2"]
             np.testing.assert_array_equal(out["actions"].numpy(), np.concatenate([p["actions"] for p in big]).astype(np.float32))
             assert st.raw("observations") is None and st._slots["observations"]["pin"].dtype == torch.float32
             out = st.stage(big, hostcast=("actions",))                # per key: observations keep their fp64 block
