@@ -1,5 +1,6 @@
+"""cProfile of NPG.train_from_paths on fresh fp64 host batches (1M timesteps): the host side of tools/bench_e2e.py."""
 import os, sys, time, json, cProfile, pstats, io
-ROOT = "/root/repo"; sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from mjrl_amd.algos.npg_cg import NPG
 from mjrl_amd.policies.gaussian_mlp import MLP

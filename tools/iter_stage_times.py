@@ -1,5 +1,6 @@
+"""Where one post-sampling iteration spends its time, with the staging calls (thread, keys, start, duration) of every thread."""
 import os, sys, time, threading
-ROOT = "/root/repo"; sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from mjrl_amd.algos.npg_cg import NPG
 from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
