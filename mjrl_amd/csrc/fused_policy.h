@@ -197,6 +197,14 @@ __device__ __forceinline__ f32x16 pk_1mh2_far(const f32x16& h) {
   }
   return o;
 }
+// a fresh MFMA result times 1 - h^2 of values that came from the vector ALU or from LDS: the factor as one packed FMA with
+// modifiers (asm: its operands are not MFMA results), the product as a builtin (the compiler sees the MFMA -> VALU hazard)
+__device__ __forceinline__ f32x2 mul_1mh2_pair(float a0, float a1, float h0, float h1) {
+  const f32x2 ff = pk_1mh2_pair_far(f32x2{h0, h1});
+  f32x2 tt = {a0, a1};
+  tt *= ff;
+  return tt;
+}
 __device__ __forceinline__ void pk_mul_1mh2_far(f32x16& t, const f32x16& h) {
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
@@ -1480,7 +1488,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
       for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dl2s[mt][r] *= fmaf(-h2[mt][r], h2[mt][r], 1.0f);
+        for (int r = 0; r < 16; r += 2) { const f32x2 v = mul_1mh2_pair(dl2s[mt][r], dl2s[mt][r + 1], h2[mt][r], h2[mt][r + 1]); dl2s[mt][r] = v.x; dl2s[mt][r + 1] = v.y; }
       // h1 / h2 are dead from here on: fetch the next tile's copies behind the weight-gradient products
       if (MODE == MODE_FVP && CACHED && tile + tstride < ntiles) load_h(tile + tstride);
       wave_sync();
@@ -1515,7 +1523,10 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dl2u[nt][4 * q + t] *= fmaf(-fc[nt][q][t], fc[nt][q][t], 1.0f);
+            for (int t = 0; t < 4; t += 2) {
+              const f32x2 v = mul_1mh2_pair(dl2u[nt][4 * q + t], dl2u[nt][4 * q + t + 1], fc[nt][q][t], fc[nt][q][t + 1]);
+              dl2u[nt][4 * q + t] = v.x; dl2u[nt][4 * q + t + 1] = v.y;
+            }
       }
 #pragma unroll
       for (int r = 0; r < RA; ++r) sb3r[r] += d3r[r];   // grad b3[a] = sum_s d3[s][a]: per-lane partial sums, reduced over the lanes after the tile loop
@@ -1595,7 +1606,10 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
           for (int nt = 0; nt < MT1; ++nt)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dl1u[nt][4 * q + t] *= fmaf(-bc[nt][t], bc[nt][t], 1.0f);
+            for (int t = 0; t < 4; t += 2) {
+              const f32x2 v = mul_1mh2_pair(dl1u[nt][4 * q + t], dl1u[nt][4 * q + t + 1], bc[nt][t], bc[nt][t + 1]);
+              dl1u[nt][4 * q + t] = v.x; dl1u[nt][4 * q + t + 1] = v.y;
+            }
 #pragma unroll
           for (int nt = 0; nt < MT1; ++nt) bc[nt] = bn[nt];
         }
