@@ -143,6 +143,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
 #pragma unroll
       for (int fb = 0; fb < NF1; ++fb) gW1[fb] = (f32x16)(0.f);
       float gb2 = 0.f, gw3 = 0.f, gb3 = 0.f;
+      // this lane's 16 output-layer weights (units 32 w + unit_of(r, hi)), fetched once per step: read from LDS where they are
+      // used -- next to the h2^T / delta2^T stores, one element at a time -- every element paid an LDS round trip of its own
+      // (store, load, wait: 2 x 16 serialised trips per half)
+      float w3v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w3v[r] = sW3[32 * w + unit_of(r, hi)];
 #pragma unroll 1
       for (int hb = 0; hb < 2; ++hb) {
         MJX_FIT_STAMP(0);
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
           float hv = fmaxf(z2[r], 0.f);
           z2[r] = hv;
           h2T[(32 * w + unit_of(r, hi)) * ST + j] = hv;
-          part = fmaf(sW3[32 * w + unit_of(r, hi)], hv, part);
+          part = fmaf(w3v[r], hv, part);
         }
         part += __shfl_xor(part, 32);
         if (hi == 0) sPart[w * 32 + j] = part;
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int u = 32 * w + unit_of(r, hi);
-          d2T[u * ST + j] = (z2[r] > 0.f) ? sW3[u] * dy : 0.f;
+          d2T[u * ST + j] = (z2[r] > 0.f) ? w3v[r] * dy : 0.f;
         }
         __syncthreads();
         MJX_FIT_STAMP(4);
