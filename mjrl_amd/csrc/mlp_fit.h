@@ -105,30 +105,30 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   // rows they address, the rows one half-step before they are staged, so neither latency is exposed.
   int gidx[GL];
   int gyi = 0;
+  // (sample, feature) of this thread's gather elements: fixed for the whole run -- the division by the run-time d_in was
+  // re-done for every element in each of the three lambdas below, twice per step
+  int gs[GL], gf[GL];
+#pragma unroll
+  for (int c = 0; c < GL; ++c) {
+    const int e = c * 256 + tid;
+    gs[c] = (e < 32 * d_in) ? e / d_in : -1;
+    gf[c] = e - (e / d_in) * d_in;
+  }
   auto index_load = [&](int ep, int64_t mb, int hb) {
     const int32_t* idx = A.perm + (int64_t)ep * A.N + mb * 64 + 32 * hb;
 #pragma unroll
-    for (int c = 0; c < GL; ++c) {
-      int e = c * 256 + tid, s = e / d_in;
-      gidx[c] = idx[(e < 32 * d_in) ? s : 0];
-    }
+    for (int c = 0; c < GL; ++c) gidx[c] = idx[gs[c] >= 0 ? gs[c] : 0];
     gyi = idx[tid & 31];
   };
   auto gather_load = [&]() {
 #pragma unroll
-    for (int c = 0; c < GL; ++c) {
-      int e = c * 256 + tid, s = e / d_in, f = e - s * d_in;
-      bool ok = e < 32 * d_in;
-      gx[c] = A.feat[ok ? (int64_t)gidx[c] * d_in + f : 0];
-    }
+    for (int c = 0; c < GL; ++c) gx[c] = A.feat[gs[c] >= 0 ? (int64_t)gidx[c] * d_in + gf[c] : 0];
     gy = A.y[gyi];
   };
   auto gather_store = [&]() {
 #pragma unroll
-    for (int c = 0; c < GL; ++c) {
-      int e = c * 256 + tid, s = e / d_in, f = e - s * d_in;
-      if (e < 32 * d_in) { if (NF1 == 1) xs[s * S1 + f] = gx[c]; xT[f * ST + s] = gx[c]; }
-    }
+    for (int c = 0; c < GL; ++c)
+      if (gs[c] >= 0) { if (NF1 == 1) xs[gs[c] * S1 + gf[c]] = gx[c]; xT[gf[c] * ST + gs[c]] = gx[c]; }
     if (tid < 32) sY[tid] = gy;
   };
 
