@@ -24,6 +24,21 @@ namespace mjx {
 #define MJX_FIT_STAMP(k) do {} while (0)
 #endif
 
+// sum over the lanes 0..31 of a wave, valid in lane 0: DPP moves inside the 16-lane rows (vector-ALU latency) + one
+// v_permlane16_swap instead of five ds_bpermute round trips through the LDS pipe (~100 cycles each, on the critical path of
+// the wave every other wave is waiting for at the next barrier)
+__device__ __forceinline__ float sum32_lane0(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});      // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});      // row_mirror: every lane holds its row's sum
+  auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(s[0]) + __uint_as_float(s[1]);   // rows 0 + 1 (lanes 0..31), rows 2 + 3 (lanes 32..63)
+}
+
 struct MlpFitArgs {
   const float* feat;       // (N, d_in) fp32
   const float* y;          // (N)
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
           h2T[(32 * w + unit_of(r, hi)) * ST + j] = hv;
           part = fmaf(w3v[r], hv, part);
         }
-        part += __shfl_xor(part, 32);
+        part = half_sum(part);                            // (+ the other lane half: v_permlane32_swap, the bits of part + shfl_xor(part, 32))
         if (hi == 0) sPart[w * 32 + j] = part;
         __syncthreads();
         MJX_FIT_STAMP(3);
@@ -227,9 +242,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         const float dy = 2.0f * err / 64.0f;              // MSELoss(mean) over the 64-row minibatch
         if (w == 0 && hi == 0) {
           sDY[j] = dy;
-          float e2 = err * err;
-#pragma unroll
-          for (int off = 1; off < 32; off <<= 1) e2 += __shfl_xor(e2, off);
+          const float e2 = sum32_lane0(err * err);
           if (j == 0) ep_loss += (double)e2 / 64.0;
         }
         // delta2 (lane = sample) -> d2T [unit][sample]
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
           float s2 = 0.f;
 #pragma unroll
           for (int r = 0; r < 16; ++r) s2 += d2u[r];
-          gb2 += s2 + __shfl_xor(s2, 32);
+          gb2 += half_sum(s2);
         }
         MJX_FIT_STAMP(5);
         // grad W2 rows of this wave: A = delta2u (registers), B = h1^T tiles
