@@ -365,6 +365,19 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         r = r * fmaf(-denom, r, 2.0f);
         return fmaf(-step_size * mi, r, p);
       };
+      // the same update on TWO weights per instruction (packed fp32): the arithmetic of adam_math element by element -- the
+      // vector ALU is paid in full on this chip (fp32 MFMAs hide none of it), the 19 457-weight update is ~12 instructions per weight
+      auto adam_math2 = [&](f32x2 p, f32x2 g, f32x2& qa, f32x2& qb) {
+        g = __builtin_elementwise_fma((f32x2)(A.wd), p, g);
+        f32x2 mi = {qa.x, qb.x}, vi = {qa.y, qb.y};
+        mi = __builtin_elementwise_fma(g - mi, (f32x2)(1.0f - b1c), mi);
+        vi = __builtin_elementwise_fma(g * g, (f32x2)(1.0f - b2c), vi * (f32x2)(b2c));
+        qa = f32x2{mi.x, vi.x}; qb = f32x2{mi.y, vi.y};
+        const f32x2 denom = __builtin_elementwise_fma(f32x2{__builtin_amdgcn_sqrtf(vi.x), __builtin_amdgcn_sqrtf(vi.y)}, (f32x2)(inv_bc2s), (f32x2)(eps));
+        f32x2 r = {__builtin_amdgcn_rcpf(denom.x), __builtin_amdgcn_rcpf(denom.y)};
+        r = r * __builtin_elementwise_fma(-denom, r, (f32x2)(2.0f));
+        return __builtin_elementwise_fma(mi * (f32x2)(-step_size), r, p);
+      };
       f32x2* __restrict__ MV = (f32x2*)A.mv;
       // Every owned element sits at a compile-time offset from one per-lane base.  ALL moment pairs a thread owns -- its 64 W2
       // weights, its 16 W1 / b1 entries, its b2 / W3 / b3 entry -- are requested up front (the backward pass's registers are
@@ -405,19 +418,32 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int o = unit_of(r, 0) * H + 32 * nt, ol = unit_of(r, 0) * S2 + 32 * nt;
-            pW2[ol] = adam_math(pW2[ol], gW2[nt][r], q2[nt][r]);
-            mvW2[o] = q2[nt][r];
+          for (int r = 0; r < 16; r += 2) {
+            const int o0 = unit_of(r, 0) * H + 32 * nt, l0 = unit_of(r, 0) * S2 + 32 * nt;
+            const int o1 = unit_of(r + 1, 0) * H + 32 * nt, l1 = unit_of(r + 1, 0) * S2 + 32 * nt;
+            if constexpr (NF1 == 1) {
+              const f32x2 pn = adam_math2(f32x2{pW2[l0], pW2[l1]}, f32x2{gW2[nt][r], gW2[nt][r + 1]}, q2[nt][r], q2[nt][r + 1]);
+              pW2[l0] = pn.x; pW2[l1] = pn.y;
+            } else {                                      // (the two-block variant already spills: the packed form's temporaries cost it 2 %)
+              pW2[l0] = adam_math(pW2[l0], gW2[nt][r], q2[nt][r]);
+              pW2[l1] = adam_math(pW2[l1], gW2[nt][r + 1], q2[nt][r + 1]);
+            }
+            mvW2[o0] = q2[nt][r]; mvW2[o1] = q2[nt][r + 1];
           }
 #pragma unroll
         for (int fb = 0; fb < NF1; ++fb)
           if (own1[fb]) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int o = unit_of(r, 0) * stg[fb], ol = unit_of(r, 0) * S1;
-              pW1[fb][ol] = adam_math(pW1[fb][ol], gW1[fb][r], q1[fb][r]);
-              mvW1[fb][o] = q1[fb][r];
+            for (int r = 0; r < 16; r += 2) {
+              const int o0 = unit_of(r, 0) * stg[fb], l0 = unit_of(r, 0) * S1, o1 = unit_of(r + 1, 0) * stg[fb], l1 = unit_of(r + 1, 0) * S1;
+              if constexpr (NF1 == 1) {
+                const f32x2 pn = adam_math2(f32x2{pW1[fb][l0], pW1[fb][l1]}, f32x2{gW1[fb][r], gW1[fb][r + 1]}, q1[fb][r], q1[fb][r + 1]);
+                pW1[fb][l0] = pn.x; pW1[fb][l1] = pn.y;
+              } else {
+                pW1[fb][l0] = adam_math(pW1[fb][l0], gW1[fb][r], q1[fb][r]);
+                pW1[fb][l1] = adam_math(pW1[fb][l1], gW1[fb][r + 1], q1[fb][r + 1]);
+              }
+              mvW1[fb][o0] = q1[fb][r]; mvW1[fb][o1] = q1[fb][r + 1];
             }
           }
         if (ownb2) { sB2[32 * w + j] = adam_math(sB2[32 * w + j], gb2, qb2); MV[gb2i] = qb2; }
