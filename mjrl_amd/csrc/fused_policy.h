@@ -149,6 +149,20 @@ __device__ __forceinline__ float half_sum(float p) {
   return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
+// every lane: the sum over its 16-lane row, by DPP moves (vector-ALU latency; the same operand pairs, hence the same bits, as
+// `v += __shfl_xor(v, 1); ... 2; ... 4; ... 8` -- after each step all lanes of a group hold the group's sum -- without the four
+// ~100-cycle trips through the LDS pipe that ds_bpermute costs)
+__device__ __forceinline__ float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});      // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});      // row_mirror
+  return v;
+}
+
 // packed fp32 element-wise helpers on 16-register tiles (register pairs -> v_pk_fma_f32 / v_pk_mul_f32)
 __device__ __forceinline__ f32x16 pk_1mh2(const f32x16& h) {                      // 1 - h^2
   f32x16 o;

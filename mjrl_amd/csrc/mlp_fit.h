@@ -28,13 +28,7 @@ namespace mjx {
 // v_permlane16_swap instead of five ds_bpermute round trips through the LDS pipe (~100 cycles each, on the critical path of
 // the wave every other wave is waiting for at the next barrier)
 __device__ __forceinline__ float sum32_lane0(float v) {
-  auto dpp = [](float x, auto ctrl) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
-  };
-  v += dpp(v, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
-  v += dpp(v, std::integral_constant<int, 0x141>{});      // row_half_mirror
-  v += dpp(v, std::integral_constant<int, 0x140>{});      // row_mirror: every lane holds its row's sum
+  v = row16_sum(v);                                       // every lane holds its row's sum
   auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(s[0]) + __uint_as_float(s[1]);   // rows 0 + 1 (lanes 0..31), rows 2 + 3 (lanes 32..63)
 }

@@ -105,13 +105,7 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_move<0xB1>(v);       // quad_perm [1,0,3,2]
-  v += dpp_move<0x4E>(v);       // quad_perm [2,3,0,1]
-  v += dpp_move<0x141>(v);      // row_half_mirror
-  v += dpp_move<0x140>(v);      // row_mirror
-  return v;
-}
+// (row16_sum -- the sum over the 16 lanes of a DPP row -- lives in fused_policy.h)
 
 #define MJX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -211,7 +205,7 @@ __device__ __forceinline__ void fit_wgrad(const float* __restrict__ delta, int D
     const int u = tid >> 4, part = tid & 15;           // 1024 threads: 64 units x 16 parts
     float g = 0.f;
     if (u < OUT) for (int sr = part; sr < B; sr += 16) g += delta[sr * DS + u];
-    g += __shfl_xor(g, 1); g += __shfl_xor(g, 2); g += __shfl_xor(g, 4); g += __shfl_xor(g, 8);
+    g = row16_sum(g);
     if (part == 0 && u < OUT) gb[u] = g;
   }
 }
