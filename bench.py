@@ -66,10 +66,76 @@ def initial_params():
 
 
 def cpu_baseline(theta0, sample_traj):
-    """The reference's CPU algorithm (torch-autograd port, oracle/torch_port.py) timed on this
-    box's host cores on a bounded slice of the same workload.  torch's intra-op thread count is
-    calibrated first on a small slice (many-core hosts are slower at their default of one thread per
-    core on these skinny matrices), so the baseline is the CPU's best showing."""
+    """The CPU path timed on this box's host cores, rank 0, N = 1.
+
+    kind "reference": the UNMODIFIED reference's NPG.train_from_paths (mjrl/algos/npg_cg.py:91-163) itself, on the FULL
+    1M-timestep batch of the metric -- imported from /root/reference where that exists, else from the bytecode
+    oracle/ref_stage.py compiled from it into oracle/_ref/ (what travels to the GPU box).  torch's intra-op thread count is
+    calibrated on a 40k slice first (many-core hosts are slower at their default of one thread per core on these skinny
+    matrices), so the baseline is the CPU's best showing.
+    kind "port" (only when the reference is not staged): oracle/torch_port.py, the same op sequence, on a slice scaled linearly."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from oracle import ref_loader
+    ref_root = ref_loader.install()
+    if ref_root is None:
+        return cpu_baseline_port(theta0, sample_traj)
+    import contextlib
+    import io
+    from mjrl.algos.npg_cg import NPG
+    from mjrl.policies.gaussian_mlp import MLP
+    from mjrl.utils.gym_env import EnvSpec
+    obs, act, adv = synth_shard(0, 1)
+    obs, act = obs.astype(np.float64), act.astype(np.float64)    # the reference holds fp64 rollouts
+    spec = EnvSpec(N_OBS, N_ACT, T)
+
+    def paths_of(n_traj):
+        return [dict(observations=obs[i * T:(i + 1) * T], actions=act[i * T:(i + 1) * T], rewards=np.zeros(T),
+                     advantages=adv[i * T:(i + 1) * T].copy(), terminated=False) for i in range(n_traj)]
+
+    def one_update(paths):
+        pol = MLP(spec, hidden_sizes=HIDDEN, seed=1, init_log_std=-0.5)
+        pol.set_param_values(theta0.copy())
+        agent = NPG(None, pol, None, normalized_step_size=STEP, FIM_invert_args={'iters': CG_ITERS, 'damping': DAMPING}, save_logs=False)
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            agent.train_from_paths(paths)
+        return time.time() - t0, pol.get_param_values()
+
+    default_threads = torch.get_num_threads()
+    one_update(paths_of(10))                                      # warm-up
+    cal, cal_paths = {}, paths_of(40)
+    for k in sorted({8, 16, 32, 64, default_threads}):
+        if k > default_threads:
+            continue
+        torch.set_num_threads(k)
+        cal[k] = one_update(cal_paths)[0]
+    best = min(cal, key=cal.get)
+    torch.set_num_threads(best)
+    n_traj = N_TRAJ if sample_traj <= 0 or sample_traj >= N_TRAJ or sample_traj == 200 else sample_traj   # default: the whole batch
+    dt, theta_ref = one_update(paths_of(n_traj))
+    torch.set_num_threads(default_threads)
+    n = n_traj * T
+    vs_fixture = None
+    fr = os.path.join(ROOT, "tests", "golden", "bench_ref_1m.npz")
+    if n_traj == N_TRAJ and os.path.exists(fr):
+        # the run just timed against the fixture the GPU path is held to (the same reference on the same batch, made in the build
+        # container on 8 threads): they differ by thread-count summation order only
+        rs = np.load(fr)["npg_new_params"].astype(np.float64) - theta0
+        vs_fixture = float(np.linalg.norm((theta_ref.astype(np.float64) - theta0) - rs) / np.linalg.norm(rs))
+    return dict(value=(n / float(N_TRAJ * T)) / dt, unit="updates/s", cores=int(best), kind="reference", step_rel_l2_vs_fixture=vs_fixture,
+                sample="%s: the unmodified reference's NPG.train_from_paths (mjrl/algos/npg_cg.py:91-163, imported from %s) on %d "
+                       "timesteps (%d trajectories) of the metric's own batch in %.2f s, torch-CPU with %d intra-op threads (best of %s "
+                       "on a 40k-timestep calibration)%s"
+                       % ("the FULL 1M-timestep batch" if n_traj == N_TRAJ else "a slice", "oracle/_ref (bytecode staged by oracle/ref_stage.py)"
+                          if ref_root != "/root/reference" else ref_root, n, n_traj, dt, best, {k: round(v, 2) for k, v in cal.items()},
+                          "" if n_traj == N_TRAJ else ", scaled linearly to 1M"),
+                seconds=dt, nproc=os.cpu_count(), reference_new_params_norm=float(np.linalg.norm(theta_ref.astype(np.float64) - theta0)))
+
+
+def cpu_baseline_port(theta0, sample_traj):
+    """fallback when the reference is not staged: its CPU algorithm as a torch-autograd port (oracle/torch_port.py, validated
+    against the reference's wall time and step: tests/golden/cpu_port_vs_reference.json) on a bounded slice."""
     import torch
     from oracle import torch_port
     obs, act, adv = synth_shard(0, N_TRAJ // sample_traj)        # first `sample_traj` trajectories
@@ -99,20 +165,16 @@ def cpu_baseline(theta0, sample_traj):
     vf = os.path.join(ROOT, "tests", "golden", "cpu_port_vs_reference.json")
     if os.path.exists(vf):
         validation = json.load(open(vf))
-        kind = "port (validated vs reference: %.2f)" % validation["port_over_reference"]
     return dict(value=ups, unit="updates/s", cores=int(best), kind=kind,
                 validation=None if validation is None else dict(
                     what="wall time of this port / wall time of the unmodified reference's NPG.train_from_paths on the same "
                          "%d-timestep batch, best of 3 each, %d threads, build container (tests/golden/make_cpu_port_validation.py)"
                          % (validation["timesteps"], validation["threads"]),
                     port_over_reference=validation["port_over_reference"], step_rel_difference=validation["step_rel_difference"]),
-                reference_probe=dict(value=0.0576, unit="updates/s", cores=8,
-                                     what="the unmodified reference, one NPG update on the full 1M-timestep batch, 8-vCPU build container "
-                                          "(BASELINE.md section 2 / SURVEY section 6: 17.4 s)"),
                 sample="%d-timestep slice (%d traj) of the 1M batch, one NPG update in %.2f s on torch-CPU "
                        "(autograd double-backward HVP, as the reference) with %d intra-op threads (best of %s on a "
-                       "%d-sample calibration), scaled linearly to 1M" % (n, sample_traj, dt, best,
-                                                                          {k: round(v, 2) for k, v in cal.items()}, ncal),
+                       "%d-sample calibration), scaled linearly to 1M; the reference itself is not staged here (oracle/_ref missing)"
+                       % (n, sample_traj, dt, best, {k: round(v, 2) for k, v in cal.items()}, ncal),
                 seconds=dt, nproc=os.cpu_count())
 
 
@@ -228,7 +290,130 @@ def secondary_measurements(eng, theta0, theta0_dev, ref=None):
         del e
         torch.cuda.empty_cache()
     out["roofline_lw"] = lw
+    out.update(user_level_measurements())
     return out
+
+
+def _host_paths(rng, n_traj=N_TRAJ, T_=T, advantages=False):
+    """fp64 rollouts as a sampler hands them over: a list of per-trajectory dicts (mjrl/samplers/core.py:85-93)"""
+    paths = [dict(observations=rng.randn(T_, N_OBS), actions=rng.randn(T_, N_ACT), rewards=rng.randn(T_), terminated=False)
+             for _ in range(n_traj)]
+    if advantages:
+        for p in paths:
+            p["advantages"] = rng.randn(T_)
+    return paths
+
+
+def user_level_measurements():
+    """What a caller of the mjrl-shaped classes sees at the metric's size (SURVEY 8d "One update" (ii)), all
+    from fp64 HOST trajectories -- PCIe-inclusive, so none of this is `value`:
+    * end_to_end: one NPG.train_from_paths (host path statistics || page-locked staging + upload, the update, parameter
+      read-back + set_param_values), median of 5 fresh batches after 2 warm-ups;
+    * iteration: everything train_step does after sampling (batch_reinforce.py:93-114: returns, baseline prediction + GAE, the
+      update, the baseline fit) with the quadratic and with the MLP baseline (2 epochs, batch 64: policy_opt_job_script's setting);
+    * mlp_fit_us_per_step: the persistent minibatch-Adam trainer alone (k_mlp_fit, 21 inputs, 8 000 steps, best of 3)."""
+    import torch
+    from mjrl_amd._lib import check, ptr
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.baselines.mlp_baseline import MLPBaseline
+    from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    from mjrl_amd.utils import ingest, process_samples
+    spec = type("Spec", (), dict(observation_dim=N_OBS, action_dim=N_ACT, horizon=T))
+    out = {}
+    # ---- end to end
+    rng = np.random.RandomState(0)
+    pol = MLP(spec, hidden_sizes=HIDDEN, seed=1, init_log_std=-0.5)
+    agent = NPG(None, pol, None, normalized_step_size=STEP, FIM_invert_args={'iters': CG_ITERS, 'damping': DAMPING})
+    base = _host_paths(rng, advantages=True)
+
+    def fresh():        # a new batch every time: the staged copy of an earlier list is never reused
+        return [dict(observations=p["observations"].copy(), actions=p["actions"].copy(), rewards=p["rewards"], advantages=p["advantages"],
+                     terminated=False) for p in base]
+    ts = []
+    for it in range(7):
+        b = fresh()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        agent.train_from_paths(b)
+        torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
+    ts = sorted(ts[2:])
+    out["end_to_end"] = {"npg_train_from_paths_ms_median": ts[len(ts) // 2], "ms_min": ts[0], "ms_each_sorted": ts,
+                         "updates_per_s": 1e3 / ts[len(ts) // 2],
+                         "what": "NPG.train_from_paths on 1000 x 1000-step fp64 host trajectories (184 MB): path statistics || page-locked "
+                                 "staging + upload (fp64 -> fp32 on the gather threads), mjx_npg_update, read-back, policy.set_param_values; "
+                                 "median of 5 fresh batches after 2 warm-ups"}
+    agent.engine.close()
+    del agent, base
+    # ---- a whole post-sampling iteration
+    it_out = {}
+    for name, reps in (("quadratic", 6), ("mlp", 4)):
+        pol = MLP(spec, hidden_sizes=HIDDEN, seed=1, init_log_std=-0.5)
+        bl = QuadraticBaseline(spec) if name == "quadratic" else MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3)
+        agent = NPG(None, pol, bl, normalized_step_size=STEP, FIM_invert_args={'iters': CG_ITERS, 'damping': DAMPING})
+        rows = []
+        for it in range(reps):
+            paths = _host_paths(rng)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            with ingest.trusted_iteration():
+                process_samples.compute_returns(paths, 0.995); t1 = time.perf_counter()
+                process_samples.compute_advantages(paths, bl, 0.995, 0.97); t2 = time.perf_counter()
+                agent.train_from_paths(paths); torch.cuda.synchronize(); t3 = time.perf_counter()
+                bl.fit(paths); torch.cuda.synchronize(); t4 = time.perf_counter()
+            ingest.drop_shared_batch()
+            rows.append([1e3 * x for x in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)])
+        rows = rows[1:]                                  # the first iteration allocates
+        med = sorted(rows, key=lambda r: r[-1])[len(rows) // 2]
+        it_out[name] = dict(zip(["returns_ms", "advantages_ms", "update_ms", "baseline_fit_ms", "total_ms"], med))
+        it_out[name]["total_ms_each"] = [r[-1] for r in rows]
+        it_out[name]["iterations_timed"] = len(rows)
+        agent.engine.close()
+        del agent
+    it_out["what"] = ("returns, baseline prediction + GAE, NPG.train_from_paths, baseline.fit on fresh 1M-timestep fp64 host batches under "
+                      "ingest.trusted_iteration() like BatchREINFORCE.train_step; the median iteration's stage times")
+    out["iteration"] = it_out
+    ingest.drop_shared()
+    # ---- the MLP-baseline trainer alone
+    d_in, steps = N_OBS + 4, 8000
+    Nf = 64 * (steps + 1)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    from mjrl_amd import _lib
+    lib = _lib.load()
+    r2 = np.random.RandomState(0)
+    feat = torch.from_numpy(r2.randn(Nf, d_in).astype(np.float32)).to(dev)
+    y = torch.from_numpy(r2.randn(Nf).astype(np.float32)).to(dev)
+    Pn = 128 * d_in + 128 + 128 * 128 + 128 + 128 + 1
+    params = torch.from_numpy((0.1 * r2.randn(Pn)).astype(np.float32)).to(dev)
+    m_, v_ = torch.zeros(Pn, device=dev), torch.zeros(Pn, device=dev)
+    perm = torch.from_numpy(r2.permutation(Nf).astype(np.int32)).to(dev)
+    loss = torch.zeros(32, dtype=torch.float64, device=dev)
+    hid = (ctypes.c_int * 2)(128, 128)
+    tt = []
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        check(lib.mjx_mlp_fit_adam(ptr(feat), ptr(y), Nf, d_in, hid, 2, ptr(params), ptr(m_), ptr(v_), 0, ptr(perm), 1, 64, 1e-3, 0.0,
+                                   ptr(loss), None))
+        torch.cuda.synchronize(); tt.append(time.perf_counter() - t0)
+    out["mlp_fit_us_per_step"] = {"value": 1e6 * min(tt) / steps, "steps": steps, "inputs": d_in, "hidden": [128, 128], "batch": 64,
+                                  "kernel": "k_mlp_fit<128,1> (csrc/mlp_fit.h): one persistent workgroup, the whole Adam chain in one launch",
+                                  "per_1M_timesteps_2_epochs_s": 1e-6 * (1e6 * min(tt) / steps) * 2 * (N_TRAJ * T // 64 - 1)}
+    return out
+
+
+def self_launch(n):
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("MJX_BENCH_SHARE_GPU") != "1":
+        sys.exit("bench.py: --gpus %d but %d GPU(s) visible (MJX_BENCH_SHARE_GPU=1 + MJX_BENCH_BACKEND=gloo put all ranks on "
+                 "GPU 0: a test mode, not a measurement)" % (n, have))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL and the peer exchange need it on these hosts
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -239,7 +424,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fvp-event-stride", type=int, default=11,
                     help="bracket every k-th Fisher-vector-product launch with HIP events (k coprime to the CG iteration count: every CG position is sampled equally); 0: none")
-    ap.add_argument("--cpu-sample-traj", type=int, default=200)
+    ap.add_argument("--cpu-sample-traj", type=int, default=200,
+                    help="cpu_baseline: with the reference staged (oracle/_ref) the default times it on the whole 1M batch (~20 s); "
+                         "any other value: that many trajectories, scaled linearly.  Without it: the slice the torch port runs")
     ap.add_argument("--repeats", type=int, default=3,
                     help="the timed region (barrier + synchronize, EXACTLY --steps updates, barrier + synchronize) is run this many "
                          "times; `value` is the median repeat, all repeats are reported")
@@ -254,12 +441,19 @@ def main():
                          "to R buffers, counter updates, stream wait and R-slot sums of an R-rank exchange, all onto this rank's buffer)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher -- one rank per GPU under torch.distributed.run (what the
+        # driver's multi-GPU command does itself); rank 0's JSON line passes through on stdout, the exit code is the job's
+        return self_launch(args.gpus)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or run "
+                 "`python bench.py --gpus %d` with WORLD_SIZE unset: it launches the ranks itself)" % (args.gpus, world, args.gpus, args.gpus))
     # (test hooks: MJX_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and MJX_BENCH_BACKEND=gloo replaces RCCL, which refuses
     #  two ranks on one device -- tests/test_gpu_parity.py runs the N = 2 path of this script on a 1-GPU box that way)
     dev_index = 0 if os.environ.get("MJX_BENCH_SHARE_GPU") == "1" else local_rank

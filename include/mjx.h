@@ -108,7 +108,13 @@ int mjx_surr_vpg(mjx_ctx* ctx, float* grad_out, double* scal_out, void* stream);
 /* ---- K2: Fisher-vector product ------------------------------------------- */
 /* out[d] = local share of (Hessian of mean_kl wrt theta_new at theta_new==theta_old) * v,
  * WITHOUT the damping term (NPG.HVP, mjrl/algos/npg_cg.py:62-81 minus `regu_coef*vector`).
- * Summing `out` over ranks gives the full product.  Requires old_is_new. */
+ * Summing `out` over ranks gives the full product.  Requires old_is_new.
+ * Reproducibility: with the forward-activation cache of mjx_surr_vpg in place the product walks the sample tiles alternately
+ * back-to-front and front-to-back (a counter the context resets in mjx_surr_vpg and mjx_cg_init: product k of a solve always
+ * walks the same way, so whole solves / updates are bit-reproducible).  Two stand-alone calls with the same `v` therefore sum
+ * the per-workgroup partials of DIFFERENT tile sets and may differ in the last bits (~1e-7 relative); call mjx_cg_init between
+ * them -- or export MJX_FVP_SWEEP=0 (always front-to-back; costs ~3.5 % at 1M samples, the activation cache then defeats the
+ * memory-side cache) -- when bit-identical repeats of single products are needed. */
 int mjx_fvp(mjx_ctx* ctx, const float* v, float* out, void* stream);
 
 /* ---- K3: surrogate + KL evaluation (no gradient) ------------------------- */
@@ -162,14 +168,20 @@ int mjx_comm_allreduce(mjx_ctx* ctx, void* buf, int64_t count, int dtype, void* 
 
 /* Peer exchange: a third transport for the same rank sums, built on HIP IPC and stream memory operations instead of RCCL --
  * for the 5-23 KB vectors of this path a collective library's launch + protocol latency is most of the cost.  Every rank owns one
- * uncached device buffer [2 parities][world slots] + an arrival counter; mjx_peer_export allocates it and returns its
+ * uncached device buffer [2 parities][world slots] + one arrival flag per source rank; mjx_peer_export allocates it and returns its
  * hipIpcMemHandle_t (MJX_PEER_HANDLE_BYTES bytes), the caller gathers the world's handles over any side channel (rank order) and
  * hands them to mjx_peer_connect, which maps the peers' buffers.  From then on every rank sum of mjx_comm_allreduce /
  * mjx_cg_solve / mjx_npg_update / mjx_trpo_update / mjx_dapg_update is: store the local vector into slot `rank` of EVERY rank's
- * buffer and add 1 to every peer's counter (in the CG loop the Fisher product's reduction kernel does both itself); the
- * consuming kernel (in the loop: the CG vector update) waits on the own counter -- local memory -- and sums the local slots in
- * rank order.  All on the launch stream: no host synchronisation, no extra launch in the loop, bit-identical results on all
- * ranks.  The wait is bounded: a peer that has not delivered within 5 s turns the result into NaN instead of hanging the GPU.  One process per rank, 2 <= world <= 16; the ranks may own different GPUs of a node (peer access over
+ * buffer, then -- once those stores are acknowledged -- store the exchange number into this rank's flag in every peer's buffer
+ * (in the CG loop the Fisher product's reduction kernel does both itself); the consuming kernel (in the loop: the CG vector
+ * update) waits on the flags of its own buffer -- local memory, one polling thread per source rank -- and sums the local slots
+ * in rank order.  A flag and the data it announces come from the same rank over the same path; nothing is assumed about the
+ * relative order of different peers' traffic.  All on the launch stream: no host synchronisation, no extra launch in the loop,
+ * bit-identical results on all ranks.  The wait is bounded: a peer that has not delivered within MJX_PEER_TIMEOUT_MS
+ * (environment, read by mjx_peer_export; default 5000) turns the result into NaN instead of hanging the GPU and is counted:
+ * mjx_peer_status returns (and clears) the number of timed-out waits since the last call -- a host that reads back a
+ * non-finite update asks it and raises (mjrl_amd.engine does).  After a timeout the ranks' exchange sequences are out of step:
+ * tear the transport down (mjx_comm_destroy).  One process per rank, 2 <= world <= 16; the ranks may own different GPUs of a node (peer access over
  * xGMI) or share one (tests).  Every rank must issue the same sequence of rank sums.  Replaces nothing in the reference (its
  * only parallelism is the sampler pool).  mjx_comm_destroy tears it down.
  * handles == NULL: loop-back rehearsal -- every "peer" is this rank's own buffer, so the stores, counter updates, the stream
@@ -178,6 +190,9 @@ int mjx_comm_allreduce(mjx_ctx* ctx, void* buf, int64_t count, int dtype, void* 
 #define MJX_PEER_HANDLE_BYTES 64
 int mjx_peer_export(mjx_ctx* ctx, int rank, int world, char* handle_out);
 int mjx_peer_connect(mjx_ctx* ctx, const char* handles /* world x MJX_PEER_HANDLE_BYTES, rank order */);
+/* *timeouts_out = waits of this rank's consumer kernels that gave up since the last call (0 without a peer transport); clears the
+ * count.  Synchronises with the device (a 4-byte read): call it after an update's own read-back, not inside the loop. */
+int mjx_peer_status(mjx_ctx* ctx, int* timeouts_out);
 
 /* ONE device-resident NPG update enqueued without a host round trip -- what NPG.train_from_paths does between
  * process_paths and the parameter read-back (mjrl/algos/npg_cg.py:108-142):

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "mjx_comm_allreduce": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mjx_peer_export": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p]),
     "mjx_peer_connect": (c_int, [c_void_p, ctypes.c_char_p]),
+    "mjx_peer_status": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "mjx_npg_update": (c_int, [c_void_p, c_int, c_float, c_double, c_double, c_double, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p]),
     "mjx_trpo_update": (c_int, [c_void_p, c_int, c_float, c_double, c_double, c_double, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,

@@ -86,11 +86,24 @@ class BatchREINFORCE:
         if sample_mode not in ('trajectories', 'samples'):
             raise ValueError("sample_mode must be either 'trajectories' or 'samples'")
         t0 = timer.time()
-        common = dict(env=env, policy=self.policy, horizon=horizon, base_seed=self.seed, num_cpu=num_cpu, env_kwargs=env_kwargs)
-        if sample_mode == 'trajectories':
-            paths = trajectory_sampler.sample_paths(num_traj=N, **common)
+        # One process per GPU (torch.distributed initialised): N is the size of the WHOLE batch and every rank samples its
+        # contiguous share of it with the seeds a single process would have used for those episodes (base_seed + episode index,
+        # samplers/core.py:44-57) -- the ranks' path lists, in rank order, are the batch of the one-process run.  Everything
+        # after sampling sums over the ranks (returns statistics, advantage whitening, the update, ONE baseline fit).
+        n_mine, seed_mine = N, self.seed
+        d = _dist()
+        if d is not None:
+            W, r = d.get_world_size(), d.get_rank()
+            lo, hi = r * N // W, (r + 1) * N // W
+            n_mine = hi - lo
+            seed_mine = None if self.seed is None else self.seed + lo
+        common = dict(env=env, policy=self.policy, horizon=horizon, base_seed=seed_mine, num_cpu=num_cpu, env_kwargs=env_kwargs)
+        if n_mine <= 0:
+            paths = []
+        elif sample_mode == 'trajectories':
+            paths = trajectory_sampler.sample_paths(num_traj=n_mine, **common)
         else:
-            paths = trajectory_sampler.sample_data_batch(num_samples=N, **common)
+            paths = trajectory_sampler.sample_data_batch(num_samples=n_mine, **common)
         if self.save_logs:
             self.logger.log_kv('time_sampling', timer.time() - t0)
         if self.seed is not None:
@@ -103,7 +116,7 @@ class BatchREINFORCE:
             eval_statistics = self.train_from_paths(paths)
             eval_statistics.append(N)
             if self.save_logs:
-                self.logger.log_kv('num_samples', int(np.sum([p["rewards"].shape[0] for p in paths])))
+                self.logger.log_kv('num_samples', self.engine.global_count(int(np.sum([p["rewards"].shape[0] for p in paths]))))
                 t0 = timer.time()
                 error_before, error_after = self.baseline.fit(paths, return_errors=True)
                 self.logger.log_kv('time_VF', timer.time() - t0)
@@ -225,9 +238,19 @@ class BatchREINFORCE:
         # copies, no GIL) while this thread assembles the advantage vector and the path statistics
         eng = self.engine
         from ..utils import ingest
+        if not paths:
+            return self._bind_empty_shard()
         # (asked before the staging job starts: the helper thread holds the registry lock while it stages)
         adv64 = ingest.lookup(eng.backend, paths, "advantages") if eng.device.type == "cuda" else None
-        if adv64 is None and eng.device.type == "cuda" and len(paths) > 64 and getattr(eng, "_stager", None) is None and all(
+        if _dist() is not None:
+            # which route the advantages take decides which collectives follow (engine.whitened_advantages: libmjx's transport;
+            # _advantages_and_statistics: torch.distributed): the ranks must agree on it.  The device block is used only when
+            # EVERY rank holds one; the host-array fast path below depends on per-rank path counts and is left to single
+            # processes.
+            from ..utils import ranks
+            if not ranks.all_true(adv64 is not None):
+                adv64 = None
+        elif adv64 is None and eng.device.type == "cuda" and len(paths) > 64 and getattr(eng, "_stager", None) is None and all(
                 isinstance(p["advantages"], np.ndarray) and p["advantages"].ndim == 1 and p["advantages"].dtype == np.float64 for p in paths):
             # host advantages (train_from_paths called on its own): the 8 bytes per timestep go up through the stager as they are
             # and are whitened on the device like the resident ones -- np.concatenate + mean + std + the division cost 2-3 ms of
@@ -248,18 +271,26 @@ class BatchREINFORCE:
         eng.set_batch(staged["observations"], staged["actions"], advantages)
         return base_stats
 
+    def _bind_empty_shard(self):
+        """a rank that holds no trajectories this iteration (more ranks than paths): it binds zero rows and still takes part in
+        every rank sum -- statistics, gradient, Fisher products -- so the other ranks' update is the one-process update"""
+        eng = self.engine
+        from ..utils import ranks
+        if _dist() is not None:
+            ranks.all_true(False)                        # the others' "does every rank hold a device block" round: no
+        mean, std = self._global_mean_std(np.zeros(0))
+        base_stats, self.running_score = self._path_statistics([])
+        self._push_policy()
+        z = np.zeros
+        eng.set_batch(z((0, self.policy.n), np.float32), z((0, self.policy.m), np.float32), z(0, np.float32))
+        return base_stats
+
     def _global_mean_std(self, x):
         """population mean / std of a sample vector that is sharded over the ranks"""
-        d = _dist()
-        if d is None:
+        if _dist() is None:
             return np.mean(x), np.std(x)
-        torch = self.engine.torch
-        s = torch.tensor([x.sum(), float(x.size)], dtype=torch.float64, device=self.engine.device)
-        d.all_reduce(s)
-        mean = float(s[0] / s[1])
-        q = torch.tensor([((x - mean) ** 2).sum()], dtype=torch.float64, device=self.engine.device)
-        d.all_reduce(q)
-        return mean, float(np.sqrt(q.item() / s[1].item()))
+        from ..utils import ranks
+        return ranks.mean_std(x)
 
     def _global_column_mean_std(self, X):
         """column-wise population mean / std of a (rows, n) block that is sharded over the ranks (the observation
@@ -277,8 +308,13 @@ class BatchREINFORCE:
         return mean, np.sqrt(q.cpu().numpy() / cnt)
 
     def log_rollout_statistics(self, paths):
-        """batch_reinforce.py:200-214"""
+        """batch_reinforce.py:200-214 (over the paths of all ranks, like every other logged statistic)"""
         path_returns = [float(np.sum(p["rewards"])) for p in paths]
+        d = _dist()
+        if d is not None:
+            gathered = [None] * d.get_world_size()
+            d.all_gather_object(gathered, path_returns)
+            path_returns = [r for g in gathered for r in g]
         self.logger.log_kv('stoc_pol_mean', np.mean(path_returns))
         self.logger.log_kv('stoc_pol_std', np.std(path_returns))
         self.logger.log_kv('stoc_pol_max', np.amax(path_returns))

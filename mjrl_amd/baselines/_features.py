@@ -19,6 +19,11 @@ def torch_dev():
     return torch, torch.device("cuda", torch.cuda.current_device())
 
 
+def num_features(kind, n):
+    """F of the ridge baselines' feature map (quadratic_baseline.py:20 / linear_baseline.py:20)"""
+    return int(_lib.load().mjx_bl_num_features(int(kind), int(n)))
+
+
 def stream(torch, dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -42,6 +47,18 @@ def _time_index(paths):
     starts = np.zeros(len(paths), np.int64)
     np.cumsum(lens[:-1], out=starts[1:])
     return (np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(starts, lens)).astype(np.int32)
+
+
+class DeviceOnly:
+    """torch, the current device, libmjx and the registry handle -- what a kernel call needs besides its tensors"""
+
+    def __init__(self):
+        self.torch, self.dev = torch_dev()
+        self.lib = _lib.load()
+        self.handle = ingest.DeviceHandle(self.torch, self.dev, self.lib)
+
+    def st(self):
+        return stream(self.torch, self.dev)
 
 
 class DeviceBlock:

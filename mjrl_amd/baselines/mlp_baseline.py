@@ -11,8 +11,8 @@ import ctypes
 import numpy as np
 
 from .._lib import check, ptr
-from ..utils import ingest
-from ._features import DeviceBlock
+from ..utils import ingest, ranks
+from ._features import DeviceBlock, DeviceOnly
 
 
 class MLPBaseline:
@@ -42,18 +42,36 @@ class MLPBaseline:
         return (ctypes.c_int * max(1, len(self.hidden_sizes)))(*self.hidden_sizes)
 
     def _forward(self, blk, feat, params_t):
-        out = blk.torch.empty(blk.N, dtype=blk.torch.float32, device=blk.dev)
-        check(blk.lib.mjx_mlp_predict(ptr(feat), blk.N, self.n + 4, self._hid(), len(self.hidden_sizes), ptr(params_t), ptr(out), blk.st()))
+        N = int(feat.shape[0])
+        out = blk.torch.empty(N, dtype=blk.torch.float32, device=blk.dev)
+        check(blk.lib.mjx_mlp_predict(ptr(feat), N, self.n + 4, self._hid(), len(self.hidden_sizes), ptr(params_t), ptr(out), blk.st()))
         return out
 
     def fit(self, paths, return_errors=False):
-        blk = DeviceBlock(paths, self.inp)
-        torch = blk.torch
-        feat = blk.mlp_features()
-        y64 = blk.returns_dev()                                # fp64, left on the device by compute_returns when possible
-        num_samples = int(y64.shape[0])
-        y = torch.empty(num_samples, dtype=torch.float32, device=blk.dev)
-        check(blk.lib.mjx_cast_f64_f32(ptr(y64), num_samples, ptr(y), blk.st()))     # == astype('float32') (mlp_baseline.py:66)
+        """mlp_baseline.py:61-95 + optimize_model.py:7-36.  With torch.distributed initialised `paths` is this rank's trajectory
+        shard; the reference fits ONE network on all paths of the iteration (batch_reinforce.py:94-110), and minibatch Adam is a
+        sequential chain, not a sum over samples -- so the ranks' fp32 feature blocks and returns are concatenated in rank order
+        (one all-gather of N x (n + 5) floats) and EVERY rank runs the identical persistent trainer on the whole block from the
+        same permutations (the LAST rank's draw from NumPy's global stream -- it sampled the batch's last episodes, so under the
+        samplers' per-episode seeding its stream stands where a single process's would; every rank draws, so the streams advance
+        alike).  The
+        trainer is one workgroup whatever the batch size: running it redundantly costs no wall time over running it once and
+        broadcasting, and the ranks' baselines stay bit-identical -- equal to a one-rank fit on the rank-ordered paths."""
+        if paths:
+            blk = DeviceBlock(paths, self.inp)
+            torch = blk.torch
+            feat = blk.mlp_features()
+            y64 = blk.returns_dev()                            # fp64, left on the device by compute_returns when possible
+            y = torch.empty(int(y64.shape[0]), dtype=torch.float32, device=blk.dev)
+            check(blk.lib.mjx_cast_f64_f32(ptr(y64), int(y64.shape[0]), ptr(y), blk.st()))   # == astype('float32') (mlp_baseline.py:66)
+        else:                                                  # a rank without trajectories still takes part in the gather
+            blk = DeviceOnly()
+            torch = blk.torch
+            feat = torch.zeros((0, self.n + 4), dtype=torch.float32, device=blk.dev)
+            y = torch.zeros(0, dtype=torch.float32, device=blk.dev)
+        if ranks.group() is not None:
+            feat, y = ranks.gather_rows(feat).contiguous(), ranks.gather_rows(y).contiguous()
+        num_samples = int(y.shape[0])
         if return_errors:
             returns = ingest.download(blk.handle, y)
         p = torch.from_numpy(self.params).to(blk.dev)
@@ -63,6 +81,7 @@ class MLPBaseline:
         m, v = torch.from_numpy(self.adam_m).to(blk.dev), torch.from_numpy(self.adam_v).to(blk.dev)
         perm = np.concatenate([np.random.permutation(num_samples) for _ in range(self.epochs)]).astype(np.int32) \
             if self.epochs > 0 else np.zeros(1, np.int32)
+        perm = ranks.broadcast_host(perm, src=-1)               # (one process: itself)
         perm_t = ingest.upload(blk.handle, perm)
         losses = torch.zeros(max(self.epochs, 1), dtype=torch.float64, device=blk.dev)
         check(blk.lib.mjx_mlp_fit_adam(ptr(feat), ptr(y), num_samples, self.n + 4, self._hid(), len(self.hidden_sizes), ptr(p), ptr(m),

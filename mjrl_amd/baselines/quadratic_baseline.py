@@ -11,7 +11,8 @@ import copy
 
 import numpy as np
 
-from ._features import FEAT_LINEAR, FEAT_QUADRATIC, DeviceBlock
+from ..utils import ranks
+from ._features import FEAT_LINEAR, FEAT_QUADRATIC, DeviceBlock, num_features
 
 
 def _few_blas_threads(limit=8):
@@ -70,19 +71,35 @@ class _RidgeBaseline:
             return None
 
     def fit(self, paths, return_errors=False):
-        blk = DeviceBlock(paths, self.inp)
-        y = blk.returns_dev()                                  # stays on the device when compute_returns put it there
+        """quadratic_baseline.py:44-69 / linear_baseline.py:37-60.  With torch.distributed initialised `paths` is this rank's
+        trajectory shard and the fit is still ONE fit over all ranks' paths, as in the reference (batch_reinforce.py:94-110 hands
+        every path of the iteration to baseline.fit): the augmented normal equations [A y]^T [A y] -- (F+1)^2 fp64, 5.4 MB at
+        BASELINE configs[4] -- and the error sums are summed over the ranks before the host solve, so every rank ends with the
+        same coefficients (the same bits: one all-reduce result, the same LAPACK call) and the same logged errors."""
+        blk = DeviceBlock(paths, self.inp) if paths else None           # (a rank without trajectories contributes zeros)
         if return_errors:
-            returns = np.concatenate([path["returns"] for path in paths])
-            predictions = blk.predict_linear(self._kind, self._coeffs) if self._coeffs is not None else np.zeros(returns.shape)
-            error_before = np.sum((returns - predictions) ** 2) / np.sum(returns ** 2)
-        Gaug = blk.gram(self._kind, y)
+            error_before = self._relative_error(blk, paths)
+        if blk is not None:
+            Gaug = blk.gram(self._kind, blk.returns_dev())
+        else:
+            F1 = num_features(self._kind, self.n) + 1
+            Gaug = np.zeros((F1, F1))
+        Gaug = ranks.sum_host(Gaug)                                      # (one process: itself)
         F = Gaug.shape[0] - 1
         self._coeffs = self._solve(Gaug[:F, :F], Gaug[:F, F])
         if return_errors:
-            predictions = blk.predict_linear(self._kind, self._coeffs)
-            error_after = np.sum((returns - predictions) ** 2) / np.sum(returns ** 2)
-            return error_before, error_after
+            return error_before, self._relative_error(blk, paths)
+
+    def _relative_error(self, blk, paths):
+        """sum (returns - predictions)^2 / sum returns^2 over the paths of ALL ranks (quadratic_baseline.py:50-52, 66-68)"""
+        if blk is not None:
+            returns = np.concatenate([path["returns"] for path in paths])
+            predictions = blk.predict_linear(self._kind, self._coeffs) if self._coeffs is not None else np.zeros(returns.shape)
+            sums = np.array([np.sum((returns - predictions) ** 2), np.sum(returns ** 2)])
+        else:
+            sums = np.zeros(2)
+        sums = ranks.sum_host(sums)
+        return sums[0] / sums[1]
 
     def predict_batch_device(self, paths, shared=True):
         """concatenated predictions as an fp64 device block (utils/process_samples keeps the GAE chain on the device);

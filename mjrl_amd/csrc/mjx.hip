@@ -88,13 +88,14 @@ struct mjx_ctx {
   size_t prof_seen = 0;
   void* comm = nullptr; int comm_world = 0, comm_rank = 0;   // RCCL communicator (one process per GPU)
   mjx_reduce_fn reduce_cb = nullptr; void* reduce_user = nullptr;   // transport hook in its place (tests)
-  // peer exchange (mjx_peer_*): one uncached device buffer per rank [2 parities][world slots] | arrival counter, the peers' mapped
-  // through HIP IPC; every all-reduce = store the vector into slot `rank` of every buffer + bump the peers' counters, one
-  // stream-ordered wait on the own counter, rank-ordered sum of the local slots (vecops.h "Peer exchange")
+  // peer exchange (mjx_peer_*): one uncached device buffer per rank [2 parities][world slots] | flag block, the peers' mapped
+  // through HIP IPC; every all-reduce = store the vector into slot `rank` of every buffer + raise this rank's flag at every
+  // peer, one bounded in-kernel wait on the own flags, rank-ordered sum of the local slots (vecops.h "Peer exchange")
   struct Peer {
-    bool on = false; int rank = 0, world = 0;
+    bool on = false, loopback = false; int rank = 0, world = 0;
     char* buf = nullptr; char* map[16] = {nullptr};
     size_t slot_bytes = 0; uint32_t seq = 0;
+    unsigned long long timeout_ticks = 500000000ull;   // 100 MHz ticks a consumer waits for a peer (MJX_PEER_TIMEOUT_MS; default 5 s)
   } peer;
   unsigned* ticket = nullptr;                      // workgroup ticket of the producer kernels (ordinary device memory, zero between launches)
   mjx::LayerwiseWS lw;             // layer-wise path workspace
@@ -706,24 +707,31 @@ namespace {
 bool has_ranks(const mjx_ctx* c) { return c->comm || c->reduce_cb || c->peer.on; }
 // slot `r` (the vector rank r contributed) of parity `par` in rank q's buffer; the arrival counter and the producers' ticket
 char* peer_slot(const mjx_ctx* c, int q, int par, int r) { return c->peer.map[q] + (size_t)(par * c->peer.world + r) * c->peer.slot_bytes; }
-unsigned* peer_counter(const mjx_ctx* c, int q) { return (unsigned*)(c->peer.map[q] + (size_t)2 * c->peer.world * c->peer.slot_bytes); }
-PeerPush peer_push(const mjx_ctx* c, int par) {
+// the flag block behind the slots of rank q's buffer: [0..15] one arrival flag per SOURCE rank (32-bit exchange numbers),
+// [32] timed-out waits of this rank's consumers (mjx_peer_status); a slot of zeros follows at +256
+unsigned* peer_flags(const mjx_ctx* c, int q) { return (unsigned*)(c->peer.map[q] + (size_t)2 * c->peer.world * c->peer.slot_bytes); }
+PeerPush peer_push(const mjx_ctx* c, int par, uint32_t seq) {
   PeerPush pp{};
-  pp.world = c->peer.world; pp.rank = c->peer.rank;
+  pp.world = c->peer.world; pp.rank = c->peer.rank; pp.seq = seq;
   pp.ticket = c->ticket;
-  for (int q = 0; q < c->peer.world; ++q) { pp.dst[q] = peer_slot(c, q, par, c->peer.rank); pp.counter[q] = peer_counter(c, q); }
+  for (int q = 0; q < c->peer.world; ++q) {
+    pp.dst[q] = peer_slot(c, q, par, c->peer.rank);
+    // the flag rank q polls for this rank; loop-back rehearsal (every peer is the own buffer): the flag this rank polls for "peer" q
+    pp.flag[q] = c->peer.loopback ? peer_flags(c, c->peer.rank) + q : peer_flags(c, q) + c->peer.rank;
+  }
   return pp;
 }
-// (the counter is 32 bits and compared as a signed difference: exchange numbers may wrap, a wait just must not span 2^31 arrivals)
-// the consumer's view of exchange `seq`: its local slots in rank order (the surplus entries: a slot of zeros behind the counter
-// block), the own arrival counter and the value it reaches once every peer has delivered
+// (exchange numbers are 32 bits and compared as a signed difference: they may wrap)
+// the consumer's view of exchange `seq`: its local slots in rank order (the surplus entries: a slot of zeros behind the flag
+// block) and the flags the peers raise to `seq` once their vectors have landed
 PeerSlots peer_slots(const mjx_ctx* c, int par, uint32_t seq) {
   PeerSlots ps{};
-  ps.world = c->peer.world;
-  const char* zeros = (const char*)peer_counter(c, c->peer.rank) + 256;
+  ps.world = c->peer.world; ps.rank = c->peer.rank; ps.seq = seq;
+  const char* zeros = (const char*)peer_flags(c, c->peer.rank) + 256;
   for (int r = 0; r < 16; ++r) ps.slot[r] = r < c->peer.world ? peer_slot(c, c->peer.rank, par, r) : zeros;
-  ps.counter = peer_counter(c, c->peer.rank);
-  ps.target = seq * (uint32_t)(c->peer.world - 1);
+  ps.flags = peer_flags(c, c->peer.rank);
+  ps.timeouts = peer_flags(c, c->peer.rank) + 32;
+  ps.ticks = c->peer.timeout_ticks;
   return ps;
 }
 int peer_allreduce(mjx_ctx* c, void* buf, int64_t count, int dtype, hipStream_t st) {
@@ -732,8 +740,8 @@ int peer_allreduce(mjx_ctx* c, void* buf, int64_t count, int dtype, hipStream_t 
   const uint32_t seq = ++c->peer.seq;
   const int par = (int)(seq & 1u);
   const unsigned grid = (unsigned)((count + 255) / 256);
-  if (dtype) hipLaunchKernelGGL(k_peer_push<double>, dim3(grid), dim3(256), 0, st, (const double*)buf, peer_push(c, par), count);
-  else hipLaunchKernelGGL(k_peer_push<float>, dim3(grid), dim3(256), 0, st, (const float*)buf, peer_push(c, par), count);
+  if (dtype) hipLaunchKernelGGL(k_peer_push<double>, dim3(grid), dim3(256), 0, st, (const double*)buf, peer_push(c, par, seq), count);
+  else hipLaunchKernelGGL(k_peer_push<float>, dim3(grid), dim3(256), 0, st, (const float*)buf, peer_push(c, par, seq), count);
   HIPCHK(hipGetLastError());
   if (dtype) hipLaunchKernelGGL(k_peer_sum<double>, dim3(grid), dim3(256), 0, st, peer_slots(c, par, seq), (double*)buf, count);
   else hipLaunchKernelGGL(k_peer_sum<float>, dim3(grid), dim3(256), 0, st, peer_slots(c, par, seq), (float*)buf, count);
@@ -780,7 +788,7 @@ int mjx_cg_solve(mjx_ctx* c, const float* b, int iters, float damping, double to
       // (A rank on another route -- empty shard -- runs the same exchange through mjx_comm_allreduce.)
       const uint32_t seq = ++c->peer.seq;
       const int par = (int)(seq & 1u);
-      const PeerPush pp = peer_push(c, par);
+      const PeerPush pp = peer_push(c, par, seq);
       if (int rc = fvp_impl(c, c->cg_p, (float*)peer_slot(c, c->peer.rank, par, c->peer.rank), stream, &pp)) return rc;
       const PeerSlots ps = peer_slots(c, par, seq);
 #define MJX_STEP_W(W) hipLaunchKernelGGL((k_cg_step_reg<8, W>), dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)nullptr, damping, tol, \
@@ -853,7 +861,7 @@ int mjx_peer_export(mjx_ctx* c, int rank, int world, char* handle_out) {
   if (slot < 64 * sizeof(double)) slot = 64 * sizeof(double);
   slot = (slot + 255) & ~(size_t)255;
   void* p = nullptr;
-  const size_t total = (size_t)(2 * world + 1) * slot + 256;      // [2 parities][world slots] | arrival counter (256 B) | one slot of zeros
+  const size_t total = (size_t)(2 * world + 1) * slot + 256;      // [2 parities][world slots] | flag block (256 B) | one slot of zeros
   HIPCHK(hipExtMallocWithFlags(&p, total, hipDeviceMallocUncached));
   HIPCHK(hipMemset(p, 0, total));
   HIPCHK(hipDeviceSynchronize());
@@ -862,6 +870,10 @@ int mjx_peer_export(mjx_ctx* c, int rank, int world, char* handle_out) {
   static_assert(sizeof(hipIpcMemHandle_t) == MJX_PEER_HANDLE_BYTES, "handle size");
   memcpy(handle_out, &h, sizeof h);
   c->peer.buf = (char*)p; c->peer.slot_bytes = slot; c->peer.rank = rank; c->peer.world = world; c->peer.seq = 0;
+  if (const char* ms = getenv("MJX_PEER_TIMEOUT_MS")) {             // how long a consumer kernel waits for a peer's vector
+    const double v = atof(ms);
+    if (v > 0.0) c->peer.timeout_ticks = (unsigned long long)(v * 1e5);
+  }
   return MJX_OK;
 }
 
@@ -878,7 +890,20 @@ int mjx_peer_connect(mjx_ctx* c, const char* handles) {
     if (e != hipSuccess) return fail((int)e, "hipIpcOpenMemHandle (rank %d): %s", r, hipGetErrorString(e));
     c->peer.map[r] = (char*)q;
   }
-  c->peer.on = true; c->comm_world = c->peer.world; c->comm_rank = c->peer.rank;
+  c->peer.on = true; c->peer.loopback = (handles == nullptr);
+  c->comm_world = c->peer.world; c->comm_rank = c->peer.rank;
+  return MJX_OK;
+}
+
+int mjx_peer_status(mjx_ctx* c, int* timeouts_out) {
+  if (!c || !timeouts_out) return fail(MJX_ERR_ARG, "bad arguments");
+  *timeouts_out = 0;
+  if (!c->peer.on) return MJX_OK;
+  HIPCHK(hipSetDevice(c->device));
+  unsigned n = 0;
+  HIPCHK(hipMemcpy(&n, peer_flags(c, c->peer.rank) + 32, sizeof n, hipMemcpyDeviceToHost));   // (synchronises: read after the update's own read-back)
+  if (n) HIPCHK(hipMemset(peer_flags(c, c->peer.rank) + 32, 0, sizeof n));
+  *timeouts_out = (int)n;
   return MJX_OK;
 }
 

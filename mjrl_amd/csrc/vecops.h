@@ -87,20 +87,24 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
   }
 }
 
-// Peer exchange (mjx_peer_*).  Every rank owns one uncached buffer [2 parities][world slots] + an arrival counter; the peers'
-// buffers are mapped through hipIpcOpenMemHandle.  An all-reduce = every rank WRITES its vector into slot `rank` of every
-// buffer (posted stores over xGMI), then adds 1 to every peer's counter; the consumer kernel waits (bounded) on its OWN counter
-// -- local memory -- and sums its local slots in rank order: the same bits on every rank, no host in the loop.
+// Peer exchange (mjx_peer_*).  Every rank owns one uncached buffer [2 parities][world slots] + one arrival flag PER SOURCE RANK;
+// the peers' buffers are mapped through hipIpcOpenMemHandle.  An all-reduce = every rank WRITES its vector into slot `rank` of
+// every buffer (posted stores over xGMI), then stores the exchange number into ITS flag in every peer's buffer; the consumer
+// kernel waits (bounded) on the flags of its OWN buffer -- local memory, one polling thread per source rank -- and sums its local
+// slots in rank order: the same bits on every rank, no host in the loop.  A flag is written by exactly one rank over the same
+// path as that rank's data stores, after they were acknowledged: no ordering between DIFFERENT peers' traffic is relied upon
+// (an aggregate counter would need it for world > 2).
 struct PeerSlots {                     // consumer: the local slots of this exchange (entries >= world point at a slot of zeros)
-  const void* slot[16]; const unsigned* counter; unsigned target; int world;
+  const void* slot[16]; const unsigned* flags; unsigned* timeouts; unsigned long long ticks; unsigned seq; int world, rank;
 };
-struct PeerPush { void* dst[16]; unsigned* counter[16]; unsigned* ticket; int world, rank; };  // producer: slot `rank` in every buffer; world == 0: off
+// producer: slot `rank` in every buffer + the flag each peer polls for this rank; world == 0: off
+struct PeerPush { void* dst[16]; unsigned* flag[16]; unsigned* ticket; unsigned seq; int world, rank; };
 
 // tail of a producer kernel (all threads call it): once the LAST workgroup's stores are visible system-wide, one thread
-// bumps every peer's arrival counter.  The ticket lives in ordinary device memory and is left at zero for the next kernel.
+// raises this rank's flag at every peer.  The ticket lives in ordinary device memory and is left at zero for the next kernel.
 __device__ __forceinline__ void peer_signal_tail(const PeerPush& pp) {
   // the slots are uncached (MTYPE UC) memory: a store is acknowledged by the memory (or the link) it went to, no cache holds it
-  // back -- waiting for the acknowledgements orders the stores before the counter updates without a system-scope release (which
+  // back -- waiting for the acknowledgements orders the stores before the flag stores without a system-scope release (which
   // on gfx950 writes back every dirty line of the L2, here the whole partials array: +10 us per launch)
 #ifdef MJX_PEER_SYSTEM_FENCE
   __threadfence_system();
@@ -113,23 +117,28 @@ __device__ __forceinline__ void peer_signal_tail(const PeerPush& pp) {
     if (t == gridDim.x - 1) {
       __hip_atomic_store(pp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int q = 0; q < pp.world; ++q)
-        if (q != pp.rank) __hip_atomic_fetch_add(pp.counter[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (q != pp.rank) __hip_atomic_store(pp.flag[q], pp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
-// head of a consumer kernel (all threads call it): every peer adds 1 per exchange and none can be more than one exchange
-// ahead, so the counter reaches `target` = exchange number x (world - 1) exactly when all vectors have arrived.  A peer that
-// never delivers must not hang the GPU: after 5 s the wait gives up and the caller poisons its result with NaN.
+// head of a consumer kernel (all threads call it): source rank r stores the exchange number into flag r once its vector has
+// landed; no rank can be more than one exchange ahead of another, so flag r - seq is -1, 0 or +1 (32-bit wrap-around included).
+// Thread r polls flag r.  A peer that never delivers must not hang the GPU: after `ticks` (100 MHz; MJX_PEER_TIMEOUT_MS, default
+// 5 s) the wait gives up, counts the event in `timeouts` (mjx_peer_status) and the caller poisons its result with NaN.
 __device__ __forceinline__ bool peer_arrived(const PeerSlots& ps) {
   __shared__ int arrived;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) arrived = 1;
+  __syncthreads();
+  if ((int)threadIdx.x < ps.world && (int)threadIdx.x != ps.rank) {
     const unsigned long long t0 = wall_clock64();           // 100 MHz
-    int good = 1;
-    while ((int)(__hip_atomic_load(ps.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - ps.target) < 0) {
+    while ((int)(__hip_atomic_load(ps.flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - ps.seq) < 0) {
       __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > 500000000ull) { good = 0; break; }
+      if (wall_clock64() - t0 > ps.ticks) {
+        arrived = 0;
+        if (blockIdx.x == 0) atomicAdd(ps.timeouts, 1u);
+        break;
+      }
     }
-    arrived = good;
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");              // system scope: nothing read below may predate the arrivals

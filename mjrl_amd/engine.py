@@ -172,10 +172,21 @@ class HipBackend:
             check(self.lib.mjx_peer_connect(self.ctx, None))
             return
         buf = ctypes.create_string_buffer(64)
-        check(self.lib.mjx_peer_export(self.ctx, int(rank), int(world), buf))
+        rc = self.lib.mjx_peer_export(self.ctx, int(rank), int(world), buf)
+        # every rank takes part in the gather whatever its own export did (a rank that skipped it would leave the others blocked
+        # in the collective): a failed export travels as an empty handle and fails the connect on ALL ranks
         handles = [None] * world
-        dist.all_gather_object(handles, buf.raw)
+        dist.all_gather_object(handles, buf.raw if rc == 0 else b"")
+        check(rc)
+        if any(len(h) != 64 for h in handles):
+            raise _lib.MjxError("peer exchange: rank(s) %s could not export their buffer" % [r for r, h in enumerate(handles) if len(h) != 64])
         check(self.lib.mjx_peer_connect(self.ctx, ctypes.create_string_buffer(b"".join(handles), 64 * world)))
+
+    def peer_timeouts(self):
+        """number of peer-exchange waits that gave up since the last call (include/mjx.h mjx_peer_status)"""
+        n = ctypes.c_int(0)
+        check(self.lib.mjx_peer_status(self.ctx, ctypes.byref(n)))
+        return int(n.value)
 
     def allreduce(self, t):
         """in-place sum over the ranks on the launch stream (fp32 / fp64 tensors)"""
@@ -367,42 +378,61 @@ class UpdateEngine:
         d = _dist()
         ok = False
         if d is not None and hasattr(self.backend, "comm_init") and os.environ.get("MJX_NATIVE_COMM", "1") != "0":
-            try:
-                # MJX_PEER_COMM=1: libmjx's own peer exchange (HIP IPC + stream-ordered flags) instead of RCCL; it is also what a
-                # process group that is not RCCL gets (gloo ranks sharing one GPU in the tests; MJX_PEER_COMM=0: the host-side hook)
-                peer = os.environ.get("MJX_PEER_COMM")
-                if (d.get_world_size() > 1 or int(os.environ.get("MJX_PEER_LOOPBACK_WORLD", "0")) > 1) and (
-                        peer == "1" or (d.get_backend() != "nccl" and peer != "0")):
-                    self.backend.peer_connect_all(d)
-                    self.comm_kind = "peer"
-                elif d.get_backend() == "nccl":
-                    box = [self.backend.comm_unique_id() if d.get_rank() == 0 else None]
-                    if d.get_world_size() > 1:
-                        d.broadcast_object_list(box, src=0)
-                    with _stdout_to_stderr():         # RCCL prints a version banner to stdout when a communicator is created
-                        self.backend.comm_init(d.get_rank(), d.get_world_size(), box[0])
-                    self.comm_kind = "rccl"
-                else:                                # same C loops, transport hooked to dist.all_reduce (a host synchronisation per sum)
-                    self.backend.comm_set_callback(d, d.get_world_size())
-                    self.comm_kind = "hook"
-                ok = True
-            except Exception as e:                   # pragma: no cover - depends on the host's RCCL
-                import warnings
-                warnings.warn("mjrl_amd: rank sums inside libmjx unavailable (%s); using torch.distributed collectives" % (e,))
-        if d is not None and d.get_world_size() > 1 and hasattr(self.backend, "comm_init"):
-            # every rank must take the same path -- RCCL inside libmjx and the one-call loops on some ranks, torch.distributed
-            # calls on others would issue different collectives and hang: all or none
-            flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.device if d.get_backend() == "nccl" else "cpu")
-            d.all_reduce(flag, op=d.ReduceOp.MIN)
-            if ok and int(flag.item()) == 0:
-                ok = False
-                try:
-                    check(self.lib.mjx_comm_destroy(self.ctx))
-                    check(self.lib.mjx_comm_set_callback(self.ctx, _lib.REDUCE_FN(0), None, 0))
-                except Exception:                    # pragma: no cover
-                    pass
+            # MJX_PEER_COMM=1: libmjx's own peer exchange (HIP IPC + in-kernel flags) instead of RCCL; it is also what a process
+            # group that is not RCCL gets (gloo ranks sharing one GPU in the tests; MJX_PEER_COMM=0: the host-side hook)
+            peer = os.environ.get("MJX_PEER_COMM")
+            multi = d.get_world_size() > 1
+            if (multi or int(os.environ.get("MJX_PEER_LOOPBACK_WORLD", "0")) > 1) and (
+                    peer == "1" or (d.get_backend() != "nccl" and peer != "0")):
+                order = ["peer"] + ([] if d.get_backend() == "nccl" else ["hook"])
+            elif d.get_backend() == "nccl":
+                order = ["rccl"]
+            else:
+                order = ["hook"]
+            # every rank walks the same list and the ranks agree after each attempt (all or none): RCCL inside libmjx and the
+            # one-call loops on some ranks, torch.distributed calls on others would issue different collectives and hang
+            for kind in order:
+                mine = self._attach_transport(kind, d)
+                if self._all_ranks(d, mine):
+                    ok, self.comm_kind = True, kind
+                    break
+                self._detach_transport()
         self._comm_state = ok
         return ok
+
+    def _attach_transport(self, kind, d):
+        try:
+            if kind == "peer":
+                self.backend.peer_connect_all(d)
+            elif kind == "rccl":
+                box = [self.backend.comm_unique_id() if d.get_rank() == 0 else None]
+                if d.get_world_size() > 1:
+                    d.broadcast_object_list(box, src=0)
+                with _stdout_to_stderr():         # RCCL prints a version banner to stdout when a communicator is created
+                    self.backend.comm_init(d.get_rank(), d.get_world_size(), box[0])
+            else:                                # same C loops, transport hooked to dist.all_reduce (a host synchronisation per sum)
+                self.backend.comm_set_callback(d, d.get_world_size())
+            return True
+        except Exception as e:                   # pragma: no cover - depends on the host's RCCL / IPC support
+            import warnings
+            warnings.warn("mjrl_amd: rank sums inside libmjx over '%s' unavailable (%s)" % (kind, e))
+            return False
+
+    def _all_ranks(self, d, flag):
+        if d.get_world_size() <= 1:
+            return bool(flag)
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int32, device=self.device if d.get_backend() == "nccl" else "cpu")
+        d.all_reduce(t, op=d.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    def _detach_transport(self):
+        """undo a transport some rank could not attach (buffers, IPC maps, hook): the next candidate starts clean"""
+        self.comm_kind = None
+        try:
+            check(self.lib.mjx_comm_destroy(self.ctx))
+            check(self.lib.mjx_comm_set_callback(self.ctx, _lib.REDUCE_FN(0), None, 0))
+        except Exception:                        # pragma: no cover
+            pass
 
     def _rank_sum(self, *tensors):
         """sum device tensors over the ranks in place (no-op for a single process)"""
@@ -481,7 +511,7 @@ class UpdateEngine:
             self._host_results = None
             self.backend.npg_update(iters, damping, tol, step_size, const_alpha, min_log_std, self.grad, self.x, self.theta_new, self.results)
             self.old_is_new = False
-            s = self._host_results = self.results.cpu().numpy()
+            s = self._host_results = self._checked(self.results.cpu().numpy())
             return float(s[0] / self.N_global), float(s[1] / self.N_global)
         g, _ = self.surr_vpg(sync=False)
         self.cg_solve(g, iters, damping, tol, sync=const_alpha is not None)
@@ -510,7 +540,7 @@ class UpdateEngine:
         self.N_global, self.N_bound = N_on_global, int(rows_on)
         self._prefix = (int(rows_on), N_on_global, adv_dev)
         self.old_is_new = False
-        s = self._host_results = self.results.cpu().numpy()
+        s = self._host_results = self._checked(self.results.cpu().numpy())
         return float(s[0] / self.N_global), float(s[1] / self.N_global)
 
     def trpo_update(self, iters, damping, step_size, kl_dist, min_log_std, tol=1e-10, batch=3, max_trials=100):
@@ -533,7 +563,7 @@ class UpdateEngine:
                                      self.results)
             self.old_is_new = False
             first = False
-            s = self._host_results = self.results.cpu().numpy()
+            s = self._host_results = self._checked(self.results.cpu().numpy())
             trials, accepted = int(s[11]), s[10] != 0.0
             for k in range(len(hist), trials):
                 hist.append((float(s[16 + 2 * (k % 24)] / self.N_global), float(s[17 + 2 * (k % 24)] / self.N_global)))
@@ -549,6 +579,23 @@ class UpdateEngine:
             surr_after, kl = self.eval_surr_kl()
         return dict(alpha=alpha, trials=trials, accepted=bool(accepted), surr_after=surr_after, kl=kl, history=hist)
 
+    def _checked(self, s):
+        """the host copy of `results` after an update's read-back: a non-finite surrogate / KL / step length must not reach
+        policy.set_param_values silently.  The peer exchange turns a wait that timed out (a lost or late rank) into NaN
+        (csrc/vecops.h peer_arrived): say so; anything else non-finite is reported as what it is."""
+        if not np.all(np.isfinite(s[:10])):
+            timeouts = self.backend.peer_timeouts() if (self.comm_kind == "peer" and hasattr(self.backend, "peer_timeouts")) else 0
+            if timeouts:
+                self._comm_state, self.comm_kind = False, None       # the ranks' exchange sequences are out of step from here on
+                try:
+                    check(self.lib.mjx_comm_destroy(self.ctx))
+                except Exception:                    # pragma: no cover
+                    pass
+                raise _lib.MjxError("peer exchange: %d wait(s) for another rank's vector timed out (MJX_PEER_TIMEOUT_MS, default 5000); "
+                                    "the update is invalid and the transport was torn down" % timeouts)
+            raise _lib.MjxError("the policy update produced non-finite results (surrogate / KL / g.x / step length: %s)" % (s[:10],))
+        return s
+
     def deferred(self):
         """-> dict(surr_before, gdotx, alpha) of the calls made with sync=False / apply_npg_step (one read-back after the update)"""
         r = self._host_results                       # eval_surr_kl() already fetched the block: no further round trip
@@ -560,7 +607,7 @@ class UpdateEngine:
         """K3 -> (surrogate, mean KL) (batch_reinforce.py:40-52)."""
         self.backend.eval_surr_kl(self.scal)
         self._rank_sum(self.scal)
-        s = self._host_results = self.results.cpu().numpy()      # the whole block: deferred() needs no second read-back
+        s = self._host_results = self._checked(self.results.cpu().numpy())      # the whole block: deferred() needs no second read-back
         return float(s[0] / self.N_global), float(s[1] / self.N_global)
 
     def enable_debug(self):

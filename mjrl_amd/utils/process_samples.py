@@ -21,7 +21,7 @@ import numpy as np
 
 from .. import _lib
 from .._lib import check, ptr
-from . import ingest
+from . import ingest, ranks
 
 
 def _handle():
@@ -124,6 +124,8 @@ def compute_advantages(paths, baseline, gamma, gae_lambda=None, normalize=False)
     """process_samples.py:7-35 (1-D baselines).  GAE when 0 <= gae_lambda <= 1, else
     advantages = returns - baseline."""
     if not paths:
+        if normalize:
+            ranks.mean_std(np.zeros(0))                  # a rank without trajectories still takes part in the statistics
         return
     h = _handle()
     torch, dev = h.torch, h.device
@@ -141,9 +143,10 @@ def compute_advantages(paths, baseline, gamma, gae_lambda=None, normalize=False)
     adv = torch.empty_like(x)
     lam = float(gae_lambda) if use_gae else -1.0
     check(h.lib.mjx_gae(ptr(x), ptr(b), ptr(_offsets_dev(h, paths, off)), ptr(term), len(paths), float(gamma), lam, ptr(adv), _stream(h)))
-    if normalize:                                        # process_samples.py:14-19 / 30-35: over the whole batch
+    if normalize:                                        # process_samples.py:14-19 / 30-35: over the whole batch -- of ALL ranks
         out = ingest.download(h, adv)
-        out = (out - out.mean()) / (out.std() + 1e-8)
+        mean, std = ranks.mean_std(out)
+        out = (out - mean) / (std + 1e-8)
         for i, p in enumerate(paths):
             p["advantages"] = out[off[i]:off[i + 1]]
         return

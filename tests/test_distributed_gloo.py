@@ -76,7 +76,7 @@ def test_two_ranks_match_one(algo, tmp_path):
     from tests.test_distributed_gloo import make_problem as mk
     theta0 = mk()[1].astype(np.float64)
     err = np.linalg.norm((step2 - theta0) - (step1 - theta0)) / np.linalg.norm(step1 - theta0)
-    assert err < 2e-5, err
+    assert err < 1e-5, err                                                # the north-star bar on the step direction
     assert abs(float(r0["alpha"]) - float(one["alpha"])) < 1e-5 * float(one["alpha"])
     assert abs(float(r0["kl"]) - float(one["kl"])) < 1e-4 * abs(float(one["kl"])) + 1e-8
     np.testing.assert_allclose(r0["stats"], one["stats"], rtol=1e-12)      # return statistics over ALL ranks' paths

@@ -349,15 +349,16 @@ def test_bench_two_rank_path_on_one_gpu():
     import subprocess
     import sys
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"],
                          env=base, capture_output=True, text=True, timeout=280)
     assert one.returncode == 0, one.stderr[-3000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    port = 29300 + (os.getpid() % 300)
+    # `python bench.py --gpus 2` on its own (WORLD_SIZE unset): the script launches its two ranks itself (the driver's command)
     env = dict(base, MJX_BENCH_SHARE_GPU="1", MJX_BENCH_BACKEND="gloo")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=280)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=280)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
     lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                # rank 0 only
