@@ -470,12 +470,23 @@ int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, con
       MlpFitArgs a{feat, y, perm, N, d_in, epochs, steps_, params, m, v, (float*)mvws.p, step0, lr, wd, epoch_loss_out};
       static thread_local bool configured = false;
       if (!configured) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         configured = true;
       }
-      if (d_in <= 31) hipLaunchKernelGGL((k_mlp_fit<128, 1>), dim3(1), dim3(256), L.bytes(), st, a);
-      else hipLaunchKernelGGL((k_mlp_fit<128, 2>), dim3(1), dim3(256), L.bytes(), st, a);   // (32 <= d_in <= 55: what 160 KB of LDS hold)
+      // r04: the Adam moments a thread owns stay in its registers for the whole run (REGMOM, mlp_fit.h); MJX_FIT_REGMOM=0: the r03
+      // kernels, which stream them through L2 in every step (same arithmetic, same bits)
+      const char* rm = getenv("MJX_FIT_REGMOM");            // (read per call: the tests compare the two in one process)
+      const bool regmom = !(rm && rm[0] == '0');
+      if (d_in <= 31) {
+        if (regmom) hipLaunchKernelGGL((k_mlp_fit<128, 1, true>), dim3(1), dim3(256), L.bytes(), st, a);
+        else hipLaunchKernelGGL((k_mlp_fit<128, 1, false>), dim3(1), dim3(256), L.bytes(), st, a);
+      } else {                                                // (32 <= d_in <= 55: what 160 KB of LDS hold)
+        if (regmom) hipLaunchKernelGGL((k_mlp_fit<128, 2, true>), dim3(1), dim3(256), L.bytes(), st, a);
+        else hipLaunchKernelGGL((k_mlp_fit<128, 2, false>), dim3(1), dim3(256), L.bytes(), st, a);
+      }
       HIPCHK(hipGetLastError());
       return MJX_OK;
     }

@@ -74,7 +74,11 @@ struct MlpFitLayout {
 
 // NF1: 32-feature blocks of the input layer's weight gradient -- 1 for d_in <= 31 (the MuJoCo locomotion observations + 4 time
 // features), 2 for d_in <= 63 as far as the LDS layout fits 160 KB (d_in <= 55: all Adroit observations, 39..46 wide).
-template <int H, int NF1 = 1>
+// REGMOM: the Adam moments of the weights a thread owns (83 (m, v) pairs at NF1 = 1) stay in its registers for the WHOLE run --
+// loaded once before the first step, written back after the last -- instead of streaming 2 x 156 KB through the CU's L2 path in
+// every step (r02 measured the Adam phase as bound by exactly that traffic, not by its arithmetic).  The compute phase needs
+// ~250 of the 512 registers of a one-wave-per-SIMD kernel; the pairs take 166 more (the allocator parks them in AGPRs).
+template <int H, int NF1 = 1, bool REGMOM = false>
 __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   static_assert(H == 128, "wave w owns unit tile w: 4 waves x 32 units");
   using LT = MlpFitLayout<H>;
@@ -140,6 +144,53 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
       if (gs[c] >= 0) { if (NF1 == 1) xs[gs[c] * S1 + gf[c]] = gx[c]; xT[gf[c] * ST + gs[c]] = gx[c]; }
     if (tid < 32) sY[tid] = gy;
   };
+
+  // ---- which weights this thread applies Adam to, and where their moment pairs live.  Every owned element sits at a
+  // compile-time offset from one per-lane base.  Without REGMOM ALL moment pairs a thread owns -- its 64 W2
+  // weights, its 16 W1 / b1 entries, its b2 / W3 / b3 entry -- are requested at the top of every Adam phase (the backward pass's
+  // registers are free by then), so the L2 latency is paid once per step and not once per block; then update, write the weight to
+  // LDS and the pair back.  Threads that do not own an entry of a block read a valid dummy pair and store nothing.
+  f32x2* __restrict__ MV = (f32x2*)A.mv;
+  const int64_t gbase2 = oW2g + (int64_t)(32 * w + 4 * hi) * H + j;
+  f32x2* __restrict__ mvW2 = MV + gbase2;
+  float* pW2 = sW2 + (32 * w + 4 * hi) * S2 + j;
+  // W1 rows of this wave (feature f = 32 fb + j < d_in) and b1 (f == d_in): one base pointer + a small per-register stride
+  bool own1[NF1];
+  int stg[NF1];
+  f32x2* mvW1[NF1];
+  float* pW1[NF1];
+#pragma unroll
+  for (int fb = 0; fb < NF1; ++fb) {
+    const int f = 32 * fb + j;
+    const bool isw = f < d_in;
+    own1[fb] = f <= d_in;
+    stg[fb] = isw ? d_in : 1;
+    const int64_t gbase1 = isw ? oW1g + (int64_t)(32 * w + 4 * hi) * d_in + f : oB1g + 32 * w + 4 * hi;
+    mvW1[fb] = MV + (own1[fb] ? gbase1 : 0);
+    pW1[fb] = sW1 + (32 * w + 4 * hi) * S1 + (isw ? f : d_in);
+  }
+  const bool ownb2 = hi == 0, ownw3 = tid < H, ownb3 = tid == 0;
+  const int64_t gb2i = oB2g + 32 * w + j, gw3i = oW3g + (ownw3 ? tid : 0), gb3i = oB3g;
+  f32x2 q2[NT][16], q1[NF1][16], qb2, qw3, qb3;
+  if constexpr (REGMOM) {
+    // the pairs this thread owns, for the whole run (MV was filled above, barrier passed), re-paired for packed math:
+    // entry r (even) = the first moments of weights r, r + 1, entry r + 1 = their second moments
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 a = mvW2[unit_of(r, 0) * H + 32 * nt], b = mvW2[unit_of(r + 1, 0) * H + 32 * nt];
+        q2[nt][r] = f32x2{a.x, b.x}; q2[nt][r + 1] = f32x2{a.y, b.y};
+      }
+#pragma unroll
+    for (int fb = 0; fb < NF1; ++fb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 a = mvW1[fb][own1[fb] ? unit_of(r, 0) * stg[fb] : 0], b = mvW1[fb][own1[fb] ? unit_of(r + 1, 0) * stg[fb] : 0];
+        q1[fb][r] = f32x2{a.x, b.x}; q1[fb][r + 1] = f32x2{a.y, b.y};
+      }
+    qb2 = MV[gb2i]; qw3 = MV[gw3i]; qb3 = MV[gb3i];
+  }
 
   for (int ep = 0; ep < A.epochs; ++ep) {
     double ep_loss = 0.0;
@@ -372,57 +423,45 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         r = r * __builtin_elementwise_fma(-denom, r, (f32x2)(2.0f));
         return __builtin_elementwise_fma(mi * (f32x2)(-step_size), r, p);
       };
-      f32x2* __restrict__ MV = (f32x2*)A.mv;
-      // Every owned element sits at a compile-time offset from one per-lane base.  ALL moment pairs a thread owns -- its 64 W2
-      // weights, its 16 W1 / b1 entries, its b2 / W3 / b3 entry -- are requested up front (the backward pass's registers are
-      // free by now), so the L2 latency is paid once per step and not once per block (the three small blocks used to
-      // follow as dependent load -> update -> store sequences: ~2 k cycles each); then update, write the weight to LDS and
-      // the pair back.  Threads that do not own an entry of a block read a valid dummy pair and store nothing.
+      // ... and on moments that already sit as (m, m) / (v, v) pairs (REGMOM): no re-pairing moves
+      auto adam_math2p = [&](f32x2 p, f32x2 g, f32x2& mi, f32x2& vi) {
+        g = __builtin_elementwise_fma((f32x2)(A.wd), p, g);
+        mi = __builtin_elementwise_fma(g - mi, (f32x2)(1.0f - b1c), mi);
+        vi = __builtin_elementwise_fma(g * g, (f32x2)(1.0f - b2c), vi * (f32x2)(b2c));
+        const f32x2 denom = __builtin_elementwise_fma(f32x2{__builtin_amdgcn_sqrtf(vi.x), __builtin_amdgcn_sqrtf(vi.y)}, (f32x2)(inv_bc2s), (f32x2)(eps));
+        f32x2 r = {__builtin_amdgcn_rcpf(denom.x), __builtin_amdgcn_rcpf(denom.y)};
+        r = r * __builtin_elementwise_fma(-denom, r, (f32x2)(2.0f));
+        return __builtin_elementwise_fma(mi * (f32x2)(-step_size), r, p);
+      };
       {
-        const int64_t gbase2 = oW2g + (int64_t)(32 * w + 4 * hi) * H + j;
-        f32x2* __restrict__ mvW2 = MV + gbase2;
-        float* pW2 = sW2 + (32 * w + 4 * hi) * S2 + j;
-        // W1 rows of this wave (feature f = 32 fb + j < d_in) and b1 (f == d_in): one base pointer + a small per-register stride
-        bool own1[NF1];
-        int stg[NF1];
-        f32x2* mvW1[NF1];
-        float* pW1[NF1];
+        if constexpr (!REGMOM) {
 #pragma unroll
-        for (int fb = 0; fb < NF1; ++fb) {
-          const int f = 32 * fb + j;
-          const bool isw = f < d_in;
-          own1[fb] = f <= d_in;
-          stg[fb] = isw ? d_in : 1;
-          const int64_t gbase1 = isw ? oW1g + (int64_t)(32 * w + 4 * hi) * d_in + f : oB1g + 32 * w + 4 * hi;
-          mvW1[fb] = MV + (own1[fb] ? gbase1 : 0);
-          pW1[fb] = sW1 + (32 * w + 4 * hi) * S1 + (isw ? f : d_in);
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q2[nt][r] = mvW2[unit_of(r, 0) * H + 32 * nt];
+#pragma unroll
+          for (int fb = 0; fb < NF1; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q1[fb][r] = mvW1[fb][own1[fb] ? unit_of(r, 0) * stg[fb] : 0];
+          qb2 = MV[gb2i]; qw3 = MV[gw3i]; qb3 = MV[gb3i];
         }
-        const bool ownb2 = hi == 0, ownw3 = tid < H, ownb3 = tid == 0;
-        const int64_t gb2i = oB2g + 32 * w + j, gw3i = oW3g + (ownw3 ? tid : 0), gb3i = oB3g;
-        f32x2 q2[NT][16], q1[NF1][16];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) q2[nt][r] = mvW2[unit_of(r, 0) * H + 32 * nt];
-#pragma unroll
-        for (int fb = 0; fb < NF1; ++fb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) q1[fb][r] = mvW1[fb][own1[fb] ? unit_of(r, 0) * stg[fb] : 0];
-        f32x2 qb2 = MV[gb2i], qw3 = MV[gw3i], qb3 = MV[gb3i];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const int o0 = unit_of(r, 0) * H + 32 * nt, l0 = unit_of(r, 0) * S2 + 32 * nt;
             const int o1 = unit_of(r + 1, 0) * H + 32 * nt, l1 = unit_of(r + 1, 0) * S2 + 32 * nt;
-            if constexpr (NF1 == 1) {
+            if constexpr (REGMOM) {
+              const f32x2 pn = adam_math2p(f32x2{pW2[l0], pW2[l1]}, f32x2{gW2[nt][r], gW2[nt][r + 1]}, q2[nt][r], q2[nt][r + 1]);
+              pW2[l0] = pn.x; pW2[l1] = pn.y;
+            } else if constexpr (NF1 == 1) {
               const f32x2 pn = adam_math2(f32x2{pW2[l0], pW2[l1]}, f32x2{gW2[nt][r], gW2[nt][r + 1]}, q2[nt][r], q2[nt][r + 1]);
               pW2[l0] = pn.x; pW2[l1] = pn.y;
             } else {                                      // (the two-block variant already spills: the packed form's temporaries cost it 2 %)
               pW2[l0] = adam_math(pW2[l0], gW2[nt][r], q2[nt][r]);
               pW2[l1] = adam_math(pW2[l1], gW2[nt][r + 1], q2[nt][r + 1]);
             }
-            mvW2[o0] = q2[nt][r]; mvW2[o1] = q2[nt][r + 1];
+            if constexpr (!REGMOM) { mvW2[o0] = q2[nt][r]; mvW2[o1] = q2[nt][r + 1]; }
           }
 #pragma unroll
         for (int fb = 0; fb < NF1; ++fb)
@@ -430,19 +469,22 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
               const int o0 = unit_of(r, 0) * stg[fb], l0 = unit_of(r, 0) * S1, o1 = unit_of(r + 1, 0) * stg[fb], l1 = unit_of(r + 1, 0) * S1;
-              if constexpr (NF1 == 1) {
+              if constexpr (REGMOM) {
+                const f32x2 pn = adam_math2p(f32x2{pW1[fb][l0], pW1[fb][l1]}, f32x2{gW1[fb][r], gW1[fb][r + 1]}, q1[fb][r], q1[fb][r + 1]);
+                pW1[fb][l0] = pn.x; pW1[fb][l1] = pn.y;
+              } else if constexpr (NF1 == 1) {
                 const f32x2 pn = adam_math2(f32x2{pW1[fb][l0], pW1[fb][l1]}, f32x2{gW1[fb][r], gW1[fb][r + 1]}, q1[fb][r], q1[fb][r + 1]);
                 pW1[fb][l0] = pn.x; pW1[fb][l1] = pn.y;
               } else {
                 pW1[fb][l0] = adam_math(pW1[fb][l0], gW1[fb][r], q1[fb][r]);
                 pW1[fb][l1] = adam_math(pW1[fb][l1], gW1[fb][r + 1], q1[fb][r + 1]);
               }
-              mvW1[fb][o0] = q1[fb][r]; mvW1[fb][o1] = q1[fb][r + 1];
+              if constexpr (!REGMOM) { mvW1[fb][o0] = q1[fb][r]; mvW1[fb][o1] = q1[fb][r + 1]; }
             }
           }
-        if (ownb2) { sB2[32 * w + j] = adam_math(sB2[32 * w + j], gb2, qb2); MV[gb2i] = qb2; }
-        if (ownw3) { sW3[tid] = adam_math(sW3[tid], gw3, qw3); MV[gw3i] = qw3; }
-        if (ownb3) { sB3[0] = adam_math(sB3[0], gb3, qb3); MV[gb3i] = qb3; }
+        if (ownb2) { sB2[32 * w + j] = adam_math(sB2[32 * w + j], gb2, qb2); if constexpr (!REGMOM) MV[gb2i] = qb2; }
+        if (ownw3) { sW3[tid] = adam_math(sW3[tid], gw3, qw3); if constexpr (!REGMOM) MV[gw3i] = qw3; }
+        if (ownb3) { sB3[0] = adam_math(sB3[0], gb3, qb3); if constexpr (!REGMOM) MV[gb3i] = qb3; }
       }
       __syncthreads();
       { const int hb = 0; MJX_FIT_STAMP(10); }
@@ -450,6 +492,27 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
     if (tid == 0) A.epoch_loss[ep] = ep_loss;
   }
   // ---- write the trained parameters and the moments back
+  if constexpr (REGMOM) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        mvW2[unit_of(r, 0) * H + 32 * nt] = f32x2{q2[nt][r].x, q2[nt][r + 1].x};
+        mvW2[unit_of(r + 1, 0) * H + 32 * nt] = f32x2{q2[nt][r].y, q2[nt][r + 1].y};
+      }
+#pragma unroll
+    for (int fb = 0; fb < NF1; ++fb)
+      if (own1[fb]) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          mvW1[fb][unit_of(r, 0) * stg[fb]] = f32x2{q1[fb][r].x, q1[fb][r + 1].x};
+          mvW1[fb][unit_of(r + 1, 0) * stg[fb]] = f32x2{q1[fb][r].y, q1[fb][r + 1].y};
+        }
+      }
+    if (ownb2) MV[gb2i] = qb2;
+    if (ownw3) MV[gw3i] = qw3;
+    if (ownb3) MV[gb3i] = qb3;
+  }
   __syncthreads();
   for (int64_t i = tid; i < Ptot; i += 256) { A.m[i] = A.mv[2 * i]; A.v[i] = A.mv[2 * i + 1]; }
   for (int i = tid; i < H * (d_in + 1); i += 256) {

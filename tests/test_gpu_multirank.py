@@ -35,10 +35,10 @@ def _run(worker, args, world, port, extra_env=None, timeout=280):
 
 @pytest.mark.parametrize("kind", ["quadratic", "mlp"])
 def test_two_rank_train_step_equals_one_rank(tmp_path, kind):
-    """2 x train_step(N = 81 trajectories: shares of 40 / 41) with NPG + the quadratic / the MLP baseline.  Every rank samples
+    """2 x train_step(N = 2 001 trajectories of 50 steps: shares of 1 000 / 1 001) with NPG + the quadratic / the MLP baseline.  Every rank samples
     its contiguous share with the seeds a single process uses for those episodes, so the ranks' paths in rank order ARE the
-    one-process batch; after iteration 1 (identical inputs) the policy step matches to 1e-5, the ridge baseline's predictions to
-    1e-9 and the MLP baseline's parameters bit for bit (all-gathered block in rank order, the last rank's permutation); the
+    one-process batch (NPG with 5 CG iterations: BASELINE configs[0]); after iteration 1 (identical inputs) the policy step matches
+    to 1e-5 (measured 2e-7), the ridge baseline's predictions to 1e-9 (3e-15) and the MLP baseline's parameters bit for bit (all-gathered block in rank order, the last rank's permutation); the
     logged statistics -- VF errors, return statistics, sample count -- are those of the whole batch on every rank."""
     one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
     port = 29700 + (os.getpid() % 200) + (50 if kind == "mlp" else 0)
@@ -47,16 +47,17 @@ def test_two_rank_train_step_equals_one_rank(tmp_path, kind):
     a, b = np.load(one), np.load(two)
     assert bool(b["ranks_identical"][0]), "ranks must hold bit-identical policies, baselines and logs"
     assert str(b["comm_kind"][0]) == "peer" and str(a["comm_kind"][0]) == "None"
-    assert int(a["seed"][0]) == int(b["seed"][0]) == 2 + 2 * 81
+    assert int(a["seed"][0]) == int(b["seed"][0]) == 2 + 2 * 2001
     np.testing.assert_array_equal(a["theta0"], b["theta0"])
     # iteration 1: the same trajectories on both sides
+    assert rel(b["grad1"], a["grad1"]) < 2e-6, rel(b["grad1"], a["grad1"])            # a plain sum over samples and ranks
     s1 = rel(b["theta1"].astype(np.float64) - a["theta0"], a["theta1"].astype(np.float64) - a["theta0"])
-    assert s1 < 1e-5, s1
+    assert s1 < 1e-5, (s1, rel(b["x1"], a["x1"]))
     np.testing.assert_allclose(b["stats1"], a["stats1"], rtol=1e-12)                 # [mean, std, min, max] of ALL returns, N
     # log: alpha, kl, surr_improvement, running_score, num_samples, VF_error_before / after, stoc_pol_*
     np.testing.assert_allclose(b["log1"][[0, 1, 2]], a["log1"][[0, 1, 2]], rtol=2e-5)
     np.testing.assert_allclose(b["log1"][[3, 4, 7, 8, 9, 10]], a["log1"][[3, 4, 7, 8, 9, 10]], rtol=1e-12)
-    assert b["log1"][4] == 81 * 25
+    assert b["log1"][4] == 2001 * 50
     if kind == "quadratic":
         assert rel(b["pred1"], a["pred1"]) < 1e-9, rel(b["pred1"], a["pred1"])
         np.testing.assert_allclose(b["log1"][[5, 6]], a["log1"][[5, 6]], rtol=1e-9)          # VF errors over all ranks' paths
@@ -65,11 +66,13 @@ def test_two_rank_train_step_equals_one_rank(tmp_path, kind):
         np.testing.assert_array_equal(b["bl1"], a["bl1"])                                    # the identical trainer on the identical block
         np.testing.assert_array_equal(b["pred1"], a["pred1"])
         np.testing.assert_array_equal(b["log1"][[5, 6]], a["log1"][[5, 6]])
-    # iteration 2 starts from policies 1e-6 apart (sampling included): still the same update
+    # iteration 2 starts from policies 2e-7 apart (sampling included): still the same update (measured 3e-7)
     s2 = rel(b["theta2"].astype(np.float64) - b["theta1"], a["theta2"].astype(np.float64) - a["theta1"])
-    assert s2 < 5e-5, s2
+    assert s2 < 1e-5, s2
     np.testing.assert_allclose(b["stats2"], a["stats2"], rtol=1e-5)
-    assert rel(b["pred2"], a["pred2"]) < (1e-5 if kind == "quadratic" else 2e-3)
+    # (the ridge fit is a smooth function of its inputs: 2e-9; the ReLU / Adam chain of the MLP baseline is not -- 3 000 steps from
+    #  inputs 1e-7 apart end 2e-3 apart in prediction, in any implementation: tools/probe_fit_wide.py)
+    assert rel(b["pred2"], a["pred2"]) < (1e-6 if kind == "quadratic" else 2e-2)
     print("[two-rank train_step, %s baseline] step 1 %.2e, step 2 %.2e, prediction 1 %.2e, prediction 2 %.2e"
           % (kind, s1, s2, rel(b["pred1"], a["pred1"]) if kind == "quadratic" else 0.0, rel(b["pred2"], a["pred2"])))
 

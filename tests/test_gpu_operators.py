@@ -581,8 +581,9 @@ def test_persistent_mlp_trainer_equals_per_step_launches(monkeypatch, d_in):
     perm = torch.from_numpy(np.concatenate([rng.permutation(N), rng.permutation(N)]).astype(np.int32)).to(dev)
     hid = (ctypes.c_int * 2)(128, 128)
     out = {}
-    for mode in ("persistent", "launches"):
+    for mode in ("persistent", "launches", "persistent_r03"):
         monkeypatch.setenv("MJX_MLP_FIT_LAUNCHES", "1" if mode == "launches" else "0")
+        monkeypatch.setenv("MJX_FIT_REGMOM", "0" if mode == "persistent_r03" else "1")
         params = torch.from_numpy(p0.copy()).to(dev)
         m, v = torch.zeros(P, device=dev), torch.zeros(P, device=dev)
         loss = torch.zeros(32, dtype=torch.float64, device=dev)
@@ -595,6 +596,11 @@ def test_persistent_mlp_trainer_equals_per_step_launches(monkeypatch, d_in):
     assert np.linalg.norm(a[0] - b[0]) < 1e-5 * move
     assert np.linalg.norm(a[1] - b[1]) < 1e-4 * np.linalg.norm(b[1]) and np.linalg.norm(a[2] - b[2]) < 1e-4 * np.linalg.norm(b[2])
     np.testing.assert_allclose(a[3], b[3], rtol=1e-6)
+    # r04: Adam moments resident in registers for the whole run vs streamed through L2 every step (MJX_FIT_REGMOM=0): the same
+    # arithmetic on the same values in the same order -- parameters, both moments and the epoch losses bit for bit
+    c = out["persistent_r03"]
+    for k in range(4):
+        np.testing.assert_array_equal(a[k], c[k])
 
 
 @pytest.mark.parametrize("hid", [(64, 64), (128, 128)])

@@ -26,4 +26,4 @@ for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     check(lib.mjx_mlp_fit_adam(ptr(feat), ptr(y), N, d_in, hid, 2, ptr(params), ptr(m), ptr(v), 0, ptr(perm), 1, 64, 1e-3, 0.0, ptr(loss), None))
     torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-print("%s  d_in %d: %.2f us / step (best of 3 x %d steps); loss %.6f" % (os.environ.get("MJX_LIB", "product"), d_in, 1e6 * min(ts) / steps, steps, float(loss[0]) / steps))
+print("%s REGMOM=%s  d_in %d: %.2f us / step (best of 3 x %d steps); loss %.6f" % (os.environ.get("MJX_LIB", "product"), os.environ.get("MJX_FIT_REGMOM", "1"), d_in, 1e6 * min(ts) / steps, steps, float(loss[0]) / steps))
