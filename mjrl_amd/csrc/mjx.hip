@@ -474,13 +474,20 @@ int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, con
         HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit1p<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         configured = true;
       }
       // r04: the Adam moments a thread owns stay in its registers for the whole run (REGMOM, mlp_fit.h); MJX_FIT_REGMOM=0: the r03
       // kernels, which stream them through L2 in every step (same arithmetic, same bits)
       const char* rm = getenv("MJX_FIT_REGMOM");            // (read per call: the tests compare the two in one process)
       const bool regmom = !(rm && rm[0] == '0');
-      if (d_in <= 31) {
+      // ... and up to 23 inputs a step is ONE pass over its 64 rows (k_mlp_fit1p: two accumulator chains, every weight fragment
+      // fetched once, 6 barriers instead of 11); MJX_FIT_ONEPASS=0: the two-halves kernel
+      const char* op = getenv("MJX_FIT_ONEPASS");
+      const MlpFit1pLayout<128> L1(d_in);
+      if (d_in <= 23 && regmom && !(op && op[0] == '0') && L1.bytes() <= (size_t)160 * 1024) {
+        hipLaunchKernelGGL((k_mlp_fit1p<128>), dim3(1), dim3(256), L1.bytes(), st, a);
+      } else if (d_in <= 31) {
         if (regmom) hipLaunchKernelGGL((k_mlp_fit<128, 1, true>), dim3(1), dim3(256), L.bytes(), st, a);
         else hipLaunchKernelGGL((k_mlp_fit<128, 1, false>), dim3(1), dim3(256), L.bytes(), st, a);
       } else {                                                // (32 <= d_in <= 55: what 160 KB of LDS hold)

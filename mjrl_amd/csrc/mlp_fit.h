@@ -33,6 +33,14 @@ __device__ __forceinline__ float sum32_lane0(float v) {
   return __uint_as_float(s[0]) + __uint_as_float(s[1]);   // rows 0 + 1 (lanes 0..31), rows 2 + 3 (lanes 32..63)
 }
 
+// workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release + acquire around s_barrier, and
+// on gfx9 the release waits for vmcnt(0) -- i.e. for every global load in flight, including the next minibatch's rows, which
+// are requested a whole step ahead precisely so that nobody has to wait for them (~1.5-2 k cycles from the memory-side cache at
+// each of the first barriers after the request).  The trainer's barriers only ever publish LDS tiles and LDS-resident weights.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct MlpFitArgs {
   const float* feat;       // (N, d_in) fp32
   const float* y;          // (N)
@@ -513,6 +521,434 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
     if (ownw3) MV[gw3i] = qw3;
     if (ownb3) MV[gb3i] = qb3;
   }
+  __syncthreads();
+  for (int64_t i = tid; i < Ptot; i += 256) { A.m[i] = A.mv[2 * i]; A.v[i] = A.mv[2 * i + 1]; }
+  for (int i = tid; i < H * (d_in + 1); i += 256) {
+    int u = i / (d_in + 1), f = i - u * (d_in + 1);
+    if (f < d_in) A.params[oW1g + (int64_t)u * d_in + f] = sW1[u * S1 + f]; else A.params[oB1g + u] = sW1[u * S1 + d_in];
+  }
+  for (int i = tid; i < H * H; i += 256) A.params[oW2g + i] = sW2[(i / H) * S2 + (i % H)];
+  for (int i = tid; i < H; i += 256) { A.params[oW3g + i] = sW3[i]; A.params[oB2g + i] = sB2[i]; }
+  if (tid == 0) A.params[oB3g] = sB3[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// One pass per step (r04): the 64 rows of a minibatch as TWO accumulator chains of the same instruction stream instead of two
+// sequential 32-sample halves.  Every weight fragment is fetched from LDS once per step and feeds both chains (the per-half
+// kernel fetched it twice), a step crosses 4 workgroup barriers instead of 10, and each LDS hand-over's latency is followed by
+// twice the matrix work.  The [unit][sample] tiles are 64 samples wide (stride 68); to fit 160 KB the h2^T tile is gone -- the
+// output layer's weight gradient is formed from the accumulator registers (lane = sample) with DPP row sums -- and so is the
+// sample-major copy of the minibatch (layer 1 reads x^T).  That fits up to 23 inputs (K1 <= 24: every MuJoCo locomotion
+// observation up to 19 wide + 4 time features; HalfCheetah's 21); wider inputs run k_mlp_fit.  Adam moments are register-resident
+// (REGMOM above).  Same minibatches, same update rule; the gradient sums run in a different order than the per-half kernel's
+// (both halves interleaved per k-group), so parameters agree with it to round-off, not bit for bit.
+template <int H>
+struct MlpFit1pLayout {
+  static constexpr int ST = 68, S2 = H + 4;
+  int K1, S1;
+  int oW1, oW2, oW3, oB2, oXT, oH1, oD2, oY, oPART, oGW3, TOTAL;
+  __host__ __device__ explicit MlpFit1pLayout(int d_in) {
+    K1 = (d_in + 1 + 3) & ~3; S1 = K1 + 2;
+    oW1 = 0; oW2 = oW1 + H * S1; oW3 = oW2 + H * S2; oB2 = oW3 + H;
+    oXT = ((oB2 + H + 4 + 3) / 4) * 4;            // [K1][ST]   (b3 sits at oB2 + H)
+    oH1 = oXT + K1 * ST;                          // [H][ST]
+    oD2 = oH1 + H * ST;
+    oY = oD2 + H * ST;                            // [64]
+    oPART = oY + 64;                              // [4][64]
+    oGW3 = oPART + 256;                           // [H]
+    TOTAL = oGW3 + H;
+  }
+  __host__ __device__ size_t bytes() const { return (size_t)TOTAL * 4; }
+};
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void k_mlp_fit1p(MlpFitArgs A) {
+  static_assert(H == 128, "wave w owns unit tile w: 4 waves x 32 units");
+  using LT = MlpFit1pLayout<H>;
+  constexpr int ST = LT::ST, S2 = LT::S2, NT = H / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const LT L(A.d_in);
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+  const int d_in = A.d_in, K1 = L.K1, S1 = L.S1;
+  float* sW1 = lds + L.oW1; float* sW2 = lds + L.oW2; float* sW3 = lds + L.oW3; float* sB2 = lds + L.oB2;
+  float* sB3 = sB2 + H;
+  float* xT = lds + L.oXT; float* h1T = lds + L.oH1; float* d2T = lds + L.oD2;
+  float* sY = lds + L.oY; float* sPart = lds + L.oPART; float* sGW3 = lds + L.oGW3;
+  const int64_t oW1g = 0, oB1g = (int64_t)H * d_in, oW2g = oB1g + H, oB2g = oW2g + (int64_t)H * H, oW3g = oB2g + H, oB3g = oW3g + H;
+
+  // ---- parameters into LDS (b1 rides as the "ones" column of W1), moments into the interleaved workspace
+  for (int i = tid; i < L.TOTAL; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < H * (d_in + 1); i += 256) {
+    int u = i / (d_in + 1), f = i - u * (d_in + 1);
+    sW1[u * S1 + f] = (f < d_in) ? A.params[oW1g + (int64_t)u * d_in + f] : A.params[oB1g + u];
+  }
+  for (int i = tid; i < H * H; i += 256) sW2[(i / H) * S2 + (i % H)] = A.params[oW2g + i];
+  for (int i = tid; i < H; i += 256) { sW3[i] = A.params[oW3g + i]; sB2[i] = A.params[oB2g + i]; }
+  if (tid == 0) sB3[0] = A.params[oB3g];
+  if (tid < 64) xT[d_in * ST + tid] = 1.0f;
+  const int64_t Ptot = oB3g + 1;
+  for (int64_t i = tid; i < Ptot; i += 256) { A.mv[2 * i] = A.m[i]; A.mv[2 * i + 1] = A.v[i]; }
+  __syncthreads();
+
+  const float b1c = 0.9f, b2c = 0.999f, eps = 1e-8f;
+  double pw1 = pow((double)b1c, (double)A.step0), pw2 = pow((double)b2c, (double)A.step0);
+  constexpr int GL = (64 * 24 + 255) / 256;          // gather elements per thread (d_in <= 23)
+  float gx[GL];
+  float gy = 0.f;
+  int gidx[GL], gyi = 0, gs[GL], gf[GL];
+#pragma unroll
+  for (int c = 0; c < GL; ++c) {
+    const int e = c * 256 + tid;
+    gs[c] = (e < 64 * d_in) ? e / d_in : -1;
+    gf[c] = e - (e / d_in) * d_in;
+  }
+  // rows are requested one step before they are staged, the permutation entries that address them one step before that
+  auto index_load = [&](int ep, int64_t mb) {
+    const int32_t* idx = A.perm + (int64_t)ep * A.N + mb * 64;
+#pragma unroll
+    for (int c = 0; c < GL; ++c) gidx[c] = idx[gs[c] >= 0 ? gs[c] : 0];
+    gyi = idx[tid & 63];
+  };
+  auto gather_load = [&]() {
+#pragma unroll
+    for (int c = 0; c < GL; ++c) gx[c] = A.feat[gs[c] >= 0 ? (int64_t)gidx[c] * d_in + gf[c] : 0];
+    gy = A.y[gyi];
+  };
+  auto gather_store = [&]() {
+#pragma unroll
+    for (int c = 0; c < GL; ++c)
+      if (gs[c] >= 0) xT[gf[c] * ST + gs[c]] = gx[c];
+    if (tid < 64) sY[tid] = gy;
+  };
+
+  // ---- Adam ownership (as k_mlp_fit): the 64 W2 weights, 16 W1 / b1 entries and the b2 / W3 / b3 entry of this thread, their
+  // moments in registers for the whole run as (m, m) / (v, v) pairs of neighbouring weights
+  f32x2* __restrict__ MV = (f32x2*)A.mv;
+  f32x2* __restrict__ mvW2 = MV + oW2g + (int64_t)(32 * w + 4 * hi) * H + j;
+  float* pW2 = sW2 + (32 * w + 4 * hi) * S2 + j;
+  const bool isw1 = j < d_in, own1 = j <= d_in;
+  const int stg = isw1 ? d_in : 1;
+  f32x2* mvW1 = MV + (own1 ? (isw1 ? oW1g + (int64_t)(32 * w + 4 * hi) * d_in + j : oB1g + 32 * w + 4 * hi) : 0);
+  float* pW1 = sW1 + (32 * w + 4 * hi) * S1 + (isw1 ? j : d_in);
+  const bool ownb2 = hi == 0, ownw3 = tid < H, ownb3 = tid == 0;
+  const int64_t gb2i = oB2g + 32 * w + j, gw3i = oW3g + (ownw3 ? tid : 0), gb3i = oB3g;
+  f32x2 q2[NT][16], q1[16], qb2, qw3, qb3;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 a = mvW2[unit_of(r, 0) * H + 32 * nt], b = mvW2[unit_of(r + 1, 0) * H + 32 * nt];
+      q2[nt][r] = f32x2{a.x, b.x}; q2[nt][r + 1] = f32x2{a.y, b.y};
+    }
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 a = mvW1[own1 ? unit_of(r, 0) * stg : 0], b = mvW1[own1 ? unit_of(r + 1, 0) * stg : 0];
+    q1[r] = f32x2{a.x, b.x}; q1[r + 1] = f32x2{a.y, b.y};
+  }
+  qb2 = MV[gb2i]; qw3 = MV[gw3i]; qb3 = MV[gb3i];
+
+  for (int ep = 0; ep < A.epochs; ++ep) {
+    double ep_loss = 0.0;
+    if (A.steps > 0) { index_load(ep, 0); gather_load(); if (A.steps > 1) index_load(ep, 1); }
+#pragma unroll 1
+    for (int64_t mb = 0; mb < A.steps; ++mb) {
+      f32x16 gW2[NT], gW1 = (f32x16)(0.f);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) gW2[nt] = (f32x16)(0.f);
+      float w3v[16];                                     // this lane's 16 output-layer weights (units 32 w + unit_of(r, hi))
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w3v[r] = sW3[32 * w + unit_of(r, hi)];
+      const int hb = 0;
+      MJX_FIT_STAMP(0);
+      gather_store();
+      lds_barrier();                                                                                // (1) minibatch staged
+      MJX_FIT_STAMP(1);
+      if (mb + 1 < A.steps) { gather_load(); if (mb + 2 < A.steps) index_load(ep, mb + 2); }   // next step's rows; indices of the one after
+      // ---- layer 1: z1[unit 32w+., sample] = W1a x~a for both halves; h1 = relu -> h1^T
+      {
+        f32x16 z1[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+        // K1 <= 24: at most 6 k-groups; every operand fragment is requested before the first MFMA (one LDS latency per step
+        // instead of one per group -- the wave issues in order)
+        const int nq = K1 / 4;
+        f32x2 a1[6];
+        float b1x[6][2], b1y[6][2];
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          if (q < nq) {
+            const int f0 = 4 * q + 2 * hi;
+            a1[q] = *(const f32x2*)&sW1[(32 * w + j) * S1 + f0];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { b1x[q][h] = xT[f0 * ST + 32 * h + j]; b1y[q][h] = xT[(f0 + 1) * ST + 32 * h + j]; }
+          }
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          if (q < nq) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              z1[h] = MJX_MFMA(a1[q].x, b1x[q][h], z1[h]);
+              z1[h] = MJX_MFMA(a1[q].y, b1y[q][h], z1[h]);
+            }
+          }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h1T[(32 * w + unit_of(r, hi)) * ST + 32 * h + j] = fmaxf(z1[h][r], 0.f);
+      }
+      lds_barrier();                                                                                // (2) h1^T complete
+      MJX_FIT_STAMP(2);
+      // ---- layer 2: K = all 128 h1 units; one W2 fragment per k-group, two B fragments (one per half)
+      f32x16 z2[2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *(const f32x4*)&sB2[32 * w + 8 * q + 4 * hi];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { z2[h][4 * q] = b.x; z2[h][4 * q + 1] = b.y; z2[h][4 * q + 2] = b.z; z2[h][4 * q + 3] = b.w; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        f32x4 ac = *(const f32x4*)&sW2[(32 * w + j) * S2 + 4 * hi], an;
+        float bc[2][4], bn[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bc[h][t] = h1T[(4 * hi + t) * ST + 32 * h + j];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          if (g + 1 < 16) {
+            const int k1 = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3) + 4 * hi;
+            an = *(const f32x4*)&sW2[(32 * w + j) * S2 + k1];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) bn[h][t] = h1T[(k1 + t) * ST + 32 * h + j];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { z2[0] = MJX_MFMA(ac[t], bc[0][t], z2[0]); z2[1] = MJX_MFMA(ac[t], bc[1][t], z2[1]); }
+          ac = an;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bc[h][t] = bn[h][t];
+        }
+        // in-order single wave: group g+1's nine LDS fetches go out ahead of group g's eight MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          if (g + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float hv = fmaxf(z2[h][r], 0.f); z2[h][r] = hv; part = fmaf(w3v[r], hv, part); }
+        part = half_sum(part);                                // + the other lane half
+        if (hi == 0) sPart[w * 64 + 32 * h + j] = part;
+      }
+      lds_barrier();                                                                                // (3) output partials complete
+      MJX_FIT_STAMP(3);
+      // ---- output + MSE gradient: every lane for the two samples j, 32 + j (all waves redundantly)
+      float dy[2], gw3p[16];
+      {
+        float e2 = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int s = 32 * h + j;
+          const float yhat = (sPart[s] + sPart[64 + s]) + (sPart[128 + s] + sPart[192 + s]) + sB3[0];
+          const float err = yhat - sY[s];
+          dy[h] = 2.0f * err / 64.0f;                         // MSELoss(mean) over the 64-row minibatch
+          e2 = fmaf(err, err, e2);
+        }
+        if (w == 0 && hi == 0) { const float t = sum32_lane0(e2); if (j == 0) ep_loss += (double)t / 64.0; }
+      }
+      // delta2 (lane = sample) -> d2^T; the output layer's weight gradient from the same registers: sum over this lane half's
+      // 32 lanes (= samples j, both halves folded first) of h2 * dy, per accumulator register (= unit)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int u = 32 * w + unit_of(r, hi);
+        d2T[u * ST + j] = (z2[0][r] > 0.f) ? w3v[r] * dy[0] : 0.f;
+        d2T[u * ST + 32 + j] = (z2[1][r] > 0.f) ? w3v[r] * dy[1] : 0.f;
+        gw3p[r] = fmaf(z2[1][r], dy[1], z2[0][r] * dy[0]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = sum32_lane0(gw3p[r]);                 // valid in lane 0 of each half
+        if (j == 0) sGW3[32 * w + unit_of(r, hi)] = t;
+      }
+      float gb3 = 0.f;
+      if (w == 0) { const float t = sum32_lane0(dy[0] + dy[1]); gb3 = t; }     // (valid in lane 0; only thread 0 uses it)
+      lds_barrier();                                                                                // (4) d2^T, sGW3 complete
+      MJX_FIT_STAMP(4);
+      // ---- delta2 in lane = unit layout, grad b2
+      f32x16 d2u[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 t4 = *(const f32x4*)&d2T[(32 * w + j) * ST + 32 * h + 8 * q + 4 * hi];
+          d2u[h][4 * q] = t4.x; d2u[h][4 * q + 1] = t4.y; d2u[h][4 * q + 2] = t4.z; d2u[h][4 * q + 3] = t4.w;
+        }
+      float gb2;
+      {
+        float s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s2 += d2u[0][r] + d2u[1][r];
+        gb2 = half_sum(s2);
+      }
+      MJX_FIT_STAMP(5);
+      // ---- grad W2 rows of this wave: A = delta2u (registers), B = h1^T tiles
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 bc[NT], bn[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bc[nt] = *(const f32x4*)&h1T[(32 * nt + j) * ST + 32 * h + 4 * hi];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q + 1 < 4) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const f32x4*)&h1T[(32 * nt + j) * ST + 32 * h + 8 * (q + 1) + 4 * hi];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) gW2[nt] = MJX_MFMA(d2u[h][4 * q + t], bc[nt][t], gW2[nt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bc[nt] = bn[nt];
+        }
+      }
+      MJX_FIT_STAMP(6);
+      // ---- delta1 (lane = h1 unit of this wave's tile): A = delta2 [sample][k] from d2^T (per half), B = W2[k][unit] (shared)
+      f32x16 d1u[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        float ac[2][4], an[2][4], bc[4], bn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          bc[t] = sW2[(4 * hi + t) * S2 + 32 * w + j];
+          ac[0][t] = d2T[(4 * hi + t) * ST + j]; ac[1][t] = d2T[(4 * hi + t) * ST + 32 + j];
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          if (g + 1 < 16) {
+            const int k1 = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3) + 4 * hi;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              bn[t] = sW2[(k1 + t) * S2 + 32 * w + j];
+              an[0][t] = d2T[(k1 + t) * ST + j]; an[1][t] = d2T[(k1 + t) * ST + 32 + j];
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { d1u[0] = MJX_MFMA(ac[0][t], bc[t], d1u[0]); d1u[1] = MJX_MFMA(ac[1][t], bc[t], d1u[1]); }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { ac[0][t] = an[0][t]; ac[1][t] = an[1][t]; bc[t] = bn[t]; }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          if (g + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                       // relu'(z1) mask from h1^T (same layout)
+          const f32x4 hv = *(const f32x4*)&h1T[(32 * w + j) * ST + 32 * h + 8 * q + 4 * hi];
+          d1u[h][4 * q] = hv.x > 0.f ? d1u[h][4 * q] : 0.f; d1u[h][4 * q + 1] = hv.y > 0.f ? d1u[h][4 * q + 1] : 0.f;
+          d1u[h][4 * q + 2] = hv.z > 0.f ? d1u[h][4 * q + 2] : 0.f; d1u[h][4 * q + 3] = hv.w > 0.f ? d1u[h][4 * q + 3] : 0.f;
+        }
+      MJX_FIT_STAMP(7);
+      // ---- grad W1a rows of this wave (column d_in = grad b1)
+      {
+        f32x4 b4[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            b4[h][q] = *(const f32x4*)&xT[(j < K1 ? j : 0) * ST + 32 * h + 8 * q + 4 * hi];
+            if (j >= K1) b4[h][q] = (f32x4)(0.f);
+          }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) gW1 = MJX_MFMA(d1u[h][4 * q + t], b4[h][q][t], gW1);
+      }
+      const float gw3 = ownw3 ? sGW3[tid] : 0.f;
+      lds_barrier();                                                                                // (5) tiles are rewritten by the next step
+      MJX_FIT_STAMP(8);
+      // ---- Adam (torch.optim.Adam: L2 weight decay folded into the gradient, bias-corrected), moments in registers
+      pw1 *= (double)b1c; pw2 *= (double)b2c;
+      const float bc1 = (float)(1.0 - pw1), bc2s = (float)sqrt(1.0 - pw2);
+      const float step_size = A.lr / bc1;
+      const float inv_bc2s = 1.0f / bc2s;
+      auto adam_math = [&](float p, float g, f32x2& q) {
+        g += A.wd * p;
+        float mi = q.x, vi = q.y;
+        mi = mi + (g - mi) * (1.0f - b1c);
+        vi = vi * b2c + g * g * (1.0f - b2c);
+        q = f32x2{mi, vi};
+        const float denom = fmaf(__builtin_amdgcn_sqrtf(vi), inv_bc2s, eps);
+        float r = __builtin_amdgcn_rcpf(denom);
+        r = r * fmaf(-denom, r, 2.0f);
+        return fmaf(-step_size * mi, r, p);
+      };
+      auto adam_math2p = [&](f32x2 p, f32x2 g, f32x2& mi, f32x2& vi) {
+        g = __builtin_elementwise_fma((f32x2)(A.wd), p, g);
+        mi = __builtin_elementwise_fma(g - mi, (f32x2)(1.0f - b1c), mi);
+        vi = __builtin_elementwise_fma(g * g, (f32x2)(1.0f - b2c), vi * (f32x2)(b2c));
+        const f32x2 denom = __builtin_elementwise_fma(f32x2{__builtin_amdgcn_sqrtf(vi.x), __builtin_amdgcn_sqrtf(vi.y)}, (f32x2)(inv_bc2s), (f32x2)(eps));
+        f32x2 r = {__builtin_amdgcn_rcpf(denom.x), __builtin_amdgcn_rcpf(denom.y)};
+        r = r * __builtin_elementwise_fma(-denom, r, (f32x2)(2.0f));
+        return __builtin_elementwise_fma(mi * (f32x2)(-step_size), r, p);
+      };
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int l0 = unit_of(r, 0) * S2 + 32 * nt, l1 = unit_of(r + 1, 0) * S2 + 32 * nt;
+          const f32x2 pn = adam_math2p(f32x2{pW2[l0], pW2[l1]}, f32x2{gW2[nt][r], gW2[nt][r + 1]}, q2[nt][r], q2[nt][r + 1]);
+          pW2[l0] = pn.x; pW2[l1] = pn.y;
+        }
+      if (own1) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int l0 = unit_of(r, 0) * S1, l1 = unit_of(r + 1, 0) * S1;
+          const f32x2 pn = adam_math2p(f32x2{pW1[l0], pW1[l1]}, f32x2{gW1[r], gW1[r + 1]}, q1[r], q1[r + 1]);
+          pW1[l0] = pn.x; pW1[l1] = pn.y;
+        }
+      }
+      if (ownb2) sB2[32 * w + j] = adam_math(sB2[32 * w + j], gb2, qb2);
+      if (ownw3) sW3[tid] = adam_math(sW3[tid], gw3, qw3);
+      if (ownb3) sB3[0] = adam_math(sB3[0], gb3, qb3);
+      lds_barrier();                                                                                // (6) weights updated
+      MJX_FIT_STAMP(9);
+    }
+    if (tid == 0) A.epoch_loss[ep] = ep_loss;
+  }
+  // ---- write the moments and the trained parameters back
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      mvW2[unit_of(r, 0) * H + 32 * nt] = f32x2{q2[nt][r].x, q2[nt][r + 1].x};
+      mvW2[unit_of(r + 1, 0) * H + 32 * nt] = f32x2{q2[nt][r].y, q2[nt][r + 1].y};
+    }
+  if (own1) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      mvW1[unit_of(r, 0) * stg] = f32x2{q1[r].x, q1[r + 1].x};
+      mvW1[unit_of(r + 1, 0) * stg] = f32x2{q1[r].y, q1[r + 1].y};
+    }
+  }
+  if (ownb2) MV[gb2i] = qb2;
+  if (ownw3) MV[gw3i] = qw3;
+  if (ownb3) MV[gb3i] = qb3;
   __syncthreads();
   for (int64_t i = tid; i < Ptot; i += 256) { A.m[i] = A.mv[2 * i]; A.v[i] = A.mv[2 * i + 1]; }
   for (int i = tid; i < H * (d_in + 1); i += 256) {

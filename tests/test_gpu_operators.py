@@ -558,7 +558,7 @@ def test_background_prefetch_hands_out_complete_blocks():
     ingest.drop_shared()
 
 
-@pytest.mark.parametrize("d_in", [21, 35, 43, 50, 55])
+@pytest.mark.parametrize("d_in", [9, 21, 23, 27, 35, 43, 50, 55])
 def test_persistent_mlp_trainer_equals_per_step_launches(monkeypatch, d_in):
     """The persistent single-workgroup trainer of the MLP baseline (csrc/mlp_fit.h; two 32-feature blocks of the input
     layer beyond 31 inputs, as far as 160 KB of LDS reach: 55; the Adroit observations + 4 time features are 43..50)
@@ -581,9 +581,10 @@ def test_persistent_mlp_trainer_equals_per_step_launches(monkeypatch, d_in):
     perm = torch.from_numpy(np.concatenate([rng.permutation(N), rng.permutation(N)]).astype(np.int32)).to(dev)
     hid = (ctypes.c_int * 2)(128, 128)
     out = {}
-    for mode in ("persistent", "launches", "persistent_r03"):
+    for mode in ("persistent", "launches", "two_halves", "persistent_r03"):
         monkeypatch.setenv("MJX_MLP_FIT_LAUNCHES", "1" if mode == "launches" else "0")
         monkeypatch.setenv("MJX_FIT_REGMOM", "0" if mode == "persistent_r03" else "1")
+        monkeypatch.setenv("MJX_FIT_ONEPASS", "1" if mode == "persistent" else "0")
         params = torch.from_numpy(p0.copy()).to(dev)
         m, v = torch.zeros(P, device=dev), torch.zeros(P, device=dev)
         loss = torch.zeros(32, dtype=torch.float64, device=dev)
@@ -598,9 +599,11 @@ def test_persistent_mlp_trainer_equals_per_step_launches(monkeypatch, d_in):
     np.testing.assert_allclose(a[3], b[3], rtol=1e-6)
     # r04: Adam moments resident in registers for the whole run vs streamed through L2 every step (MJX_FIT_REGMOM=0): the same
     # arithmetic on the same values in the same order -- parameters, both moments and the epoch losses bit for bit
-    c = out["persistent_r03"]
+    c, h = out["persistent_r03"], out["two_halves"]
     for k in range(4):
-        np.testing.assert_array_equal(a[k], c[k])
+        np.testing.assert_array_equal(h[k], c[k])
+    # ... and the one-pass kernel (up to 23 inputs; beyond that "persistent" IS the two-halves kernel) against both
+    assert np.linalg.norm(h[0] - b[0]) < 1e-5 * move and np.linalg.norm(a[0] - h[0]) < 1e-5 * move
 
 
 @pytest.mark.parametrize("hid", [(64, 64), (128, 128)])

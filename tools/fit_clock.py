@@ -24,6 +24,13 @@ st = loss.cpu().numpy().view(np.int64)[8:19]
 names = ["gather store+sync", "L1 + h1T + sync", "L2 (64 MFMA) + relu + h2T + sync", "yhat/dy + d2T + sync", "gW3/gb + d2u", "gW2 (64 MFMA)", "delta1u (64 MFMA) + mask", "gW1 (16)+sync",
          "(second half)", "Adam"]
 d = np.diff(st)
+if st[10] == 0 or os.environ.get("MJX_FIT_ONEPASS", "1") != "0":        # the one-pass kernel (k_mlp_fit1p) leaves 10 stamps
+    names = ["gather store+sync", "L1 (2 chains) + h1T + sync", "L2 (128 MFMA) + relu + partials + sync", "yhat/dy + d2T + gW3 (DPP) + sync",
+             "d2u + gb2", "gW2 (128 MFMA)", "delta1u (128 MFMA) + mask", "gW1 (32) + sync", "Adam + sync"]
+    for i, x in enumerate(np.diff(st[:10])):
+        print("%-44s %8d cycles" % (names[i], x))
+    print("step total", st[9] - st[0])
+    sys.exit(0)
 for i, x in enumerate(d):
     print("%-36s %8d cycles" % (names[i], x))
 print("half total", st[8] - st[0], " step total ~", st[10] - st[0])
