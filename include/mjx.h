@@ -308,6 +308,23 @@ int mjx_host_gather(void* dst, const void* const* src, const int64_t* offsets, i
  * host at half its size and needs no device-side cast.  src[i] is rows(i) x row_elems doubles, dst the fp32 staging block. */
 int mjx_host_gather_f64_f32(float* dst, const double* const* src, const int64_t* offsets, int64_t first, int64_t count,
                             int64_t row_elems, int n_threads);
+/* The whole staging of one block of a batch as ONE asynchronous job (r04): src[i] is lens[i] rows x row_elems items of
+ * src_itemsize bytes (8: float64, 4: float32).  A native thread gathers the trajectories group by group (>= group_rows rows, whole
+ * trajectories) into `pinned` -- converting fp64 -> fp32 on the way when hostcast != 0 -- and queues each group's host-to-device
+ * copy on `stream` right behind its gather, so gather k + 1 overlaps transfer k; with hostcast == 0, float64 sources and
+ * device_f32 != NULL the fp32 image is cast from the raw block on the device (mjx_cast_f64_f32 on the same stream).  Returns at
+ * once: *job_out is joined (and freed) by mjx_stage_wait, after which everything is QUEUED on `stream` (order consumers after
+ * it).  src / lens are copied; the trajectories themselves, `pinned` and the device blocks must stay alive until the wait.
+ * Replaces np.concatenate + the per-call float32 casts of mjrl/algos/batch_reinforce.py:180-181 / mjrl/policies/gaussian_mlp.py:102-109
+ * without a Python thread (no interpreter lock is held while the 184 MB of a 1M-timestep batch move). */
+int mjx_stage_async(void** job_out, const void* const* src, const int64_t* lens, int64_t count, int64_t row_elems, int src_itemsize,
+                    int hostcast, void* pinned, void* device_raw, float* device_f32, int64_t group_rows, int n_threads,
+                    int device_index, void* stream);
+int mjx_stage_wait(void* job);
+/* Per-trajectory sums of a 1-D fp64 quantity: out[i] = src[i][0] + src[i][1] + ... + src[i][lens[i] - 1], added in that order --
+ * the path returns of process_paths, `path_returns = [sum(p["rewards"]) for p in paths]` (mjrl/algos/batch_reinforce.py:187; Python's
+ * sum() adds left to right, so the results carry the reference's bits).  Trajectories are spread over n_threads.  No device work. */
+int mjx_host_segment_sums(const double* const* src, const int64_t* lens, int64_t count, double* out, int n_threads);
 
 /* ---- K6: value baselines --------------------------------------------------- */
 /* Feature maps of the reference baselines over the concatenated fp64 observation block

@@ -67,6 +67,10 @@ PROTOTYPES = {
                                           c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p]),
     "mjx_host_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "mjx_host_gather_f64_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
+    "mjx_host_segment_sums": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int]),
+    "mjx_stage_async": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                c_int64, c_int, c_int, c_void_p]),
+    "mjx_stage_wait": (c_int, [c_void_p]),
     "mjx_bl_num_features": (c_int, [c_int, c_int]),
     "mjx_bl_features_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "mjx_bl_gram": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),

@@ -183,6 +183,18 @@ class BatchREINFORCE:
                     starts = np.zeros(len(paths), np.int64)
                     np.cumsum(lens[:-1], out=starts[1:])
                     path_returns = np.add.reduceat(blk.reshape(-1), starts)
+        if path_returns is None and eng is not None and getattr(eng, "lib", None) is not None and len(paths) > 16:
+            # host arrays as the sampler left them: addresses by one C walk over the path list (csrc/pathwalk.c), the sums on
+            # libmjx's host threads -- each path added left to right like the reference's sum(p["rewards"]) (its very bits);
+            # a NumPy call per path cost 3 ms per 1 000 paths, most of this thread's share of train_from_paths
+            from ..utils import ingest
+            got = ingest.collect_arrays(paths, "rewards")
+            if got is not None and got[2] == 1 and got[3] == 8:
+                import ctypes
+                from .._lib import check
+                path_returns = np.empty(len(paths), np.float64)
+                check(eng.lib.mjx_host_segment_sums(ctypes.c_void_p(got[0].ctypes.data), ctypes.c_void_p(got[1].ctypes.data),
+                                                    len(paths), ctypes.c_void_p(path_returns.ctypes.data), 16))
         if path_returns is None:
             add = np.add.reduce                      # (np.sum's dispatch wrappers cost more than a 1 000-element sum: 3.0 -> 1.3 us per path)
             path_returns = np.fromiter((float(add(p["rewards"])) for p in paths), dtype=np.float64, count=len(paths))
@@ -240,8 +252,9 @@ class BatchREINFORCE:
         from ..utils import ingest
         if not paths:
             return self._bind_empty_shard()
-        # (asked before the staging job starts: the helper thread holds the registry lock while it stages)
+        # (asked before the staging jobs start: a helper holds its key's registry lock while it stages)
         adv64 = ingest.lookup(eng.backend, paths, "advantages") if eng.device.type == "cuda" else None
+        host_adv = False
         if _dist() is not None:
             # which route the advantages take decides which collectives follow (engine.whitened_advantages: libmjx's transport;
             # _advantages_and_statistics: torch.distributed): the ranks must agree on it.  The device block is used only when
@@ -250,14 +263,27 @@ class BatchREINFORCE:
             from ..utils import ranks
             if not ranks.all_true(adv64 is not None):
                 adv64 = None
-        elif adv64 is None and eng.device.type == "cuda" and len(paths) > 64 and getattr(eng, "_stager", None) is None and all(
-                isinstance(p["advantages"], np.ndarray) and p["advantages"].ndim == 1 and p["advantages"].dtype == np.float64 for p in paths):
-            # host advantages (train_from_paths called on its own): the 8 bytes per timestep go up through the stager as they are
-            # and are whitened on the device like the resident ones -- np.concatenate + mean + std + the division cost 2-3 ms of
-            # this thread per 1M timesteps, next to 3 ms of per-path return sums
-            adv64 = ingest.stage_shared(eng.backend, paths, ("advantages",))["advantages"]["raw"].view(-1)
-        fut = self._staging_pool().submit(self._stage_on_callers_stream(), paths, ("observations", "actions"))
+        elif adv64 is None and eng.device.type == "cuda" and len(paths) > 64 and getattr(eng, "_stager", None) is None:
+            got = ingest.collect_arrays(paths, "advantages")             # one C walk: uniform 1-D float64 arrays?
+            host_adv = (got is not None and got[2] == 1 and got[3] == 8 and isinstance(paths[0]["advantages"], np.ndarray)
+                        and paths[0]["advantages"].ndim == 1) if ingest._pathwalk is not None else all(
+                isinstance(p["advantages"], np.ndarray) and p["advantages"].ndim == 1 and p["advantages"].dtype == np.float64 for p in paths)
+        # observations and actions start their way to the device NOW: one native staging job per block (mjx_stage_async: libmjx's
+        # threads gather / convert the trajectories group by group and queue each group's copy behind it; no Python thread, no
+        # interpreter lock) -- the call returns at once and this thread goes on with the advantages and the path statistics.  The
+        # update cannot begin until the last block has landed; everything else fits under that.
+        native = getattr(eng, "_stager", None) is None and eng.device.type == "cuda"
+        futs, staged = [], {}
+        if native:
+            staged = eng.stage_paths(paths, ("observations", "actions"), defer=True)
+        else:                                    # (CPU stand-ins, caller-supplied stagers: a helper thread)
+            futs = [self._staging_pool().submit(self._stage_on_callers_stream(), paths, ("observations", "actions"))]
         try:
+            if host_adv:
+                # host advantages (train_from_paths called on its own): the 8 bytes per timestep go up through the stager as they are
+                # and are whitened on the device like the resident ones -- np.concatenate + mean + std + the division cost 2-3 ms of
+                # this thread per 1M timesteps
+                adv64 = ingest.stage_shared(eng.backend, paths, ("advantages",))["advantages"]["raw"].view(-1)
             if adv64 is not None:
                 # the advantages never left the device (utils/process_samples.compute_advantages): whitening statistics
                 # and the fp32 cast happen there; only the per-path return statistics are host work
@@ -266,8 +292,13 @@ class BatchREINFORCE:
             else:
                 advantages, base_stats, self.running_score = self._advantages_and_statistics(paths)
         finally:
-            staged = fut.result()
-        self._push_policy()
+            for f in futs:
+                staged.update(f.result())
+            if native:
+                self._push_policy()              # (four small uploads: under the staging jobs, not behind them)
+                ingest.settle(eng.backend)       # the staging jobs have queued their copies; this stream waits for them
+        if not native:
+            self._push_policy()
         eng.set_batch(staged["observations"], staged["actions"], advantages)
         return base_stats
 

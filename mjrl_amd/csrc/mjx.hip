@@ -1220,7 +1220,13 @@ struct HostPool {
     return true;
   }
 };
-HostPool& host_pool() { static HostPool* p = new HostPool(); return *p; }
+// three pools: the observation and the action block of a batch are staged by two helper threads at the same time (r04) while the
+// training thread stages its 8 MB of advantages; a fourth concurrent caller falls back to its own threads
+struct HostPools {
+  HostPool a, b, c;                                // (c: the advantage / reward block the training thread stages meanwhile)
+  bool run(int nt, const std::function<void(int)>& fn) { return a.run(nt, fn) || b.run(nt, fn) || c.run(nt, fn); }
+};
+HostPools& host_pool() { static HostPools* p = new HostPools(); return *p; }
 }  // namespace
 
 extern "C" {
@@ -1232,6 +1238,7 @@ int mjx_host_gather(void* dst, const void* const* src, const int64_t* offsets, i
   const int64_t total = (offsets[first + count] - offsets[first]) * row_bytes;
   int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
   if (total < (int64_t)(1 << 20)) nt = 1;
+  else if (total < (int64_t)(16 << 20) && nt > 8) nt = 8;      // a few MB: waking 31 workers costs more than they save
   // every thread takes a contiguous byte range of the destination (blocks are split where the range ends)
   auto work = [&](int t) {
     const int64_t lo = total * t / nt, hi = total * (t + 1) / nt;
@@ -1275,6 +1282,7 @@ int mjx_host_gather_f64_f32(float* dst, const double* const* src, const int64_t*
   const int64_t total = (offsets[first + count] - offsets[first]) * row_elems;      // elements
   int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
   if (total < (int64_t)(1 << 17)) nt = 1;
+  else if (total < (int64_t)(2 << 20) && nt > 8) nt = 8;
   const char* no_avx2 = getenv("MJX_NO_AVX2");             // (tests: the portable loop on an AVX2 host)
   const bool avx2 = __builtin_cpu_supports("avx2") && !(no_avx2 && no_avx2[0] == '1');
   auto work = [&](int t) {
@@ -1302,6 +1310,105 @@ int mjx_host_gather_f64_f32(float* dst, const double* const* src, const int64_t*
   work(0);
   for (auto& x : th) x.join();
   return MJX_OK;
+}
+
+// per-trajectory sums of a 1-D fp64 quantity (path returns, batch_reinforce.py:187): out[i] = src[i][0] + src[i][1] + ... in that
+// order -- the order of Python's sum() over the array, which is what the reference calls -- the trajectories spread over threads
+int mjx_host_segment_sums(const double* const* src, const int64_t* lens, int64_t count, double* out, int n_threads) {
+  if (!src || !lens || !out || count < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (count == 0) return MJX_OK;
+  int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+  if (count < 64) nt = 1;
+  auto work = [&](int t) {
+    const int64_t lo = count * t / nt, hi = count * (t + 1) / nt;
+    for (int64_t i = lo; i < hi; ++i) {
+      const double* p = src[i];
+      double a = 0.0;                                  // (sum() starts from int 0: 0 + x == x exactly)
+      for (int64_t k = 0; k < lens[i]; ++k) a += p[k];
+      out[i] = a;
+    }
+  };
+  if (nt == 1) { work(0); return MJX_OK; }
+  if (nt > HostPool::MAXW + 1) nt = HostPool::MAXW + 1;
+  {
+    const std::function<void(int)> fn = work;
+    if (host_pool().run(nt, fn)) return MJX_OK;
+  }
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  return MJX_OK;
+}
+
+// ---- asynchronous staging of one block of a rollout batch (r04): gather (+ fp64 -> fp32 conversion) group by group on the host
+// pools and the group's host-to-device copy queued right behind it -- all on a native thread, so the caller (a Python training
+// loop) gets control back at once and no interpreter lock is involved while 184 MB of rollouts move.  mjx_stage_wait joins.
+namespace {
+struct StageJob {
+  std::thread th;
+  int rc = MJX_OK;
+  std::string err;
+  std::vector<const void*> src;
+  std::vector<int64_t> offs;
+};
+}  // namespace
+
+int mjx_stage_async(void** job_out, const void* const* src, const int64_t* lens, int64_t count, int64_t row_elems, int src_itemsize,
+                    int hostcast, void* pinned, void* device_raw, float* device_f32, int64_t group_rows, int n_threads,
+                    int device_index, void* stream) {
+  if (!job_out || !src || !lens || count < 0 || row_elems <= 0 || (src_itemsize != 4 && src_itemsize != 8) || !pinned || !device_raw ||
+      group_rows <= 0 || (hostcast && src_itemsize != 8))
+    return fail(MJX_ERR_ARG, "bad arguments");
+  StageJob* job = new StageJob();
+  job->src.assign(src, src + count);                       // (the caller's pointer / length arrays need not outlive the call)
+  job->offs.resize(count + 1);
+  job->offs[0] = 0;
+  for (int64_t i = 0; i < count; ++i) {
+    if (lens[i] < 0) { delete job; return fail(MJX_ERR_ARG, "negative length"); }
+    job->offs[i + 1] = job->offs[i] + lens[i];
+  }
+  const int64_t dst_item = hostcast ? 4 : src_itemsize;
+  job->th = std::thread([=] {
+    const int64_t* offs = job->offs.data();
+    const void* const* sp = job->src.data();
+    hipStream_t st = (hipStream_t)stream;
+    if (hipSetDevice(device_index) != hipSuccess) { job->rc = MJX_ERR_STATE; job->err = "hipSetDevice failed in the staging thread"; return; }
+    int64_t first = 0;
+    while (first < count) {
+      int64_t last = first;
+      while (last < count && offs[last] - offs[first] < group_rows) ++last;     // whole trajectories, at least group_rows rows
+      if (last == first) last = first + 1;
+      int rc;
+      if (hostcast) rc = mjx_host_gather_f64_f32((float*)pinned, (const double* const*)sp, offs, first, last - first, row_elems, n_threads);
+      else rc = mjx_host_gather(pinned, sp, offs, first, last - first, row_elems * src_itemsize, n_threads);
+      if (rc != MJX_OK) { job->rc = rc; job->err = mjx_last_error(); return; }
+      const int64_t lo = offs[first] * row_elems, hi = offs[last] * row_elems;   // elements
+      if (hi > lo) {
+        hipError_t e = hipMemcpyAsync((char*)device_raw + lo * dst_item, (const char*)pinned + lo * dst_item, (size_t)((hi - lo) * dst_item),
+                                      hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { job->rc = (int)e; job->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); return; }
+        if (device_f32 && !hostcast && src_itemsize == 8) {                     // raw fp64 block + its fp32 image (cast on the device)
+          rc = mjx_cast_f64_f32((const double*)device_raw + lo, hi - lo, device_f32 + lo, stream);
+          if (rc != MJX_OK) { job->rc = rc; job->err = mjx_last_error(); return; }
+        }
+      }
+      first = last;
+    }
+  });
+  *job_out = job;
+  return MJX_OK;
+}
+
+int mjx_stage_wait(void* job_) {
+  if (!job_) return fail(MJX_ERR_ARG, "null job");
+  StageJob* job = (StageJob*)job_;
+  if (job->th.joinable()) job->th.join();
+  const int rc = job->rc;
+  const std::string err = job->err;
+  delete job;
+  return rc == MJX_OK ? MJX_OK : fail(rc, "staging job failed: %s", err.c_str());
 }
 
 int mjx_cast_f64_f32(const double* x, int64_t count, float* out32, void* stream) {

@@ -337,14 +337,16 @@ class UpdateEngine:
         check(lib.mjx_whiten_cast(ptr(adv64), N, mean, std, 1e-6, ptr(out), self.stream()))
         return out
 
-    def stage_paths(self, paths, keys=("observations", "actions")):
+    def stage_paths(self, paths, keys=("observations", "actions"), defer=False):
         """per-path host arrays -> fp32 device blocks through the page-locked stager (utils/ingest.py): no
         concatenated host copy, chunked transfers overlapped with the staging copies.  One upload per batch and
         process: the value baselines (predict before, fit after the update) share it (utils/ingest.stage_shared)."""
         if getattr(self, "_stager", None) is not None:             # a caller-supplied stager (tools, tests)
             return self._stager.stage(paths, keys, hostcast=True)
         from .utils.ingest import stage_shared
-        return {k: v["f32"] for k, v in stage_shared(self.backend, paths, keys, raw=()).items()}
+        # defer: the blocks are handed out while libmjx's staging threads are still at work (mjx_stage_async); the caller runs
+        # utils.ingest.settle() before it enqueues the first kernel that reads them
+        return {k: v["f32"] for k, v in stage_shared(self.backend, paths, keys, raw=(), defer=defer).items()}
 
     def bind_rows(self, rows, adv=None, N_global=None):
         """(re)bind the first `rows` samples of the uploaded block (DAPG runs the Fisher on the

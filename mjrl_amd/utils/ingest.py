@@ -19,6 +19,25 @@ import numpy as np
 
 from .._lib import check, ptr
 
+try:                                        # C-speed walk over the path list (csrc/pathwalk.c, built by __graft_entry__.build());
+    from .. import _pathwalk                # without it the same walk runs in Python (~0.5 us per array instead of ~0.05)
+except Exception:                           # pragma: no cover
+    _pathwalk = None
+
+
+def collect_arrays(paths, key):
+    """addresses and first dimensions of paths[.][key] -> (ptrs: (n,) uint64 ndarray, lens: (n,) int64 ndarray, width, itemsize), or
+    None when the arrays are not uniform C-contiguous float32 / float64 blocks (the caller converts / copies them itself).  The
+    addresses are valid while the caller holds the arrays."""
+    n = len(paths)
+    if _pathwalk is None or n == 0 or type(paths) is not list:
+        return None
+    ptrs, lens = np.empty(n, np.uint64), np.empty(n, np.int64)
+    r = _pathwalk.collect(paths, key, ptrs, lens)
+    if r < 0:
+        return None
+    return ptrs, lens, r >> 4, r & 15
+
 
 class PathStager:
     """Page-locked staging + chunked asynchronous upload of per-path arrays.
@@ -26,7 +45,14 @@ class PathStager:
     The returned tensors are views of buffers owned by the stager: they stay valid until the
     next ``begin`` / ``stage`` call (one batch at a time, like the update engine itself)."""
 
-    def __init__(self, backend, threads=16, group_rows=262144, native=None):
+    def __init__(self, backend, threads=None, group_rows=262144, native=None):
+        # gather threads per staging job: the rollouts of a fresh batch sit in DRAM, not in cache -- converting 136 MB of fp64
+        # observations alone takes 2.35 / 1.35 / 1.06 ms on 8 / 16 / 32 threads of the 2 x 64-core hosts (tools/stage_breakdown.py), but
+        # a batch's blocks are staged by concurrent jobs (observations, actions, advantages): 16 each measured best end to end
+        # (profiles/r04_e2e/sweep.log; MJX_STAGE_THREADS / MJX_STAGE_GROUP_ROWS override)
+        if threads is None:
+            import os
+            threads = int(os.environ.get("MJX_STAGE_THREADS", "0")) or max(4, min(16, (os.cpu_count() or 8) // 2))
         self.backend = backend
         self.torch = backend.torch
         self.device = backend.device
@@ -34,7 +60,8 @@ class PathStager:
         self.lib = getattr(backend, "lib", None)
         self.native = (self.lib is not None) if native is None else bool(native)   # host gather inside libmjx
         self.native_threads = int(threads)
-        self.group_rows = int(group_rows)
+        import os as _os
+        self.group_rows = int(_os.environ.get("MJX_STAGE_GROUP_ROWS", "0")) or int(group_rows)
         # (fallback without the library: NumPy copies; they hold the GIL for per-path sized arrays, so one thread)
         self.pool = ThreadPoolExecutor(max_workers=int(threads)) if (threads > 1 and not self.native) else None
         self.side = self.torch.cuda.Stream(device=self.device) if self.on_gpu else None
@@ -42,6 +69,7 @@ class PathStager:
         self._keys = ()
         self._rows = 0
         self._pending = []
+        self._jobs = []             # native staging jobs in flight (mjx_stage_async): joined by join() / finish() / the next begin()
         self._lock = threading.Lock()
 
     # ------------------------------------------------------------------ buffers
@@ -68,10 +96,25 @@ class PathStager:
             s["dev_f32"] = torch.empty((rows, width), dtype=torch.float32) if tdt == torch.float64 else s["dev_raw"]
         return s
 
+    def join(self):
+        """wait until the native staging jobs of the last stage() have QUEUED all their copies on the side stream (the copies
+        themselves are ordered by the stream: current_stream.wait_stream(self.side) / finish())"""
+        with self._lock:
+            jobs, self._jobs = self._jobs, []
+        err = None
+        for j in jobs:
+            try:
+                check(self.lib.mjx_stage_wait(j))
+            except Exception as e:              # (join the rest first)
+                err = err or e
+        if err is not None:
+            raise err
+
     # ------------------------------------------------------------------ incremental interface
     def begin(self, keys, widths, dtypes, capacity, hostcast=()):
         """start a batch of at most `capacity` rows; keys e.g. ("observations", "actions"); hostcast: the keys whose fp64
         arrays only have to reach the device as fp32 (no raw block)"""
+        self.join()
         if self.on_gpu:
             self.side.synchronize()             # the previous batch's transfers have left the staging block
         self._keys = tuple(keys)
@@ -118,16 +161,32 @@ class PathStager:
         n = len(paths)
         key0 = self._keys[0]
         offs = np.zeros(n + 1, np.int64)
-        np.cumsum([len(p[key0]) for p in paths], out=offs[1:])
+        keep, srcs = [], {}
+        fast = {}
+        pre = getattr(self, "_pre", None)
+        pre = pre[1] if (pre is not None and pre[0] is paths) else {}
+        self._pre = None
+        for k in self._keys:                                 # the C walk: addresses + lengths of every array, ~50 ns apiece
+            s = self._slots[k]
+            got = pre[k] if k in pre else collect_arrays(paths, k)
+            if got is not None and got[3] == np.dtype(s["dtype"]).itemsize and got[2] == s["width"]:
+                fast[k] = got
+        if key0 in fast:
+            np.cumsum(fast[key0][1], out=offs[1:])
+        else:
+            np.cumsum([len(p[key0]) for p in paths], out=offs[1:])
         total = int(offs[-1])
         row0 = self._rows
         cap = min(self._slots[k]["cap"] for k in self._keys)
         if row0 + total > cap:
             raise ValueError("PathStager: batch exceeds the capacity given to begin() (%d > %d rows)" % (row0 + total, cap))
-        keep, srcs = [], {}
         from_buffer, addressof = ctypes.c_char.from_buffer, ctypes.addressof
         for k in self._keys:
             s = self._slots[k]
+            if k in fast:
+                keep.append(fast[k][0])
+                srcs[k] = ctypes.c_void_p(fast[k][0].ctypes.data)
+                continue
             arr = (ctypes.c_void_p * n)()
             for i, p in enumerate(paths):
                 a = p[k]
@@ -190,6 +249,7 @@ class PathStager:
         """-> dict key -> (rows, width) fp32 device tensor; the current stream is ordered after the transfers
         (wait=False: the caller orders its consumers itself, after an event it records on ``self.side``)"""
         self._drain(block=True)
+        self.join()
         if self.on_gpu and wait:
             self.torch.cuda.current_stream(self.device).wait_stream(self.side)
         return {k: self._slots[k]["dev_f32"][:self._rows] for k in self._keys}
@@ -200,13 +260,45 @@ class PathStager:
         s = self._slots[key]
         return None if s["hostcast"] else s["dev_raw"][:self._rows]
 
+    def _stage_async(self, paths, keys, pre):
+        """the whole batch as one native job per key (mjx_stage_async): gather + conversion + queued copies run on libmjx's
+        threads, this call returns at once.  -> False when some key's arrays are not uniform float blocks (general route)."""
+        import ctypes
+        if not (self.native and self.on_gpu and all(k in pre for k in keys)):
+            return False
+        for k in keys:
+            s, (ptrs, lens, width, isz) = self._slots[k], pre[k]
+            if isz != np.dtype(s["dtype"]).itemsize or width != s["width"]:
+                return False
+        rows = int(pre[keys[0]][1].sum())
+        for k in keys:
+            s, (ptrs, lens, width, isz) = self._slots[k], pre[k]
+            if int(lens.sum()) != rows:
+                raise ValueError("PathStager: the arrays of key %r do not have the row counts of key %r" % (k, keys[0]))
+            job = ctypes.c_void_p()
+            f32 = s["dev_f32"] if (s["dev_f32"] is not s["dev_raw"]) else None
+            check(self.lib.mjx_stage_async(ctypes.byref(job), ctypes.c_void_p(ptrs.ctypes.data), ctypes.c_void_p(lens.ctypes.data), len(paths),
+                                           width, isz, 1 if s["hostcast"] else 0, ptr(s["pin"]), ptr(s["dev_raw"]), ptr(f32),
+                                           self.group_rows, self.native_threads, self.device.index or 0, ctypes.c_void_p(self.side.cuda_stream)))
+            with self._lock:
+                self._jobs.append(job)
+        self._rows = rows
+        return True
+
     # ------------------------------------------------------------------ one-shot
     def stage(self, paths, keys=("observations", "actions"), wait=True, hostcast=()):
         first = paths[0]
         widths = [first[k].shape[1] if first[k].ndim == 2 else 1 for k in keys]
         dtypes = [np.float64 if first[k].dtype == np.float64 else np.float32 for k in keys]
-        rows = sum(len(p[keys[0]]) for p in paths)
+        pre = {k: g for k, g in ((k, collect_arrays(paths, k)) for k in keys) if g is not None} if self.native else {}
+        self._pre = (paths, pre)                     # (one C walk per key serves the row count here and the gather below)
+        rows = int(pre[keys[0]][1].sum()) if keys[0] in pre else sum(len(p[keys[0]]) for p in paths)
         self.begin(keys, widths, dtypes, rows, hostcast=hostcast)
+        if self._stage_async(paths, keys, pre):
+            self._pre = None
+            if wait:
+                return self.finish(True)
+            return {k: self._slots[k]["dev_f32"][:self._rows] for k in keys}      # (the caller joins: join() / _order_after)
         self.add_paths(paths)
         return self.finish(wait)
 
@@ -303,7 +395,13 @@ def _key_lock(dev, key):
 
 
 def _order_after(backend, ent):
-    """the caller's current stream waits for the block's transfers (recorded on the stager's side stream)"""
+    """the caller's current stream waits for the block's transfers (queued on the stager's side stream -- by a native job that may
+    still be running: joined first)"""
+    st = ent.get("active")
+    if st is not None and st.on_gpu:
+        st.join()
+        backend.torch.cuda.current_stream(backend.device).wait_stream(st.side)
+        return
     ev = ent.get("ready")
     if ev is not None:
         backend.torch.cuda.current_stream(backend.device).wait_event(ev)
@@ -365,14 +463,19 @@ def _same_batch(ent, paths, key):
     arrays = ent["arrays"]
     if ent["paths"] is not paths or len(arrays) != len(paths):
         return False
-    for a, p in zip(arrays, paths):
-        if a is not p[key]:
+    if _pathwalk is not None and type(paths) is list and type(arrays) is list:
+        if not _pathwalk.identity(paths, key, arrays):
             return False
+    else:
+        for a, p in zip(arrays, paths):
+            if a is not p[key]:
+                return False
     for i, pr in zip(_probed(len(arrays)), ent["probes"]):
         if _probe(arrays[i]) != pr:
             return False
     if not _trusted() and ent.get("f32") is not None and ent.get("active") is not None:
         st = ent["active"]
+        st.join()                                    # (the page-locked copy is complete once the staging job has finished)
         slot = st._slots.get(key)
         if slot is None:
             return False
@@ -391,13 +494,29 @@ def _same_batch(ent, paths, key):
 _RAW_STICKY = set()          # (device type, index, key): some consumer asked for the raw block of this key before
 
 
-def stage_shared(backend, paths, keys, raw=None):
+_DEFERRED = []                # entries handed out by stage_shared(defer=True) whose consumers have not been ordered yet (settle())
+_DEFERRED_LOCK = threading.Lock()
+
+
+def settle(backend):
+    """order the caller's current stream after every block that stage_shared(defer=True) handed out: joins the native staging
+    jobs (their copies are then queued) and makes the stream wait for the stagers' copy streams.  MUST run before the first
+    kernel that reads such a block is enqueued."""
+    with _DEFERRED_LOCK:
+        ents, _DEFERRED[:] = list(_DEFERRED), []
+    for ent in ents:
+        _order_after(backend, ent)
+
+
+def stage_shared(backend, paths, keys, raw=None, defer=False):
     """-> dict key -> dict(f32=(N, w) fp32 device tensor, raw=(N, w) tensor in the paths' dtype).  Re-uses the upload
     of the same `paths` list (the same list object holding the same array objects, see _same_batch) made earlier in
     this process on this device; train_step drops the entries when its iteration ends (drop_shared_batch).
     raw: the keys whose block the caller needs in the paths' own dtype (None: all of them).  A key nobody has ever asked the
     raw block of is converted to fp32 by the host gather and uploaded at half its size (raw = None in the result); the first
-    raw request for such a key stages it again in full -- and is remembered, so later batches go up raw at once and serve both."""
+    raw request for such a key stages it again in full -- and is remembered, so later batches go up raw at once and serve both.
+    defer: return as soon as the staging jobs are STARTED (native threads gather and queue the copies); the caller does other work
+    and calls settle() before it enqueues the first consumer."""
     dev = backend.device
     out = {}
     for k in keys:
@@ -429,7 +548,11 @@ def stage_shared(backend, paths, keys, raw=None):
                 ent = new
                 with _SHARED_LOCK:
                     reg[k] = ent
-            _order_after(backend, ent)
+            if defer:
+                with _DEFERRED_LOCK:
+                    _DEFERRED.append(ent)
+            else:
+                _order_after(backend, ent)
             out[k] = dict(f32=ent["f32"], raw=ent["raw"])
     return out
 
@@ -505,6 +628,7 @@ def host_block(backend, paths, key):
         if ent is None or ent.get("paths") is None or ent.get("active") is None or ent.get("f32") is None or not _same_batch(ent, paths, key):
             return None
         st = ent["active"]
+        st.join()
         if st._slots[key]["hostcast"]:                 # staged as fp32: no host copy in the paths' dtype
             return None
         return st._slots[key]["pin_np"][:st._rows]

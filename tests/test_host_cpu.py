@@ -367,3 +367,38 @@ def test_raw_blocks_are_uploaded_on_demand():
     assert f["f32"] is not e["actions"]["f32"]
     assert f["f32"][5 + 2, 1].item() == np.float32(paths2[1]["actions"][2, 1])
     ingest.drop_shared()
+
+
+def test_path_walk_extension_and_native_path_sums():
+    """csrc/pathwalk.c (addresses / lengths of paths[.][key] by one C walk; identity of the staged arrays) and
+    mjx_host_segment_sums (per-path reward sums on libmjx's host threads, added left to right: the bits of the reference's
+    `sum(p["rewards"])`, mjrl/algos/batch_reinforce.py:187) -- host plumbing, runs without a GPU."""
+    import ctypes
+    from mjrl_amd import _lib
+    from mjrl_amd import _pathwalk as pw
+    from mjrl_amd.utils import ingest
+    rng = np.random.RandomState(3)
+    paths = [dict(observations=rng.randn(int(T), 5), rewards=rng.randn(int(T)) * 10 ** rng.uniform(-3, 3)) for T in rng.randint(1, 400, 300)]
+    got = ingest.collect_arrays(paths, "observations")
+    assert got is not None and got[2] == 5 and got[3] == 8
+    assert all(int(got[0][i]) == p["observations"].ctypes.data and int(got[1][i]) == len(p["observations"]) for i, p in enumerate(paths))
+    arrays = [p["rewards"] for p in paths]
+    assert pw.identity(paths, "rewards", arrays) == 1
+    # the rules of the fast walk: read-only arrays are fine, anything non-uniform / non-contiguous / not float sends the caller to its general route
+    paths[3]["rewards"].setflags(write=False)
+    assert ingest.collect_arrays(paths, "rewards") is not None
+    for bad in (paths[7]["rewards"][::2], paths[7]["rewards"].astype(np.float32), paths[7]["rewards"].astype(np.int64), [1.0, 2.0]):
+        q = list(paths); q[7] = dict(paths[7], rewards=bad)
+        assert ingest.collect_arrays(q, "rewards") is None
+        assert pw.identity(q, "rewards", arrays) == 0
+    assert ingest.collect_arrays(paths, "no_such_key") is None and ingest.collect_arrays([], "rewards") is None
+    # sums: every path left to right == Python's sum(), bit for bit (np.sum's pairwise order differs in the last bits)
+    lib = _lib.load()
+    ptrs, lens, w, isz = ingest.collect_arrays(paths, "rewards")
+    for threads in (1, 7):
+        out = np.empty(len(paths), np.float64)
+        _lib.check(lib.mjx_host_segment_sums(ctypes.c_void_p(ptrs.ctypes.data), ctypes.c_void_p(lens.ctypes.data), len(paths),
+                                             ctypes.c_void_p(out.ctypes.data), threads))
+        ref = np.array([sum(p["rewards"]) for p in paths], np.float64)
+        np.testing.assert_array_equal(out, ref)
+    assert any(float(np.sum(p["rewards"])) != sum(p["rewards"]) for p in paths)      # (the two orders do differ on this data)

@@ -1,0 +1,48 @@
+"""Timeline of one NPG.train_from_paths on fresh fp64 host paths (1M timesteps): when each stage of the main thread and of the
+staging helper starts and ends, relative to the call (ms).  python tools/e2e_timeline.py"""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+from mjrl_amd.algos.npg_cg import NPG
+from mjrl_amd.algos import batch_reinforce as br
+from mjrl_amd.policies.gaussian_mlp import MLP
+from mjrl_amd import engine as eng_mod
+from mjrl_amd.utils import ingest
+spec = type("Spec", (), dict(observation_dim=17, action_dim=6, horizon=1000))
+rng = np.random.RandomState(0)
+paths = [dict(observations=rng.randn(1000, 17), actions=rng.randn(1000, 6), rewards=rng.randn(1000), advantages=rng.randn(1000), terminated=False) for _ in range(1000)]
+pol = MLP(spec, hidden_sizes=(64, 64), seed=1, init_log_std=-0.5)
+agent = NPG(None, pol, None, normalized_step_size=0.05)
+def fresh():
+    return [dict(observations=p["observations"].copy(), actions=p["actions"].copy(), rewards=p["rewards"], advantages=p["advantages"], terminated=False) for p in paths]
+T0 = [0.0]; LOG = []
+def wrap(obj, name, tag):
+    f = getattr(obj, name)
+    def g(*a, **k):
+        t = time.perf_counter(); r = f(*a, **k); LOG.append((tag, 1e3 * (t - T0[0]), 1e3 * (time.perf_counter() - T0[0]))); return r
+    setattr(obj, name, g)
+wrap(eng_mod.UpdateEngine, "stage_paths", "helper: stage obs+act")
+wrap(eng_mod.UpdateEngine, "whitened_advantages", "main: whiten advantages (2 syncs)")
+wrap(eng_mod.UpdateEngine, "set_batch", "main: set_batch")
+wrap(eng_mod.UpdateEngine, "set_policy", "main: set_policy")
+wrap(eng_mod.UpdateEngine, "npg_update", "main: npg_update (enqueue + read-back)")
+wrap(eng_mod.UpdateEngine, "to_host", "main: theta to host")
+wrap(br.BatchREINFORCE, "_path_statistics", "main: path statistics")
+wrap(br.BatchREINFORCE, "_process_and_bind", "main: _process_and_bind (all)")
+wrap(pol, "set_param_values", "main: policy.set_param_values")
+_ss = ingest.stage_shared
+def ss(backend, paths_, keys, raw=None, defer=False):
+    t = time.perf_counter(); r = _ss(backend, paths_, keys, raw, defer); LOG.append(("stage_shared%s" % (tuple(keys),), 1e3 * (t - T0[0]), 1e3 * (time.perf_counter() - T0[0]))); return r
+ingest.stage_shared = ss
+_settle = ingest.settle
+def settle(backend):
+    t = time.perf_counter(); _settle(backend); LOG.append(("main: settle (join staging jobs)", 1e3 * (t - T0[0]), 1e3 * (time.perf_counter() - T0[0])))
+ingest.settle = settle
+batches = [fresh() for _ in range(6)]
+for b in batches:
+    LOG.clear(); torch.cuda.synchronize(); T0[0] = time.perf_counter()
+    agent.train_from_paths(b)
+    torch.cuda.synchronize(); total = 1e3 * (time.perf_counter() - T0[0])
+for tag, a, b in sorted(LOG, key=lambda x: x[1]):
+    print("%-44s %7.2f -> %7.2f  (%.2f ms)" % (tag, a, b, b - a))
+print("total %.2f ms" % total)
