@@ -397,6 +397,11 @@ def _key_lock(dev, key):
 def _order_after(backend, ent):
     """the caller's current stream waits for the block's transfers (queued on the stager's side stream -- by a native job that may
     still be running: joined first)"""
+    with _DEFERRED_LOCK:                              # (a deferred hand-out is settled by whoever orders a consumer after it first)
+        for i, e in enumerate(_DEFERRED):
+            if e is ent:
+                del _DEFERRED[i]
+                break
     st = ent.get("active")
     if st is not None and st.on_gpu:
         st.join()
@@ -508,6 +513,15 @@ def settle(backend):
         _order_after(backend, ent)
 
 
+def _prefetch_inline(backend, paths, keys, raw):
+    """the staging jobs of `keys` started from the calling thread (mjx_stage_async returns at once): no helper thread needed"""
+    try:
+        stage_shared(backend, paths, keys, raw=raw, defer=True)
+        return True
+    except Exception:                             # pragma: no cover  (left to the foreground request)
+        return False
+
+
 def stage_shared(backend, paths, keys, raw=None, defer=False):
     """-> dict key -> dict(f32=(N, w) fp32 device tensor, raw=(N, w) tensor in the paths' dtype).  Re-uses the upload
     of the same `paths` list (the same list object holding the same array objects, see _same_batch) made earlier in
@@ -570,6 +584,11 @@ def prefetch(backend, paths, keys, raw=()):
     keys = tuple(k for k in keys if k in paths[0] and isinstance(paths[0][k], np.ndarray))
     if dev.type != "cuda" or not keys:
         return None
+    if getattr(backend, "lib", None) is not None and _pathwalk is not None and all(collect_arrays(paths, k) is not None for k in keys):
+        # uniform float blocks: one native asynchronous staging job per key, started right here (r04) -- whoever asks for a block
+        # later joins its job (_order_after); no Python thread, no interpreter lock while the rollouts move
+        if _prefetch_inline(backend, paths, keys, raw):
+            return None
     if _PREFETCH_POOL is None:
         _PREFETCH_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mjx-prefetch")
     cur = torch.cuda.current_stream(dev)
