@@ -41,6 +41,32 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// sum32_lane0 of 16 independent values, stage by stage: each DPP step runs over all 16 registers before the next one starts, so a
+// DPP instruction never reads the register the previous instruction wrote (that hazard costs two wait states -- the per-value form
+// compiled to a v_add_f32_dpp / s_nop chain, ~110 s_nop per step of the one-pass trainer)
+__device__ __forceinline__ void sum32_lane0_x16(float (&v)[16]) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] += dpp(v[r], std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] += dpp(v[r], std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] += dpp(v[r], std::integral_constant<int, 0x141>{});      // row_half_mirror
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] += dpp(v[r], std::integral_constant<int, 0x140>{});      // row_mirror
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[r]), __float_as_uint(v[r]), false, false);
+    v[r] = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+  }
+}
+
 struct MlpFitArgs {
   const float* feat;       // (N, d_in) fp32
   const float* y;          // (N)
@@ -660,6 +686,26 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit1p(MlpFitArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) w3v[r] = sW3[32 * w + unit_of(r, hi)];
       const int hb = 0;
+      // this lane's byte address in row group (32 w + 4 hi) of the two [unit][sample] tiles, re-laundered every step: every access
+      // below is then `base + immediate`.  (Left to the compiler, the 16 + 32 row addresses of the h1^T / delta2^T stores were hoisted
+      // out of the step loop as invariants, parked in AGPRs by the register allocator and fetched back with v_accvgpr_read + s_nop
+      // in front of every store: ~75 isolated vector-ALU instructions per step that fp32 MFMAs do not hide.)
+      uint32_t h1w = lds_pin(&h1T[(32 * w + 4 * hi) * ST + j]), d2w = lds_pin(&d2T[(32 * w + 4 * hi) * ST + j]);
+      // ... and of every fragment read of the MFMA phases (the same story: 41 + 114 v_add_u32 between the MFMAs of layer 2 and of the
+      // backward pass, re-deriving `lane offset + buffer base + constant`)
+      const uint32_t h1c = lds_pin(&h1T[(4 * hi) * ST + j]), d2c = lds_pin(&d2T[(4 * hi) * ST + j]);                 // rows k (+ const), sample 32 h + j
+      const uint32_t h1r = lds_pin(&h1T[(32 * w + j) * ST + 4 * hi]), d2r = lds_pin(&d2T[(32 * w + j) * ST + 4 * hi]); // row = this lane's unit, 4 samples per read
+      const uint32_t h1n = lds_pin(&h1T[j * ST + 4 * hi]);                                                           // rows 32 nt + j
+      const uint32_t w2r = lds_pin(&sW2[(32 * w + j) * S2 + 4 * hi]), w2c = lds_pin(&sW2[(4 * hi) * S2 + 32 * w + j]);
+      const uint32_t x1c = lds_pin(&xT[(2 * hi) * ST + j]), w1r = lds_pin(&sW1[(32 * w + j) * S1 + 2 * hi]);
+      const uint32_t xgr = lds_pin(&xT[(j < K1 ? j : 0) * ST + 4 * hi]);
+      typedef __attribute__((address_space(3))) f32x4 lds_f4;
+      typedef __attribute__((address_space(3))) f32x2 lds_f2;
+// (volatile: keeps the load a single ds_read_b32 with its 16-bit byte offset.  Paired into ds_read2_b32 -- 8-bit offsets, 1 020
+//  bytes of reach -- every k-group of the MFMA loops needed a v_add_u32 to re-base: 33 + 64 per step between MFMAs)
+#define FIT_LD1(base, off) (*(const volatile lds_float*)(uintptr_t)((base) + (uint32_t)((off) * 4)))
+#define FIT_LD2(base, off) (*(const lds_f2*)(uintptr_t)((base) + (uint32_t)((off) * 4)))
+#define FIT_LD4(base, off) (*(const lds_f4*)(uintptr_t)((base) + (uint32_t)((off) * 4)))
       MJX_FIT_STAMP(0);
       gather_store();
       lds_barrier();                                                                                // (1) minibatch staged
@@ -676,10 +722,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit1p(MlpFitArgs A) {
 #pragma unroll
         for (int q = 0; q < 6; ++q)
           if (q < nq) {
-            const int f0 = 4 * q + 2 * hi;
-            a1[q] = *(const f32x2*)&sW1[(32 * w + j) * S1 + f0];
+            a1[q] = FIT_LD2(w1r, 4 * q);                                   // W1[32 w + j][4 q + 2 hi .. + 1]
 #pragma unroll
-            for (int h = 0; h < 2; ++h) { b1x[q][h] = xT[f0 * ST + 32 * h + j]; b1y[q][h] = xT[(f0 + 1) * ST + 32 * h + j]; }
+            for (int h = 0; h < 2; ++h) { b1x[q][h] = FIT_LD1(x1c, (4 * q) * ST + 32 * h); b1y[q][h] = FIT_LD1(x1c, (4 * q + 1) * ST + 32 * h); }
           }
 #pragma unroll
         for (int q = 0; q < 6; ++q)
@@ -693,7 +738,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit1p(MlpFitArgs A) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) h1T[(32 * w + unit_of(r, hi)) * ST + 32 * h + j] = fmaxf(z1[h][r], 0.f);
+          for (int r = 0; r < 16; ++r) LDS_AT(h1w)[unit_of(r, 0) * ST + 32 * h] = fmaxf(z1[h][r], 0.f);     // row 32 w + unit_of(r, hi)
       }
       lds_barrier();                                                                                // (2) h1^T complete
       MJX_FIT_STAMP(2);
@@ -707,21 +752,21 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit1p(MlpFitArgs A) {
       }
       __builtin_amdgcn_sched_barrier(0);
       {
-        f32x4 ac = *(const f32x4*)&sW2[(32 * w + j) * S2 + 4 * hi], an;
+        f32x4 ac = FIT_LD4(w2r, 0), an;
         float bc[2][4], bn[2][4];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) bc[h][t] = h1T[(4 * hi + t) * ST + 32 * h + j];
+          for (int t = 0; t < 4; ++t) bc[h][t] = FIT_LD1(h1c, t * ST + 32 * h);
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           if (g + 1 < 16) {
-            const int k1 = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3) + 4 * hi;
-            an = *(const f32x4*)&sW2[(32 * w + j) * S2 + k1];
+            const int k1c = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3);          // (+ 4 hi: in the pinned bases)
+            an = FIT_LD4(w2r, k1c);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-              for (int t = 0; t < 4; ++t) bn[h][t] = h1T[(k1 + t) * ST + 32 * h + j];
+              for (int t = 0; t < 4; ++t) bn[h][t] = FIT_LD1(h1c, (k1c + t) * ST + 32 * h);
           }
 #pragma unroll
           for (int t = 0; t < 4; ++t) { z2[0] = MJX_MFMA(ac[t], bc[0][t], z2[0]); z2[1] = MJX_MFMA(ac[t], bc[1][t], z2[1]); }
@@ -768,15 +813,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit1p(MlpFitArgs A) {
       // 32 lanes (= samples j, both halves folded first) of h2 * dy, per accumulator register (= unit)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int u = 32 * w + unit_of(r, hi);
-        d2T[u * ST + j] = (z2[0][r] > 0.f) ? w3v[r] * dy[0] : 0.f;
-        d2T[u * ST + 32 + j] = (z2[1][r] > 0.f) ? w3v[r] * dy[1] : 0.f;
+        LDS_AT(d2w)[unit_of(r, 0) * ST] = (z2[0][r] > 0.f) ? w3v[r] * dy[0] : 0.f;                          // row 32 w + unit_of(r, hi)
+        LDS_AT(d2w)[unit_of(r, 0) * ST + 32] = (z2[1][r] > 0.f) ? w3v[r] * dy[1] : 0.f;
         gw3p[r] = fmaf(z2[1][r], dy[1], z2[0][r] * dy[0]);
       }
+      sum32_lane0_x16(gw3p);                                  // valid in lane 0 of each half
+      if (j == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float t = sum32_lane0(gw3p[r]);                 // valid in lane 0 of each half
-        if (j == 0) sGW3[32 * w + unit_of(r, hi)] = t;
+        for (int r = 0; r < 16; ++r) sGW3[32 * w + unit_of(r, hi)] = gw3p[r];
       }
       float gb3 = 0.f;
       if (w == 0) { const float t = sum32_lane0(dy[0] + dy[1]); gb3 = t; }     // (valid in lane 0; only thread 0 uses it)
@@ -788,7 +832,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit1p(MlpFitArgs A) {
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 t4 = *(const f32x4*)&d2T[(32 * w + j) * ST + 32 * h + 8 * q + 4 * hi];
+          const f32x4 t4 = FIT_LD4(d2r, 32 * h + 8 * q);
           d2u[h][4 * q] = t4.x; d2u[h][4 * q + 1] = t4.y; d2u[h][4 * q + 2] = t4.z; d2u[h][4 * q + 3] = t4.w;
         }
       float gb2;
@@ -804,12 +848,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit1p(MlpFitArgs A) {
       for (int h = 0; h < 2; ++h) {
         f32x4 bc[NT], bn[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bc[nt] = *(const f32x4*)&h1T[(32 * nt + j) * ST + 32 * h + 4 * hi];
+        for (int nt = 0; nt < NT; ++nt) bc[nt] = FIT_LD4(h1n, 32 * nt * ST + 32 * h);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (q + 1 < 4) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const f32x4*)&h1T[(32 * nt + j) * ST + 32 * h + 8 * (q + 1) + 4 * hi];
+            for (int nt = 0; nt < NT; ++nt) bn[nt] = FIT_LD4(h1n, 32 * nt * ST + 32 * h + 8 * (q + 1));
           }
 #pragma unroll
           for (int t = 0; t < 4; ++t)
@@ -827,17 +871,17 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit1p(MlpFitArgs A) {
         float ac[2][4], an[2][4], bc[4], bn[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          bc[t] = sW2[(4 * hi + t) * S2 + 32 * w + j];
-          ac[0][t] = d2T[(4 * hi + t) * ST + j]; ac[1][t] = d2T[(4 * hi + t) * ST + 32 + j];
+          bc[t] = FIT_LD1(w2c, t * S2);
+          ac[0][t] = FIT_LD1(d2c, t * ST); ac[1][t] = FIT_LD1(d2c, t * ST + 32);
         }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           if (g + 1 < 16) {
-            const int k1 = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3) + 4 * hi;
+            const int k1c = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-              bn[t] = sW2[(k1 + t) * S2 + 32 * w + j];
-              an[0][t] = d2T[(k1 + t) * ST + j]; an[1][t] = d2T[(k1 + t) * ST + 32 + j];
+              bn[t] = FIT_LD1(w2c, (k1c + t) * S2);
+              an[0][t] = FIT_LD1(d2c, (k1c + t) * ST); an[1][t] = FIT_LD1(d2c, (k1c + t) * ST + 32);
             }
           }
 #pragma unroll
@@ -857,7 +901,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit1p(MlpFitArgs A) {
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                       // relu'(z1) mask from h1^T (same layout)
-          const f32x4 hv = *(const f32x4*)&h1T[(32 * w + j) * ST + 32 * h + 8 * q + 4 * hi];
+          const f32x4 hv = FIT_LD4(h1r, 32 * h + 8 * q);
           d1u[h][4 * q] = hv.x > 0.f ? d1u[h][4 * q] : 0.f; d1u[h][4 * q + 1] = hv.y > 0.f ? d1u[h][4 * q + 1] : 0.f;
           d1u[h][4 * q + 2] = hv.z > 0.f ? d1u[h][4 * q + 2] : 0.f; d1u[h][4 * q + 3] = hv.w > 0.f ? d1u[h][4 * q + 3] : 0.f;
         }
@@ -869,7 +913,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit1p(MlpFitArgs A) {
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            b4[h][q] = *(const f32x4*)&xT[(j < K1 ? j : 0) * ST + 32 * h + 8 * q + 4 * hi];
+            b4[h][q] = FIT_LD4(xgr, 32 * h + 8 * q);
             if (j >= K1) b4[h][q] = (f32x4)(0.f);
           }
 #pragma unroll
