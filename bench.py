@@ -395,7 +395,7 @@ def user_level_measurements():
         torch.cuda.synchronize(); tt.append(time.perf_counter() - t0)
     out["mlp_fit_us_per_step"] = {"value": 1e6 * min(tt) / steps, "steps": steps, "inputs": d_in, "hidden": [128, 128], "batch": 64,
                                   "kernel": "k_mlp_fit1p<128> (csrc/mlp_fit.h): one persistent workgroup, the whole Adam chain in one launch, one pass per 64-row "
-                                            "step, Adam moments register-resident (r03: k_mlp_fit<128,1>, 23.3 us)",
+                                            "step, Adam moments register-resident, pinned LDS addressing (r03: k_mlp_fit<128,1>, 23.3 us)",
                                   "per_1M_timesteps_2_epochs_s": 1e-6 * (1e6 * min(tt) / steps) * 2 * (N_TRAJ * T // 64 - 1)}
     return out
 

@@ -226,7 +226,10 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm(GemmArgs g) {      // (second a
     auto frag = [&](auto rt, const float* S, int mode, int row0, int q) {
       constexpr int RT = decltype(rt)::value;
       if (mode == 1) {
-        const float* p = &S[(8 * q + 4 * hi) * (RT + 4) + row0 + j];
+        // (volatile: four single ds_read_b32 with 16-bit byte offsets.  Paired into ds_read2_b32 -- 8-bit offsets, 1 020 bytes of reach
+        //  against rows (RT + 4) * 4 = 528 / 1 040 bytes apart -- every k-group re-based with v_add_u32: 16-25 vector-ALU instructions
+        //  per k-tile and wave between the MFMAs, which fp32 MFMAs do not hide; LDS instructions they do.)
+        const volatile lds_float* p = (const volatile lds_float*)(const lds_float*)&S[(8 * q + 4 * hi) * (RT + 4) + row0 + j];
         return f32x4{p[0], p[RT + 4], p[2 * (RT + 4)], p[3 * (RT + 4)]};
       }
       return *(const f32x4*)&S[(row0 + j) * GLD + 8 * q + 4 * hi];

@@ -120,7 +120,9 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
   auto fragA = [&](uint32_t pa, int a, int q) { return *(const lds_f4*)(uintptr_t)(pa + (uint32_t)((32 * a * GP_LD + 8 * q) * 4)); };
   auto fragB = [&](uint32_t pb, int b, int q) {
     if (LB) {
-      const lds_f1* p = (const lds_f1*)(uintptr_t)(pb + (uint32_t)((8 * q * (GP_BN + 4) + 32 * b) * 4));
+      // (volatile: single ds_read_b32 with 16-bit offsets; as ds_read2_b32 pairs -- 8-bit offsets -- rows 1 040 bytes apart needed a
+      //  v_add_u32 re-base per pair: 18 per k-tile and wave between the MFMAs of the delta products)
+      const volatile lds_f1* p = (const volatile lds_f1*)(uintptr_t)(pb + (uint32_t)((8 * q * (GP_BN + 4) + 32 * b) * 4));
       return f32x4{p[0], p[GP_BN + 4], p[2 * (GP_BN + 4)], p[3 * (GP_BN + 4)]};
     }
     return *(const lds_f4*)(uintptr_t)(pb + (uint32_t)((32 * b * GP_LD + 8 * q) * 4));
