@@ -1122,7 +1122,14 @@ struct LayerwiseWS {
     if (!wide_tiles()) { launch_tile<128, 128>(g, splits, st); return; }
     // 256-column blocks; a remainder of up to 128 columns gets its own 128-column launch (a half-empty 256-column
     // block would spend matrix-core time on padding), a larger one rides in one more 256-column block
-    if (splits > 1 && thin_wgrad(g.N)) { launch_tile<128, 128, 256>(g, splits, st); return; }
+    if (splits > 1 && thin_wgrad(g.N)) {
+      // (r04) up to 64 columns -- the 512 x 39 first-layer gradient of configs[4], stored 64 wide -- a 128 x 64 tile: the 128-column
+      // tile spent half its matrix work and half its B-operand LDS traffic on padding (MJX_LW_THIN64=0: the r03 shape)
+      static const bool t64 = [] { const char* e = getenv("MJX_LW_THIN64"); return !(e && e[0] == '0'); }();
+      if (t64 && g.N <= 64) { launch_tile<128, 64, 256>(g, splits, st); return; }
+      launch_tile<128, 128, 256>(g, splits, st);
+      return;
+    }
     int n256 = (g.N / 256) * 256, rem = g.N - n256;
     if (rem > 128) { n256 = g.N; rem = 0; }
     if (n256 == g.N) { launch_tile<128, 256>(g, splits, st); return; }
