@@ -1356,8 +1356,10 @@ struct LayerwiseWS {
       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lw_head8_lds_bytes(), st, a);
     };
     static const bool eight = [] { const char* e = getenv("MJX_LW_HEAD8"); return !(e && e[0] == '0'); }();
-    if (eight && hl == 256) launch8(std::integral_constant<int, 1>{});
-    else if (eight && hl == 512) launch8(std::integral_constant<int, 2>{});
+    // (k_lw_head8 addresses H / T with 32-bit byte offsets from their base: the padded blocks must stay below 4 GB)
+    const bool off32 = ((uint64_t)((N + 127) / 128) * 128u * (uint64_t)hl * 4u) < (1ull << 32);
+    if (eight && off32 && hl == 256) launch8(std::integral_constant<int, 1>{});
+    else if (eight && off32 && hl == 512) launch8(std::integral_constant<int, 2>{});
     else switch (hl / 128) {
       case 1: launch(std::integral_constant<int, 1>{}); break;
       case 2: launch(std::integral_constant<int, 2>{}); break;

@@ -259,20 +259,32 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
   const uint32_t laneoff = (uint32_t)(4 * hi) * (uint32_t)h + (uint32_t)j;
   auto rowof = [](int r) { return (r & 3) + 8 * (r >> 2); };
 
+  // r04: buffer addressing throughout -- resource base (scalar) + scalar row / k-tile offset + ONE 32-bit lane offset per access
+  // kind, formed once.  H and T are workspace blocks allocated in whole 128-row tiles (LayerwiseWS::reserve), so rows past N
+  // are readable: their mudot rows are zeroed where d3 is formed (a select, so NaN garbage does not survive) and nothing else of
+  // them is used -- the per-load row masks of the first version are gone.  The weight matrices are [m x h]: their resources
+  // are bounded at m rows, reads of the rows m..31 return zero by the hardware's range check (no clamp, no select).
+  // (The first version formed a 64-bit address and two selects per load: 1 092 vector-ALU instructions per 144 MFMAs in the
+  //  tile loop, tools/isa_mix.py -- vector-ALU time that fp32 MFMAs do not hide.)
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)a.H, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)a.T, 0, -1, 0x00020000);
+  const int wbytes = m * h * 4;
+  const __amdgpu_buffer_rsrc_t rV3 = __builtin_amdgcn_make_buffer_rsrc((void*)a.V3, 0, wbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW3 = __builtin_amdgcn_make_buffer_rsrc((void*)a.W3, 0, wbytes, 0x00020000);
+  const uint32_t voA = ((uint32_t)(tid >> 3) * (uint32_t)h + 4u * (uint32_t)(tid & 7)) * 4u;           // row tid / 8 of the tile, 16 bytes of the k-tile
+  const uint32_t voW = ((uint32_t)((tid >> 3) & 31) * (uint32_t)h + 4u * (uint32_t)(tid & 7)) * 4u;    // action (tid / 8) % 32
+  const uint32_t lane4 = laneoff * 4u;
+  auto ld128 = [](const __amdgpu_buffer_rsrc_t& r, uint32_t vo, uint32_t so) {
+    return __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, (int)so, 0));
+  };
   // per k-tile: A 2 pairs x 64 rows x 8 float4 = 1024 -> two per thread; B 2 pairs x 32 rows x 8 = 512 -> one per thread
   auto gload = [&](f32x4 (&ra)[2], f32x4& rbq, int64_t r0, int kt) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const float* __restrict__ S = p ? (const float*)a.T : a.H;
-      const int row = tid >> 3;                        // 0..63
-      const bool ok = r0 + row < a.N;
-      const f32x4 v = *(const f32x4*)(S + (ok ? (r0 + row) : 0) * (int64_t)h + 32 * kt + 4 * (tid & 7));
-      ra[p] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const int pb = tid >> 8, act = (tid >> 3) & 31;
-    const float* __restrict__ Wm = pb ? a.W3 : a.V3;
-    const f32x4 w = *(const f32x4*)(Wm + (int64_t)(act < m ? act : 0) * h + 32 * kt + 4 * (tid & 7));
-    rbq = act < m ? w : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint32_t so = (uint32_t)(((uint64_t)r0 * (uint64_t)h + (uint64_t)(32 * kt)) * 4u);       // (N128 x h x 4 < 4 GB: checked on the host)
+    ra[0] = ld128(rH, voA, so);
+    ra[1] = ld128(rT, voA, so);
+    const uint32_t sw = (uint32_t)(32 * kt) * 4u;
+    rbq = (tid >> 8) ? ld128(rW3, voW, sw) : ld128(rV3, voW, sw);
   };
   auto lstore = [&](const f32x4 (&ra)[2], const f32x4& rbq, int buf) {
 #pragma unroll
@@ -339,23 +351,20 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
         const int cb = 32 * (8 * i + wv);
         __builtin_amdgcn_sched_barrier(0);
         float w3f[16];
-        const float* w3p = a.W3;             // (laundered: keeps these loads inside the tile loop, see k_lw_head)
-        asm volatile("" : "+s"(w3p));
+        uint32_t w3o = ((uint32_t)hi * (uint32_t)h + (uint32_t)j) * 4u;     // lane part of W3[2 s + hi][cb + j]; laundered: keeps these loads
+        asm volatile("" : "+v"(w3o));                                       // inside the tile loop (hoisted, CH x 16 fragments stay live: spills)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const int act = 2 * s + hi;
-          const float w = w3p[(int64_t)(act < m ? act : 0) * h + cb + j];
-          w3f[s] = act < m ? w : 0.f;
-        }
+        for (int s = 0; s < 16; ++s)
+          w3f[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rW3, (int)w3o, (int)((uint32_t)(2 * s * h + cb) * 4u), 0));   // rows >= m: 0
 #pragma unroll 1
         for (int rb = 0; rb < 2; ++rb) {
           __builtin_amdgcn_sched_barrier(0);
-          const float* __restrict__ Hb = a.H + (row0 + 32 * rb) * (int64_t)h + cb;
           float* __restrict__ Db = a.T + (row0 + 32 * rb) * (int64_t)h + cb;
+          const uint32_t sob = (uint32_t)((((uint64_t)row0 + (uint64_t)(32 * rb)) * (uint64_t)h + (uint64_t)cb) * 4u);
           float y[16];
           if (FULL) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = (Hb + rowof(r) * h)[laneoff];
+            for (int r = 0; r < 16; ++r) y[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rH, (int)lane4, (int)(sob + (uint32_t)(rowof(r) * h) * 4u), 0));
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
           for (int r = 0; r < 16; ++r) {
             const float dv = dacc[r] * fmaf(-y[r], y[r], 1.0f);
             csum[i] += dv;
-            if (FULL) (Db + rowof(r) * h)[laneoff] = dv;
+            if (FULL) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv), rT, (int)lane4, (int)(sob + (uint32_t)(rowof(r) * h) * 4u), 0);
             else if (row0 + 32 * rb + unit_of(r, hi) < a.N) (Db + rowof(r) * h)[laneoff] = dv;
             gacc[i] = MJX_MFMA(mud[(32 * rb + unit_of(r, hi)) * LH_MS + j], y[r], gacc[i]);
           }
