@@ -1013,6 +1013,14 @@ def test_batched_policy_forward_device(hid):
     pickle.loads(pickle.dumps(pol))                                 # the device context never travels
 
 
+# N3 bars (r04: set from what the chains measure, VERDICT r03 weak 3 -- they had been 2e-3 of the parameter movement "because minibatch
+# Adam is chaotic"; measured on MI355X: BC-MSE 6.4e-7, BC-MLE 5.7e-7 (54 / 20 steps), PPO 3.2e-6 / 2.5e-6 (28 steps, twice), PPO against
+# torch autograd + torch.optim.Adam 9.7e-6, the persistent one-workgroup trainer against the per-step launches 7e-6..1e-5).  The bars
+# sit ~10 x above that; the long chains (MLP baseline: 188 / 9 372 steps) stay statistical, as documented there.
+BAR_BC = {"bc_mse_32x32": 1e-5, "bc_mle_64x64": 1e-5}
+BAR_PPO = 3e-5
+
+
 @pytest.mark.parametrize("name", ["bc_mse_32x32", "bc_mle_64x64"])
 def test_bc_minibatch_adam_vs_reference(name):
     """BC.train: the device minibatch-Adam loop lands on the parameters the reference's torch loop
@@ -1035,7 +1043,8 @@ def test_bc_minibatch_adam_vs_reference(name):
     bc.train()
     moved = np.linalg.norm(g["theta_final"] - g["theta_start"])
     err = np.linalg.norm(pol.get_param_values() - g["theta_final"])
-    assert err < 2e-3 * moved, (err, moved)
+    print("[N3 %s] distance from the reference's parameters / their movement: %.2e" % (name, err / moved))
+    assert err < BAR_BC[name] * moved, (err, moved)
     assert np.array_equal(pol.get_param_values(), pol.get_old_param_values())
     assert bc.logger.log['loss_after'][-1] < bc.logger.log['loss_before'][-1]
 
@@ -1061,7 +1070,8 @@ def test_ppo_minibatch_adam_vs_reference():
         agent.train_from_paths(paths)
         moved = np.linalg.norm(ref - g["theta0"])
         err = np.linalg.norm(pol.get_param_values() - ref)
-        assert err < 2e-3 * moved, (err, moved)
+        print("[N3 ppo_64x64] distance from the reference's parameters / their movement: %.2e" % (err / moved))
+        assert err < BAR_PPO * moved, (err, moved)
     assert agent.last_update["kl_dist"] > 0
 
 
@@ -1101,7 +1111,8 @@ def test_ppo_fixed_old_policy_vs_torch_autograd():
     agent.train_from_paths(paths)
     moved = np.linalg.norm(ref.get_param_values() - g["theta0"])
     err = np.linalg.norm(pol.get_param_values() - ref.get_param_values())
-    assert moved > 0.05 and err < 1e-3 * moved, (err, moved)
+    print("[N3 ppo vs torch autograd, old policy fixed] %.2e of the movement" % (err / moved))
+    assert moved > 0.05 and err < 1e-4 * moved, (err, moved)
 
 
 @pytest.mark.parametrize("n,m,H,B", [(17, 6, 64, 64), (5, 2, 32, 8), (63, 16, 64, 32), (11, 3, 32, 64), (17, 6, 64, 48), (39, 16, 64, 12),
@@ -1140,7 +1151,8 @@ def test_persistent_policy_trainer_equals_launch_path(n, m, H, B, monkeypatch):
         (th_a, am_a, av_a, lt_a), (th_b, am_b, av_b, lt_b) = out
         moved = np.linalg.norm(th_b - th0)
         assert moved > 1e-3
-        assert np.linalg.norm(th_a - th_b) < 2e-3 * moved, (loss, track, np.linalg.norm(th_a - th_b), moved)
+        print("[N3 persistent vs launches, loss %d track %d] %.2e of the movement" % (loss, track, np.linalg.norm(th_a - th_b) / moved))
+        assert np.linalg.norm(th_a - th_b) < 1e-4 * moved, (loss, track, np.linalg.norm(th_a - th_b), moved)
         np.testing.assert_allclose(lt_a, lt_b, rtol=2e-4, atol=1e-5)      # (a PPO minibatch loss is a sum of cancelling O(1) terms)
         assert np.linalg.norm(am_a - am_b) < 1e-3 * np.linalg.norm(am_b)
         assert np.linalg.norm(av_a - av_b) < 1e-3 * np.linalg.norm(av_b)
