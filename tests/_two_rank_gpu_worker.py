@@ -24,7 +24,8 @@ def main():
     rng = np.random.RandomState(5)                       # identical on all ranks
     obs, act, adv = rng.randn(N, n).astype(np.float32), rng.randn(N, m).astype(np.float32), rng.randn(N).astype(np.float32)
     cut = int(os.environ.get("MJX_TEST_CUT", "23456"))   # ragged shards (0: rank 0 holds NO trajectories)
-    lo, hi = (0, cut) if rank == 0 else (cut, N)
+    cuts = [0, cut, N] if world == 2 else [0] + [int(c) for c in os.environ["MJX_TEST_CUTS"].split(",")] + [N]   # world > 2: explicit cuts
+    lo, hi = cuts[rank], cuts[rank + 1]
     th = synth.perturbed_params(synth.init_params(n, m, hid))
     ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
     eng = UpdateEngine(n, m, hid)

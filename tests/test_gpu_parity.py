@@ -271,7 +271,7 @@ def test_shard_sum_parity():
     eng.close()
 
 
-@pytest.mark.parametrize("transport,cut", [("peer", 23456), ("hook", 23456), ("peer", 0)])
+@pytest.mark.parametrize("transport,cut", [("peer", 23456), ("hook", 23456), ("peer", 0), ("peer3", 20000)])
 def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport, cut):
     """The multi-rank control flow on real kernels: two processes (torch.distributed.run) share the GPU, each binds a ragged
     trajectory shard and runs the engine's update sequence (K1 + rank sum, the per-iteration FVP / rank sum / CG-step loop,
@@ -281,24 +281,28 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport, cut):
     dist.all_reduce over gloo (RCCL refuses two ranks on one device).  cut = 0: rank 0 holds no trajectories at all -- it runs the
     exchange through the generic path (zeros into every buffer) while rank 1 runs it folded into its reduction / vector-update
     kernels.  Result == the one-process update on the whole batch (NPG call by call and as one call, TRPO with the device-side
-    line search, DAPG as one call); all ranks hold bit-identical vectors."""
+    line search, DAPG as one call); all ranks hold bit-identical vectors.
+    "peer3" (r04): THREE processes on the GPU -- the peer exchange with one arrival flag per source rank beyond two ranks (a 4-slot
+    sum with one slot of zeros; ADVICE r03 asked for >= 3 ranks: this covers the protocol, not the ordering of real xGMI links)."""
     import subprocess
     import sys
     import torch
     from mjrl_amd.engine import UpdateEngine
     out = str(tmp_path / "two_rank.npz")
     port = 29600 + (os.getpid() % 300)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MJX_PEER_COMM="1" if transport == "peer" else "0",
-               MJX_TEST_CUT=str(cut))
-    port += (7 if transport == "peer" else 0) + (13 if cut == 0 else 0)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    world = 3 if transport == "peer3" else 2
+    cuts3 = [20000, 41000]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MJX_PEER_COMM="1" if transport.startswith("peer") else "0",
+               MJX_TEST_CUT=str(cut), MJX_TEST_CUTS=",".join(str(c) for c in cuts3))
+    port += (7 if transport == "peer" else 0) + (13 if cut == 0 else 0) + (29 if world == 3 else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "_two_rank_gpu_worker.py"), out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     two = np.load(out)
     assert bool(two["ranks_identical"][0])
     assert two["native_comm"].all(), "the rank sums must run inside libmjx's C loops (mjx_cg_solve / mjx_npg_update)"
-    assert str(two["comm_kind"][0]) == transport
+    assert str(two["comm_kind"][0]) == ("peer" if world == 3 else transport)
     assert bool(two["one_call_equal"][0]), "mjx_npg_update != the call-by-call sequence on two ranks"
     n, m, hid, N = 17, 6, (64, 64), 60000
     rng = np.random.RandomState(5)
@@ -325,9 +329,9 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport, cut):
     np.testing.assert_allclose(two["trpo"][[0, 2, 3]], [tr["alpha"], tr["kl"], tr["surr_after"]], rtol=2e-5, atol=1e-7)
     assert rel(two["trpo_theta"], eng.theta_new.cpu().numpy()) < 1e-6
     # DAPG: the ranks' blocks are [on-policy ; demonstrations] each; one rank sees the same rows as [all on-policy ; all demonstrations]
-    los, his = (0, cut), (cut, N)
+    bounds = [0, cut, N] if world == 2 else [0] + cuts3 + [N]
     on_idx, demo_idx = [], []
-    for lo, hi in (los, his):
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
         n_demo = min(500, hi - lo)
         on_idx += list(range(lo, hi - n_demo)); demo_idx += list(range(hi - n_demo, hi))
     idx = np.array(on_idx + demo_idx)
