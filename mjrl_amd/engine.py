@@ -565,7 +565,7 @@ class UpdateEngine:
                                      self.results)
             self.old_is_new = False
             first = False
-            s = self._host_results = self._checked(self.results.cpu().numpy())
+            s = self._host_results = self._checked(self.results.cpu().numpy(), fields=(4, 8))
             trials, accepted = int(s[11]), s[10] != 0.0
             for k in range(len(hist), trials):
                 hist.append((float(s[16 + 2 * (k % 24)] / self.N_global), float(s[17 + 2 * (k % 24)] / self.N_global)))
@@ -573,6 +573,8 @@ class UpdateEngine:
             if accepted or trials >= max_trials:
                 break
             batch = 2 * nb                               # a long search reads back less and less often: 3, 6, 12, 24, 24, ...
+        if accepted:
+            self._checked(s)
         alpha, surr_after, kl = float(s[9]), float(s[0] / self.N_global), float(s[1] / self.N_global)
         if not accepted:
             # trpo.py:119-126: after 100 rejected step lengths alpha = 0 -- the parameters stay, KL and surrogate are evaluated there
@@ -581,11 +583,13 @@ class UpdateEngine:
             surr_after, kl = self.eval_surr_kl()
         return dict(alpha=alpha, trials=trials, accepted=bool(accepted), surr_after=surr_after, kl=kl, history=hist)
 
-    def _checked(self, s):
-        """the host copy of `results` after an update's read-back: a non-finite surrogate / KL / step length must not reach
+    def _checked(self, s, fields=(0, 1, 4, 8, 9)):
+        """the host copy of `results` after an update's read-back: a non-finite surrogate / KL / g.x / step length must not reach
         policy.set_param_values silently.  The peer exchange turns a wait that timed out (a lost or late rank) into NaN
-        (csrc/vecops.h peer_arrived): say so; anything else non-finite is reported as what it is."""
-        if not np.all(np.isfinite(s[:10])):
+        (csrc/vecops.h peer_arrived): say so; anything else non-finite is reported as what it is.  `fields`: the entries that
+        must be finite at this point (a REJECTED line-search trial may legitimately overflow: trpo_update checks K1's sums and
+        g.x per batch of trials and the accepted trial's surrogate / KL at the end)."""
+        if not np.all(np.isfinite(s[list(fields)])):
             timeouts = self.backend.peer_timeouts() if (self.comm_kind == "peer" and hasattr(self.backend, "peer_timeouts")) else 0
             if timeouts:
                 self._comm_state, self.comm_kind = False, None       # the ranks' exchange sequences are out of step from here on

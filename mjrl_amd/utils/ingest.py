@@ -303,6 +303,10 @@ class PathStager:
         return self.finish(wait)
 
     def close(self):
+        try:
+            self.join()                          # (a staging job must not outlive the buffers it writes)
+        except Exception:                        # pragma: no cover
+            pass
         if self.pool is not None:
             self.pool.shutdown(wait=True)
             self.pool = None
