@@ -246,6 +246,18 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
 #pragma unroll 1
       for (int hb = 0; hb < 2; ++hb) {
         MJX_FIT_STAMP(0);
+        // (r04, REGMOM builds) this lane's byte address per tile and use, re-laundered every half: every LDS access of the MFMA phases
+        // below is then `base + immediate` -- no hoisted address parked in an AGPR, no v_add_u32 re-basing ds_read2 pairs between
+        // MFMAs (k_mlp_fit1p tells the story; the r03 kernels, REGMOM = false, keep the compiler's addressing)
+        const uint32_t h1w = lds_pin(&h1T[(32 * w + 4 * hi) * ST + j]), d2w = lds_pin(&d2T[(32 * w + 4 * hi) * ST + j]);
+        const uint32_t h2w = lds_pin(&h2T[(32 * w + 4 * hi) * ST + j]);
+        const uint32_t h1c = lds_pin(&h1T[(4 * hi) * ST + j]), d2c = lds_pin(&d2T[(4 * hi) * ST + j]);
+        const uint32_t h1r = lds_pin(&h1T[(32 * w + j) * ST + 4 * hi]), d2r = lds_pin(&d2T[(32 * w + j) * ST + 4 * hi]);
+        const uint32_t h1n = lds_pin(&h1T[j * ST + 4 * hi]);
+        const uint32_t w2r = lds_pin(&sW2[(32 * w + j) * S2 + 4 * hi]), w2c = lds_pin(&sW2[(4 * hi) * S2 + 32 * w + j]);
+        typedef __attribute__((address_space(3))) f32x4 lds_f4;
+#define FIT2_LD1(base, off) (*(const volatile lds_float*)(uintptr_t)((base) + (uint32_t)((off) * 4)))
+#define FIT2_LD4(base, off) (*(const lds_f4*)(uintptr_t)((base) + (uint32_t)((off) * 4)))
         gather_store();
         __syncthreads();
         // prefetch the next half's rows while this half computes
@@ -264,7 +276,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
           z1 = MJX_MFMA(a.y, b.y, z1);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h1T[(32 * w + unit_of(r, hi)) * ST + j] = fmaxf(z1[r], 0.f);
+        for (int r = 0; r < 16; ++r) {
+          if constexpr (REGMOM) LDS_AT(h1w)[unit_of(r, 0) * ST] = fmaxf(z1[r], 0.f);
+          else h1T[(32 * w + unit_of(r, hi)) * ST + j] = fmaxf(z1[r], 0.f);
+        }
         __syncthreads();
         MJX_FIT_STAMP(2);
         // ---- layer 2: K = all 128 h1 units (B operand from the shared h1^T tile)
@@ -276,17 +291,19 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         }
         __builtin_amdgcn_sched_barrier(0);
         {
-          f32x4 ac = *(const f32x4*)&sW2[(32 * w + j) * S2 + 4 * hi], an;
+          f32x4 ac, an;
           float bc[4], bn[4];
+          if constexpr (REGMOM) ac = FIT2_LD4(w2r, 0); else ac = *(const f32x4*)&sW2[(32 * w + j) * S2 + 4 * hi];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) bc[t] = h1T[(4 * hi + t) * ST + j];
+          for (int t = 0; t < 4; ++t) { if constexpr (REGMOM) bc[t] = FIT2_LD1(h1c, t * ST); else bc[t] = h1T[(4 * hi + t) * ST + j]; }
 #pragma unroll
           for (int g = 0; g < 16; ++g) {
             if (g + 1 < 16) {
               const int k1 = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3) + 4 * hi;
-              an = *(const f32x4*)&sW2[(32 * w + j) * S2 + k1];
+              const int k1c = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3);
+              if constexpr (REGMOM) an = FIT2_LD4(w2r, k1c); else an = *(const f32x4*)&sW2[(32 * w + j) * S2 + k1];
 #pragma unroll
-              for (int t = 0; t < 4; ++t) bn[t] = h1T[(k1 + t) * ST + j];
+              for (int t = 0; t < 4; ++t) { if constexpr (REGMOM) bn[t] = FIT2_LD1(h1c, (k1c + t) * ST); else bn[t] = h1T[(k1 + t) * ST + j]; }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) z2 = MJX_MFMA(ac[t], bc[t], z2);
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         for (int r = 0; r < 16; ++r) {
           float hv = fmaxf(z2[r], 0.f);
           z2[r] = hv;
-          h2T[(32 * w + unit_of(r, hi)) * ST + j] = hv;
+          if constexpr (REGMOM) LDS_AT(h2w)[unit_of(r, 0) * ST] = hv; else h2T[(32 * w + unit_of(r, hi)) * ST + j] = hv;
           part = fmaf(w3v[r], hv, part);
         }
         part = half_sum(part);                            // (+ the other lane half: v_permlane32_swap, the bits of part + shfl_xor(part, 32))
@@ -328,7 +345,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int u = 32 * w + unit_of(r, hi);
-          d2T[u * ST + j] = (z2[r] > 0.f) ? w3v[r] * dy : 0.f;
+          if constexpr (REGMOM) LDS_AT(d2w)[unit_of(r, 0) * ST] = (z2[r] > 0.f) ? w3v[r] * dy : 0.f;
+          else d2T[u * ST + j] = (z2[r] > 0.f) ? w3v[r] * dy : 0.f;
         }
         __syncthreads();
         MJX_FIT_STAMP(4);
@@ -347,7 +365,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         f32x16 d2u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          f32x4 t4 = *(const f32x4*)&d2T[(32 * w + j) * ST + 8 * q + 4 * hi];
+          f32x4 t4;
+          if constexpr (REGMOM) t4 = FIT2_LD4(d2r, 8 * q); else t4 = *(const f32x4*)&d2T[(32 * w + j) * ST + 8 * q + 4 * hi];
           d2u[4 * q] = t4.x; d2u[4 * q + 1] = t4.y; d2u[4 * q + 2] = t4.z; d2u[4 * q + 3] = t4.w;
         }
         {
@@ -361,12 +380,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         {
           f32x4 bc[NT], bn[NT];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bc[nt] = *(const f32x4*)&h1T[(32 * nt + j) * ST + 4 * hi];
+          for (int nt = 0; nt < NT; ++nt) { if constexpr (REGMOM) bc[nt] = FIT2_LD4(h1n, 32 * nt * ST); else bc[nt] = *(const f32x4*)&h1T[(32 * nt + j) * ST + 4 * hi]; }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             if (q + 1 < 4) {
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const f32x4*)&h1T[(32 * nt + j) * ST + 8 * (q + 1) + 4 * hi];
+              for (int nt = 0; nt < NT; ++nt) { if constexpr (REGMOM) bn[nt] = FIT2_LD4(h1n, 32 * nt * ST + 8 * (q + 1)); else bn[nt] = *(const f32x4*)&h1T[(32 * nt + j) * ST + 8 * (q + 1) + 4 * hi]; }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -383,13 +402,20 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         {
           float ac[4], an[4], bc[4], bn[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) { ac[t] = d2T[(4 * hi + t) * ST + j]; bc[t] = sW2[(4 * hi + t) * S2 + 32 * w + j]; }
+          for (int t = 0; t < 4; ++t) {
+            if constexpr (REGMOM) { ac[t] = FIT2_LD1(d2c, t * ST); bc[t] = FIT2_LD1(w2c, t * S2); }
+            else { ac[t] = d2T[(4 * hi + t) * ST + j]; bc[t] = sW2[(4 * hi + t) * S2 + 32 * w + j]; }
+          }
 #pragma unroll
           for (int g = 0; g < 16; ++g) {
             if (g + 1 < 16) {
               const int k1 = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3) + 4 * hi;
 #pragma unroll
-              for (int t = 0; t < 4; ++t) { an[t] = d2T[(k1 + t) * ST + j]; bn[t] = sW2[(k1 + t) * S2 + 32 * w + j]; }
+              for (int t = 0; t < 4; ++t) {
+                const int k1c = 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3);
+                if constexpr (REGMOM) { an[t] = FIT2_LD1(d2c, (k1c + t) * ST); bn[t] = FIT2_LD1(w2c, (k1c + t) * S2); }
+                else { an[t] = d2T[(k1 + t) * ST + j]; bn[t] = sW2[(k1 + t) * S2 + 32 * w + j]; }
+              }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) d1u = MJX_MFMA(ac[t], bc[t], d1u);
@@ -406,7 +432,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                       // relu'(z1) mask from h1^T (same layout)
-          f32x4 hv = *(const f32x4*)&h1T[(32 * w + j) * ST + 8 * q + 4 * hi];
+          f32x4 hv;
+          if constexpr (REGMOM) hv = FIT2_LD4(h1r, 8 * q); else hv = *(const f32x4*)&h1T[(32 * w + j) * ST + 8 * q + 4 * hi];
           d1u[4 * q] = hv.x > 0.f ? d1u[4 * q] : 0.f; d1u[4 * q + 1] = hv.y > 0.f ? d1u[4 * q + 1] : 0.f;
           d1u[4 * q + 2] = hv.z > 0.f ? d1u[4 * q + 2] : 0.f; d1u[4 * q + 3] = hv.w > 0.f ? d1u[4 * q + 3] : 0.f;
         }
