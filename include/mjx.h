@@ -253,6 +253,10 @@ int mjx_apply_npg_step(mjx_ctx* ctx, const float* theta, const float* x, const d
  * terminal value 0 (process_samples.discount_sum :37-44, compute_returns :3-5). fp64. */
 int mjx_discount_scan(const double* x, const int64_t* offsets, int64_t n_traj, double gamma,
                       double* y, void* stream);
+/* tpos[s] = index of sample s inside its trajectory, for all trajectories [offsets[i], offsets[i+1]) (device pointers; int32
+ * out): the np.arange(len(path)) of the baselines' time features (quadratic_baseline.py:28, mlp_baseline.py:47), formed where
+ * the feature kernels (mjx_bl_*) read it. */
+int mjx_time_index(const int64_t* offsets, int64_t n_traj, int32_t* tpos, void* stream);
 /* GAE branch of compute_advantages (process_samples.py:21-29):
  *   b1 = [b, terminated ? 0 : b[-1]]; td = r + gamma*b1[1:] - b1[:-1];
  *   adv = discount_scan(td, gamma*lam).

@@ -57,6 +57,7 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_void_p]),
     "mjx_apply_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "mjx_apply_npg_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_float, c_void_p, c_void_p, c_void_p]),
+    "mjx_time_index": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mjx_discount_scan": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p]),
     "mjx_gae": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_void_p, c_void_p]),
     "mjx_sum_stats": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p]),

@@ -77,8 +77,7 @@ class DeviceBlock:
             self.shared = True
             self.obs = ingest.stage_shared(self.handle, paths, ("observations",))["observations"]["raw"]
             self.N, self.n = int(self.obs.shape[0]), int(self.obs.shape[1])
-            self.tpos = ingest.derived(self.handle, paths, "observations", "tpos",
-                                       lambda: ingest.upload(self.handle, _time_index(paths)))
+            self.tpos = ingest.derived(self.handle, paths, "observations", "tpos", lambda: self._time_index_dev(paths))
         else:
             o, tpos = path_inputs(paths, inp)
             self.N, self.n = o.shape
@@ -87,6 +86,19 @@ class DeviceBlock:
 
     def st(self):
         return stream(self.torch, self.dev)
+
+    def _time_index_dev(self, paths):
+        """the time index formed on the device from the trajectory offsets (8 bytes per trajectory cross the bus instead of
+        4 per timestep, and the host does not build three N-sized temporaries)"""
+        got = ingest.collect_arrays(paths, "rewards")           # (the reference counts a path's steps on its rewards)
+        if got is None or self.dev.type != "cuda":
+            return ingest.upload(self.handle, _time_index(paths))
+        off = np.zeros(len(paths) + 1, np.int64)
+        np.cumsum(got[1], out=off[1:])
+        offd = self.torch.from_numpy(off).to(self.dev)
+        tpos = self.torch.empty(int(off[-1]), dtype=self.torch.int32, device=self.dev)
+        check(self.lib.mjx_time_index(ptr(offd), len(paths), ptr(tpos), self.st()))
+        return tpos
 
     def returns_dev(self):
         """the concatenated fp64 returns on the device: the block compute_returns left there (utils/process_samples.py)

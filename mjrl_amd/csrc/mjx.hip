@@ -1058,6 +1058,14 @@ int mjx_discount_scan(const double* x, const int64_t* offsets, int64_t n_traj, d
   return MJX_OK;
 }
 
+int mjx_time_index(const int64_t* offsets, int64_t n_traj, int32_t* tpos, void* stream) {
+  if (n_traj == 0) return MJX_OK;
+  if (!offsets || !tpos || n_traj < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  hipLaunchKernelGGL(k_time_index, dim3((unsigned)n_traj), dim3(256), 0, (hipStream_t)stream, offsets, tpos);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+
 int mjx_gae(const double* rewards, const double* baseline, const int64_t* offsets, const uint8_t* terminated,
             int64_t n_traj, double gamma, double lam, double* adv, void* stream) {
   if (n_traj == 0) return MJX_OK;

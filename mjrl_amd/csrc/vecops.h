@@ -393,6 +393,13 @@ __global__ void k_apply_npg_step(const float* __restrict__ theta, const float* _
   out[i] = v;
 }
 
+// tpos[s] = position of sample s inside its trajectory (the np.arange(l) per path of the baselines' time features,
+// mjrl/baselines/quadratic_baseline.py:28 / mlp_baseline.py:47): one block per trajectory, coalesced int32 stores
+__global__ __launch_bounds__(256) void k_time_index(const int64_t* __restrict__ offsets, int* __restrict__ tpos) {
+  const int64_t lo = offsets[blockIdx.x], len = offsets[blockIdx.x + 1] - lo;
+  for (int64_t i = threadIdx.x; i < len; i += 256) tpos[lo + i] = (int)i;
+}
+
 // ---- K5: reverse discounted scans over ragged trajectories (process_samples.py:21-44) ----
 // One 256-thread block per trajectory; the trajectory is cut into 256 contiguous segments,
 // pass 1 reduces every segment with zero carry, thread 0 chains the 256 carries, pass 2

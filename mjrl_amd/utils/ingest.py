@@ -12,6 +12,8 @@ A sampler that wants to overlap ingestion with sampling calls ``begin / add_path
 as trajectories complete; ``stage`` does the three steps for a finished list.
 """
 import contextlib
+import os
+import sys
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
@@ -379,6 +381,46 @@ def download(backend, t):
         slot["event"].record(torch.cuda.current_stream(dev))
     finally:
         slot["busy"] = False
+    return out
+
+
+_OWNED = {}                     # (device) -> page-locked buffers whose memory is handed out AS the host block
+_OWNED_MAX = int(os.environ.get("MJX_OWNED_BUFFERS", "12"))
+
+
+def download_owned(backend, t):
+    """device tensor -> host ndarray that IS the page-locked memory the copy engine wrote: no second copy and no fresh multi-
+    megabyte allocation (page faults) per block.  For the blocks that are handed to the paths as views and live as long as the
+    batch (returns, baseline, advantages: utils/process_samples.py).  A buffer goes back into circulation when the last view
+    of it has died -- its NumPy reference count says so (every view's .base is the buffer's root array); at most
+    MJX_OWNED_BUFFERS (12) buffers are kept, a caller that holds on to more batches than that gets ordinary copies."""
+    torch, dev = backend.torch, backend.device
+    n = t.numel() * t.element_size()
+    if dev.type != "cuda" or not t.is_cuda or n < _BOUNCE_MIN or _OWNED_MAX <= 0:
+        return download(backend, t)
+    t = t.contiguous()
+    out = None
+    with _BOUNCE_LOCK:                                                        # (not re-entrant: the fall-back below runs outside it)
+        pool = _OWNED.setdefault((dev.type, dev.index), [])
+        ent = None
+        for e in pool:
+            if n <= e["cap"] <= 4 * n and sys.getrefcount(e["np"]) <= 2:      # the dict's reference + getrefcount's argument
+                ent = e
+                break
+        if ent is None and len(pool) >= _OWNED_MAX:
+            idle = [e for e in pool if sys.getrefcount(e["np"]) <= 2]
+            if idle:
+                pool[:] = [e for e in pool if e is not idle[0]]               # (a wrong-sized idle buffer makes room)
+        if ent is None and len(pool) < _OWNED_MAX:
+            cap = max(1 << 20, 1 << int(n - 1).bit_length())
+            ent = dict(cap=cap, pin=torch.empty(cap, dtype=torch.uint8, pin_memory=True))
+            ent["np"] = ent["pin"].numpy()
+            pool.append(ent)
+        if ent is not None:                                                   # the view holds the buffer from here on
+            out = ent["np"][:n].view(torch.empty(0, dtype=t.dtype).numpy().dtype).reshape(tuple(t.shape))
+    if out is None:
+        return download(backend, t)
+    ent["pin"][:n].copy_(t.view(-1).view(torch.uint8))                        # device -> page-locked host, blocking
     return out
 
 

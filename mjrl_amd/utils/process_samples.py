@@ -58,7 +58,7 @@ def _offsets_dev(h, paths, off):
 
 def _hand_out(h, paths, key, block, off):
     """one read-back of a device block; the paths get per-path views of the host copy -> the list of views"""
-    host = ingest.download(h, block)
+    host = ingest.download_owned(h, block)   # (page-locked memory that lives as long as the paths' views of it)
     host.setflags(write=False)          # the device block stays registered for this batch: an in-place edit of a view must not go unnoticed (utils/ingest.py)
     views = [host[off[i]:off[i + 1]] for i in range(len(paths))]
     for p, v in zip(paths, views):

@@ -464,6 +464,59 @@ def test_upload_download_never_touch_pageable_memory_and_round_trip():
     assert all(m.shape == (200_000,) for m in many)
 
 
+def test_owned_downloads_are_zero_copy_exact_and_recycled_only_when_unreferenced():
+    """utils/ingest.download_owned: the host block the paths get views of IS the page-locked memory the copy wrote; a buffer is
+    handed out again only after every view of it has died, and a caller that keeps more blocks alive than the pool holds still
+    gets correct (copied) arrays."""
+    import torch
+    from mjrl_amd import _lib
+    from mjrl_amd.utils import ingest
+    h = ingest.DeviceHandle(torch, torch.device("cuda", torch.cuda.current_device()), _lib.load())
+    ts = [torch.randn(300_000, dtype=torch.float64, device=h.device) + i for i in range(ingest._OWNED_MAX + 4)]
+    ref = [t.cpu().numpy() for t in ts]
+    held = [ingest.download_owned(h, t) for t in ts]                       # all alive at once: the last ones fall back to copies
+    views = [a[1000:2000] for a in held]
+    for a, r in zip(held, ref):
+        assert a.dtype == r.dtype and np.array_equal(a, r)
+    addr = {a.ctypes.data for a in held}
+    assert len(addr) == len(held)                                          # no buffer handed out twice while referenced
+    first = held[0].ctypes.data
+    keep = views[0]
+    del held
+    again = ingest.download_owned(h, ts[1])                                # buffer 0 is still referenced through `keep`
+    assert again.ctypes.data != first and np.array_equal(keep, ref[0][1000:2000])
+    del keep, views
+    recycled = ingest.download_owned(h, ts[2])
+    pool_addrs = {e["np"].ctypes.data for e in ingest._OWNED[(h.device.type, h.device.index)]}
+    assert recycled.ctypes.data in pool_addrs and np.array_equal(recycled, ref[2])
+    small = ingest.download_owned(h, ts[0][:10])                           # below the bounce threshold: an ordinary copy
+    assert np.array_equal(small, ref[0][:10])
+    del recycled, again
+    wide = torch.randn(5_000_000, dtype=torch.float64, device=h.device)    # no buffer of the pool fits: an idle one makes room
+    got = ingest.download_owned(h, wide)
+    assert np.array_equal(got, wide.cpu().numpy())
+    assert len(ingest._OWNED[(h.device.type, h.device.index)]) <= ingest._OWNED_MAX
+    assert got.ctypes.data in {e["np"].ctypes.data for e in ingest._OWNED[(h.device.type, h.device.index)]}
+
+
+def test_time_index_kernel_equals_the_per_path_arange():
+    """mjx_time_index (the baselines' time feature index, quadratic_baseline.py:28 / mlp_baseline.py:47) on ragged trajectories,
+    including empty and one-step ones"""
+    import torch
+    from mjrl_amd import _lib
+    from mjrl_amd._lib import check, ptr
+    lib = _lib.load()
+    rng = np.random.RandomState(3)
+    lens = np.concatenate([[0, 1, 255, 256, 257, 1000, 0, 3], rng.randint(1, 2000, 200)]).astype(np.int64)
+    off = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    offd = torch.from_numpy(off).cuda()
+    out = torch.full((int(off[-1]),), -7, dtype=torch.int32, device="cuda")
+    check(lib.mjx_time_index(ptr(offd), len(lens), ptr(out), 0))
+    want = np.concatenate([np.arange(l, dtype=np.int32) for l in lens])
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
 def test_device_resident_chain_equals_host_chain():
     """returns -> baseline values -> GAE -> whitening -> NPG update -> baseline fit with the blocks left on the device
     (utils/process_samples + the registry of utils/ingest) == the same iteration with every hand-over through the host
