@@ -75,14 +75,15 @@ inline int lw_ncu() {                                                        // 
   cache.push_back({dev, c});
   return c;
 }
-inline int* lw_ticket_ring() {                                               // 256 ticket counters on the current device; nullptr if the allocation fails
+inline int* lw_ticket_ring() {                                               // 256 ticket counters (+ leaver counts) on the current device; nullptr if the allocation fails
   static std::mutex mu;
   static std::vector<std::pair<int, int*>> rings;
   const int dev = lw_cur_device();
   std::lock_guard<std::mutex> lk(mu);
   for (auto& e : rings) if (e.first == dev) return e.second;
-  int* p = nullptr;
-  if (hipMalloc(&p, 256 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+  int* p = nullptr;                                                          // [256 tickets][256 leaver counts], zero between launches
+  if (hipMalloc(&p, 512 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+  else if (hipMemset(p, 0, 512 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); p = nullptr; }
   rings.push_back({dev, p});
   return p;
 }
@@ -1094,8 +1095,7 @@ struct LayerwiseWS {
     //  persistent_lb() has checked that the ring exists)
     int* ring = lw_ticket_ring();
     static std::atomic<unsigned> turn{0};
-    int* ticket = ring + (turn.fetch_add(1) & 255u);
-    (void)hipMemsetAsync(ticket, 0, sizeof(int), st);
+    int* ticket = ring + (turn.fetch_add(1) & 255u);                      // (zero: the kernel's last workgroup leaves it so)
 #ifdef MJX_PHASE_CLOCK
     if (lw_clk_buf() && lw_clk_slot() < LW_CLK_SLOTS) {
       GemmArgs h = g; h.clk = lw_clk_buf() + (int64_t)(lw_clk_slot()++) * LW_CLK_SLOT;
@@ -1105,6 +1105,9 @@ struct LayerwiseWS {
 #endif
     hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(GP_NTH), gp_lds_bytes<LB>(), st, g, row_tiles, cbs, ticket);
   }
+  // (r04, measured and dropped: handing the row blocks of the last, partial ticket round -- 67 of 3 907 tiles at the configs[3]
+  //  shard -- to the general kernel as 128 x 128 tiles in a second launch, to halve the tail: 4.39 -> 4.45 ms; the ticket scheme
+  //  already spreads the remainder, a kernel boundary costs more than the half tile it saves.  profiles/r04_lw/ab_tail_launch.log)
   static void launch_persistent(const GemmArgs& g0, int lb, hipStream_t st) {
     GemmArgs g = g0;
     if (!g.cs_ld) g.cs_ld = g.N;

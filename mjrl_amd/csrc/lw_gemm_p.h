@@ -52,8 +52,18 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
   __shared__ int s_next;
   const int ntiles = row_tiles * col_blocks;
   int t = blockIdx.x;                      // the first tile of every workgroup is its block index, the following ones come from
-  if (t >= ntiles) return;                 // a ticket counter (zeroed before the launch): 3 907 tiles over 256 workgroups as a
-                                           // static stride would end in a 16th round that only 67 workgroups run (+4.7 %)
+                                           // a ticket counter: 3 907 tiles over 256 workgroups as a static stride would end in a
+                                           // 16th round that only 67 workgroups run (+4.7 %).
+  // The counter is zero when a launch starts and is put back to zero by the LAST workgroup that leaves (ticket[256] counts the
+  // leavers; every workgroup has drawn its final ticket before it is counted): no memset launch in front of every product
+  // (r04: three 5 us fill kernels per Fisher-vector product).
+  auto leave = [&]() {
+    if (tid == 0) {
+      const int d = atomicAdd(ticket + 256, 1);
+      if (d == (int)gridDim.x - 1) { atomicExch(ticket + 256, 0); atomicExch(ticket, 0); }
+    }
+  };
+  if (t >= ntiles) { leave(); return; }
   const int KT0 = g.K[0] / GP_BK, KT = KT0 + (g.npairs > 1 ? g.K[1] / GP_BK : 0);
 
   // Operand addresses of the k-tile that is loaded next: ONE wave-uniform base per operand (scalar registers, bumped by one
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(GP_NTH, 2) void k_gemm_p(Args g, int row_tiles, int
     if (EPI == EPI_BACK && g.colsum && tid < GP_BN)
       g.colsum[(int64_t)(m0 / GP_BM) * (g.cs_ld ? g.cs_ld : g.N) + n0 + tid] = Cs[tid] + Cs[GP_BN + tid];
     GP_STAMP(3);
-    if (tn >= ntiles) break;
+    if (tn >= ntiles) { leave(); break; }
     t = tn;
   }
 }
