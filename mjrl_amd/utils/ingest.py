@@ -404,7 +404,7 @@ def download_owned(backend, t):
         pool = _OWNED.setdefault((dev.type, dev.index), [])
         ent = None
         for e in pool:
-            if n <= e["cap"] <= 4 * n and sys.getrefcount(e["np"]) <= 2:      # the dict's reference + getrefcount's argument
+            if n <= e["cap"] <= max(4 * n, 1 << 20) and sys.getrefcount(e["np"]) <= 2:      # (2: the dict's reference + getrefcount's argument)
                 ent = e
                 break
         if ent is None and len(pool) >= _OWNED_MAX:

@@ -497,6 +497,16 @@ def test_owned_downloads_are_zero_copy_exact_and_recycled_only_when_unreferenced
     assert np.array_equal(got, wide.cpu().numpy())
     assert len(ingest._OWNED[(h.device.type, h.device.index)]) <= ingest._OWNED_MAX
     assert got.ctypes.data in {e["np"].ctypes.data for e in ingest._OWNED[(h.device.type, h.device.index)]}
+    del got
+    # blocks far smaller than the smallest buffer (a 100 kB batch) circulate through the SAME buffers: no allocation per call
+    tiny = torch.randn(12_000, dtype=torch.float64, device=h.device)
+    a1 = ingest.download_owned(h, tiny)
+    a1 = ingest.download_owned(h, tiny)                                    # (the previous block is alive during the call: two buffers alternate)
+    ids = {id(e) for e in ingest._OWNED[(h.device.type, h.device.index)]}
+    for _ in range(20):
+        a1 = ingest.download_owned(h, tiny)
+        assert np.array_equal(a1, tiny.cpu().numpy())
+    assert {id(e) for e in ingest._OWNED[(h.device.type, h.device.index)]} == ids
 
 
 def test_time_index_kernel_equals_the_per_path_arange():
