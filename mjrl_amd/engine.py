@@ -583,12 +583,14 @@ class UpdateEngine:
             surr_after, kl = self.eval_surr_kl()
         return dict(alpha=alpha, trials=trials, accepted=bool(accepted), surr_after=surr_after, kl=kl, history=hist)
 
-    def _checked(self, s, fields=(0, 1, 4, 8, 9)):
+    def _checked(self, s, fields=(0, 1, 4, 8, 9), timeouts_only=False):
         """the host copy of `results` after an update's read-back: a non-finite surrogate / KL / g.x / step length must not reach
         policy.set_param_values silently.  The peer exchange turns a wait that timed out (a lost or late rank) into NaN
         (csrc/vecops.h peer_arrived): say so; anything else non-finite is reported as what it is.  `fields`: the entries that
         must be finite at this point (a REJECTED line-search trial may legitimately overflow: trpo_update checks K1's sums and
-        g.x per batch of trials and the accepted trial's surrogate / KL at the end)."""
+        g.x per batch of trials and the accepted trial's surrogate / KL at the end; eval_surr_kl -- called once per trial by the
+        call-by-call line searches, trpo.py:107-120 / batch_reinforce.py:153-160 -- raises for a timed-out exchange only and
+        otherwise hands the values on as they are, like the reference's `kl < kl_dist` on a NaN)."""
         if not np.all(np.isfinite(s[list(fields)])):
             timeouts = self.backend.peer_timeouts() if (self.comm_kind == "peer" and hasattr(self.backend, "peer_timeouts")) else 0
             if timeouts:
@@ -599,7 +601,8 @@ class UpdateEngine:
                     pass
                 raise _lib.MjxError("peer exchange: %d wait(s) for another rank's vector timed out (MJX_PEER_TIMEOUT_MS, default 5000); "
                                     "the update is invalid and the transport was torn down" % timeouts)
-            raise _lib.MjxError("the policy update produced non-finite results (surrogate / KL / g.x / step length: %s)" % (s[:10],))
+            if not timeouts_only:
+                raise _lib.MjxError("the policy update produced non-finite results (surrogate / KL / g.x / step length: %s)" % (s[:10],))
         return s
 
     def deferred(self):
@@ -613,7 +616,7 @@ class UpdateEngine:
         """K3 -> (surrogate, mean KL) (batch_reinforce.py:40-52)."""
         self.backend.eval_surr_kl(self.scal)
         self._rank_sum(self.scal)
-        s = self._host_results = self._checked(self.results.cpu().numpy())      # the whole block: deferred() needs no second read-back
+        s = self._host_results = self._checked(self.results.cpu().numpy(), fields=(0, 1), timeouts_only=True)   # the whole block: deferred() needs no second read-back
         return float(s[0] / self.N_global), float(s[1] / self.N_global)
 
     def enable_debug(self):
