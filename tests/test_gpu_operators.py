@@ -685,15 +685,19 @@ def test_device_line_search_equals_call_by_call_trpo(hid):
     ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
     obs, act, adv = rng.randn(N, n), rng.randn(N, m), rng.randn(N)
     if hid == (64, 64):
-        cases = ((0.01, 0.02), (0.002, 0.02), (4e-5, 0.02), (-1.0, 0.02))
+        cases = ((0.01, 0.02), (0.002, 0.02), (4e-5, 0.02), (-1.0, 0.02), (0.01, 1e60))
     else:
         cases = ((0.01, 0.02), (0.002, 0.02))
-    for kl_dist, step_size in cases:   # (the second: the step is sized for 5 x the KL it has to meet; third: ~27 trials; fourth: never)
+    # (the second: the step is sized for 5 x the KL it has to meet; third: ~27 trials; fourth: never; fifth: a step so long that
+    #  every trial overflows fp32 -- surrogate / KL of the trials are not finite, the comparison `kl < kl_dist` rejects them like
+    #  the reference's, nothing raises, the search gives up with alpha = 0)
+    for kl_dist, step_size in cases:
+        overflow = step_size > 1e30
         eng = UpdateEngine(n, m, hid)
         eng.set_policy(th, th, ident, ident)
         eng.set_batch(obs, act, adv)
         res = eng.trpo_update(10, 1e-4, step_size, kl_dist, -3.0)
-        assert res is not None and res["accepted"] == (kl_dist > 0)
+        assert res is not None and res["accepted"] == (kl_dist > 0 and not overflow)
         one = dict(theta=eng.theta_new.clone(), **res)
         late = eng.deferred()
         # call by call
@@ -717,10 +721,13 @@ def test_device_line_search_equals_call_by_call_trpo(hid):
         assert trials == one["trials"] and (trials > 3 or kl_dist == 0.01)
         if kl_dist == 4e-5:
             assert 24 < trials < 100, trials
-        if kl_dist < 0:
+        if kl_dist < 0 or overflow:
             assert trials == 100 and one["alpha"] == 0.0 and torch.equal(eng.theta_new, eng.theta_old)
+            assert np.isfinite(kl) and np.isfinite(surr_after)
+        if overflow:
+            assert not np.all(np.isfinite(one["history"][0]))
         assert float(alpha) == one["alpha"] and kl == one["kl"] and surr_after == one["surr_after"]
         assert torch.equal(eng.theta_new, one["theta"])
         assert late["surr_before"] == surr_before and late["gdotx"] == gdotx
-        assert len(one["history"]) == trials and one["history"][-1] == hist_last
+        assert len(one["history"]) == trials and np.array_equal(one["history"][-1], hist_last, equal_nan=True)
         eng.close()
