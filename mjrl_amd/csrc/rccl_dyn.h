@@ -52,6 +52,9 @@ struct RcclApi {
 
   bool load() {
     if (handle) return true;
+    if (const char* off = getenv("MJX_RCCL_DISABLE")) {      // (tests: the fall-back chain of engine._native_comm without a loadable RCCL)
+      if (off[0] == '1') { error = "RCCL binding disabled (MJX_RCCL_DISABLE=1)"; return false; }
+    }
     const char* env = getenv("MJX_RCCL_LIB");
     std::string cands[4] = {env ? env : "", mapped_rccl(), "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const std::string& c : cands) {

@@ -388,7 +388,7 @@ class UpdateEngine:
                     peer == "1" or (d.get_backend() != "nccl" and peer != "0")):
                 order = ["peer"] + ([] if d.get_backend() == "nccl" else ["hook"])
             elif d.get_backend() == "nccl":
-                order = ["rccl"]
+                order = ["rccl", "hook"]         # (a communicator libmjx cannot create itself: the same loops over torch's own RCCL group)
             else:
                 order = ["hook"]
             # every rank walks the same list and the ranks agree after each attempt (all or none): RCCL inside libmjx and the

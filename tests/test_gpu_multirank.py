@@ -88,3 +88,14 @@ def test_peer_timeout_surfaces_as_an_error(tmp_path):
     assert "timed out" in msg and "peer exchange" in msg, msg
     assert str(r["comm_kind_after"][0]) == "None"
     assert float(r["seconds"][0]) < 20.0
+
+
+def test_nccl_group_without_in_library_rccl_falls_back_to_the_hook(tmp_path):
+    """engine._native_comm on an nccl group whose in-library communicator cannot be created (librccl not loadable by libmjx):
+    the ranks agree, detach, and attach the hook transport -- the one-call update loops keep running, over torch.distributed's
+    own RCCL group -- and a one-rank group reproduces the single-process update bit for bit"""
+    out = str(tmp_path / "fallback.npz")
+    _run("_rccl_fallback_worker.py", [out], 1, 0, extra_env={"MJX_RCCL_DISABLE": "1", "MJX_TEST_PORT": str(29800 + (os.getpid() % 100))})
+    r = np.load(out)
+    assert str(r["kind"][0]) == "hook", r["kind"]
+    assert bool(r["same"][0])
