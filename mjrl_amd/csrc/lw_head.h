@@ -25,6 +25,14 @@
 
 #include "fused_policy.h"
 
+#ifndef MJX_HEAD_EXP
+#define MJX_HEAD_EXP 0        // timing experiments (results WRONG): 1 = k_lw_head8 without phase 2, 2 = without phase 1's k-loop.
+                              // r04: each phase alone runs 0.25 ms of the pass's 0.44 ms at the configs[3] shard (0.8 + 0.8 of 1.63 ms at
+                              // configs[4]): one workgroup per CU (89 KB of LDS, 210 registers), its two phases back to back.  Picking phase 2's
+                              // H values out of the operand buffer while their k-tile is in LDS (no re-read from L2) changed nothing:
+                              // profiles/r04_lw/head_phases.log
+#endif
+
 namespace mjx {
 
 struct HeadArgs {
@@ -308,6 +316,11 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
         for (int t = 0; t < 4; ++t) acc1 = MJX_MFMA(a4[t], b4[t], acc1);
       }
     };
+#if MJX_HEAD_EXP == 2
+    if (false) {
+#else
+    {
+#endif
     __syncthreads();
     lstore(raA, rbA, 0);
     gload(raA, rbA, row0, 2);              // (NKT >= 8)
@@ -324,6 +337,7 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
       }
       compute(1);
       __syncthreads();
+    }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) mud[((kh1 * 2 + pr1) * LH_R + 32 * rb1 + unit_of(r, hi)) * LH_MS + j] = acc1[r];
@@ -386,8 +400,10 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
         }
       }
     };
+#if MJX_HEAD_EXP != 1
     if (full) phase2(std::true_type{});
     else phase2(std::false_type{});
+#endif
   }
   float* gw = a.gw_part + (int64_t)blockIdx.x * m * h;
 #pragma unroll
