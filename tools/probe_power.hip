@@ -16,7 +16,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
-template <int L, bool STORE, int NT, bool B4>
+template <int L, bool STORE, int NT, bool B4, bool LOAD = true, int GLDS = 0>
 __global__ __launch_bounds__(NT) void k_probe(const float* __restrict__ src, float* __restrict__ dst, size_t region_f4, long long* out, int groups) {
   const int lane = threadIdx.x;
   const f32x4* p = (const f32x4*)src + (size_t)blockIdx.x * region_f4;
@@ -41,7 +41,16 @@ __global__ __launch_bounds__(NT) void k_probe(const float* __restrict__ src, flo
       // (the request made eight slots ago is "used" without a vector-ALU instruction -- those are NOT free beside fp32 MFMAs -- and
       //  the stream position advances on the scalar unit: buffer addressing, lane offset fixed, scalar offset bumped)
       asm volatile("" : : "v"(ring[l & 7]));
-      if (B4) ring[l & 7].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)so, 0));
+      if (GLDS) {
+        // the same bytes straight into LDS (global_load_lds_dwordx4: wave-uniform LDS base + lane x 16, no VGPR write-back);
+        // GLDS == 2 additionally reads them back from LDS into registers a ring turn later (ds_read_b128)
+        __shared__ __attribute__((aligned(16))) char stage[NT / 64][8][1024];
+        if (GLDS == 2) ring[l & 7] = *(const f32x4*)&stage[threadIdx.x >> 6][l & 7][(threadIdx.x & 63) * 16];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)p + so + (uint32_t)voff),
+                                         (__attribute__((address_space(3))) void*)&stage[threadIdx.x >> 6][l & 7][0], 16, 0, 0);
+      }
+      else if (!LOAD) {}
+      else if (B4) ring[l & 7].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)so, 0));
       else ring[l & 7] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)so, 0));
       if (STORE) __builtin_amdgcn_raw_buffer_store_b128((u32x4_t)__builtin_bit_cast(u32x4_t, ring[(l + 4) & 7]), rd, voff, (int)so, 0);
       so += (uint32_t)(NT * (B4 ? 4 : 16));
@@ -60,14 +69,14 @@ __global__ __launch_bounds__(NT) void k_probe(const float* __restrict__ src, flo
   if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = c1 - c0; }
 }
 
-template <int L, bool STORE, int NT = 256, bool B4 = false>
+template <int L, bool STORE, int NT = 256, bool B4 = false, bool LOAD = true, int GLDS = 0>
 void run(const char* name, const float* src, float* dst, size_t region_f4, long long* out, int nwg) {
   const int groups = 20000;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float ms = 0.f;
   for (int rep = 0; rep < 2; ++rep) {
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((k_probe<L, STORE, NT, B4>), dim3(nwg), dim3(NT), 0, 0, src, dst, region_f4, out, groups);
+    hipLaunchKernelGGL((k_probe<L, STORE, NT, B4, LOAD, GLDS>), dim3(nwg), dim3(NT), 0, 0, src, dst, region_f4, out, groups);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     CK(hipEventElapsedTime(&ms, e0, e1));
@@ -76,7 +85,7 @@ void run(const char* name, const float* src, float* dst, size_t region_f4, long 
   long long h[2];
   CK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost));
   const double ns = h[0] * 10.0 / groups, cyc = (double)h[1] / groups, ghz = (double)h[1] / (h[0] * 10.0);
-  const double bytes = (double)L * (B4 ? 4.0 : 16.0) * NT * nwg * (STORE ? 2.0 : 1.0);          // per group, whole chip
+  const double bytes = (double)L * (B4 ? 4.0 : 16.0) * NT * nwg * ((STORE ? 1.0 : 0.0) + (LOAD ? 1.0 : 0.0));          // per group, whole chip
   printf("%-46s %7.1f cycles %7.1f ns per 16 MFMAs   %.3f GHz   stream %.2f TB/s   %.1f TFLOP/s (events)\n", name, cyc, ns, ghz, bytes / ns * 1e-3, tf);
 }
 
@@ -95,6 +104,19 @@ int main() {
   run<8, false>("+ 8 loads", src, dst, region_f4, out, nwg);
   run<2, true>("+ 2 loads + 2 stores", src, dst, region_f4, out, nwg);
   run<4, true>("+ 4 loads + 4 stores", src, dst, region_f4, out, nwg);
+  printf("the same loads straight into LDS (global_load_lds_dwordx4), without / with a ds_read_b128 of the data afterwards:\n");
+  run<1, false, 256, false, true, 1>("+ 1 x 16 B global -> LDS", src, dst, region_f4, out, nwg);
+  run<2, false, 256, false, true, 1>("+ 2 global -> LDS", src, dst, region_f4, out, nwg);
+  run<4, false, 256, false, true, 1>("+ 4 global -> LDS", src, dst, region_f4, out, nwg);
+  run<1, false, 256, false, true, 2>("+ 1 x (global -> LDS, LDS -> registers)", src, dst, region_f4, out, nwg);
+  run<2, false, 256, false, true, 2>("+ 2 x (global -> LDS, LDS -> registers)", src, dst, region_f4, out, nwg);
+  run<4, false, 256, false, true, 2>("+ 4 x (global -> LDS, LDS -> registers)", src, dst, region_f4, out, nwg);
+  printf("stores only (16 B per lane; the HBM WRITE rate):\n");
+  run<1, true, 256, false, false>("+ 1 store per lane and group", src, dst, region_f4, out, nwg);
+  run<2, true, 256, false, false>("+ 2 stores", src, dst, region_f4, out, nwg);
+  run<4, true, 256, false, false>("+ 4 stores", src, dst, region_f4, out, nwg);
+  run<8, true, 256, false, false>("+ 8 stores", src, dst, region_f4, out, nwg);
+  run<2, true, 512, false, false>("+ 2 stores, two waves per SIMD", src, dst, region_f4, out, nwg);
   printf("4-byte loads (256 B per wave and instruction instead of 1 KB):\n");
   run<1, false, 256, true>("+ 1 x 4 B load per lane and group", src, dst, region_f4, out, nwg);
   run<4, false, 256, true>("+ 4 x 4 B loads", src, dst, region_f4, out, nwg);
