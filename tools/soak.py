@@ -38,4 +38,30 @@ for name, cls, kw in (("npg", NPG, dict(normalized_step_size=0.05)), ("trpo", TR
         mem.append(torch.cuda.memory_allocated())
     out[name] = dict(seconds=round(time.perf_counter() - t0, 2), mem_first_MB=round(mem[10] / 2**20, 1), mem_last_MB=round(mem[-1] / 2**20, 1),
                      mem_max_MB=round(max(mem) / 2**20, 1), final_log_std=float(np.mean(pol.log_std_val)))
+# the same loop with the MLP baseline (persistent Adam trainer, all-gather-free single rank) and the host's resident set watched:
+# the page-locked hand-out buffers (ingest.download_owned) and the staging blocks must not grow with the iterations
+import psutil
+from mjrl_amd.baselines.mlp_baseline import MLPBaseline
+pol = MLP(spec, hidden_sizes=(64, 64), seed=1, init_log_std=-0.5)
+bl = MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=1, learn_rate=1e-3)
+agent = NPG(None, pol, bl, normalized_step_size=0.05)
+proc = psutil.Process()
+rss, mem = [], []
+t0 = time.perf_counter()
+for it in range(60):
+    n_traj = int(rng.randint(20, 200))
+    paths = []
+    for _ in range(n_traj):
+        T = int(rng.randint(1, 1000))
+        obs = rng.randn(T, 17)
+        act = pol.model.forward(np.float32(obs)) + np.exp(pol.log_std_val) * rng.randn(T, 6)
+        paths.append(dict(observations=obs, actions=act, rewards=-np.sum(act ** 2, axis=1) + rng.randn(T) * 0.1, terminated=bool(T < 999)))
+    process_samples.compute_returns(paths, 0.995)
+    process_samples.compute_advantages(paths, bl, 0.995, 0.97)
+    stats = agent.train_from_paths(paths)
+    bl.fit(paths)
+    assert np.all(np.isfinite(pol.get_param_values())) and np.all(np.isfinite(stats)), ("npg+mlp", it)
+    rss.append(proc.memory_info().rss); mem.append(torch.cuda.memory_allocated())
+out["npg_mlp_baseline"] = dict(seconds=round(time.perf_counter() - t0, 2), host_rss_MB_at_10=round(rss[10] / 2**20, 1), host_rss_MB_last=round(rss[-1] / 2**20, 1),
+                               host_rss_MB_max=round(max(rss) / 2**20, 1), dev_mem_MB_at_10=round(mem[10] / 2**20, 1), dev_mem_MB_last=round(mem[-1] / 2**20, 1))
 print(json.dumps(out))
