@@ -492,6 +492,35 @@ def test_returns_and_gae_vs_reference(kind):
     np.testing.assert_allclose(process_samples.discount_sum(x, 0.9), O.discount_sum(x, 0.9), rtol=1e-12, atol=1e-12)
 
 
+def test_scans_on_edge_lengths_vs_oracle():
+    """K5 on the trajectory lengths that sit on the scan kernel's seams -- one block of 256 threads per trajectory, the trajectory
+    cut into 256 segments (csrc/vecops.h k_traj_scan): 1, 2, 255, 256, 257, 511, 512, 513, 1000, 4099 steps, terminated and
+    not, in one batch -- against the sequential recurrences of the oracle (process_samples.py:21-44); > 64 KB of rewards, so the
+    hand-out runs through the page-locked buffers as well."""
+    from mjrl_amd.utils import process_samples
+    rng = np.random.RandomState(11)
+    lens = [1, 2, 255, 256, 257, 511, 512, 513, 1000, 4099, 1, 3, 4099, 256]
+    paths = [dict(observations=rng.randn(T, 5), actions=rng.randn(T, 2), rewards=rng.randn(T), terminated=bool(i % 2)) for i, T in enumerate(lens)]
+    gamma, lam = 0.995, 0.97
+    process_samples.compute_returns(paths, gamma)
+    for p in paths:
+        np.testing.assert_allclose(p["returns"], O.discount_sum(p["rewards"], gamma), rtol=1e-12, atol=1e-12)
+    base = [rng.randn(T) for T in lens]
+
+    class Frozen:
+        def __init__(self):
+            self.k = 0
+        def predict(self, path):
+            self.k += 1
+            return base[self.k - 1]
+    process_samples.compute_advantages(paths, Frozen(), gamma, lam)
+    for p, b in zip(paths, base):
+        np.testing.assert_allclose(p["advantages"], O.gae_path(p["rewards"], b, p["terminated"], gamma, lam), rtol=1e-10, atol=1e-10)
+    process_samples.compute_advantages(paths, Frozen(), gamma, None)
+    for p, b in zip(paths, base):
+        np.testing.assert_allclose(p["advantages"], p["returns"] - b, rtol=1e-12, atol=1e-12)
+
+
 def test_scan_full_size_properties():
     """1M timesteps: linearity of the scan and the one-step recurrence y[t] - g*y[t+1] == x[t]."""
     from mjrl_amd.utils import process_samples
