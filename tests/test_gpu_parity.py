@@ -492,6 +492,26 @@ def test_returns_and_gae_vs_reference(kind):
     np.testing.assert_allclose(process_samples.discount_sum(x, 0.9), O.discount_sum(x, 0.9), rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("N", [1, 30, 64, 127, 128, 200])
+def test_mlp_baseline_fit_on_batches_smaller_than_two_minibatches(N):
+    """MLPBaseline.fit runs int(N / 64) - 1 Adam steps per epoch (utils/optimize_model.py:24: the last, partial minibatch and one
+    more are never visited): below 128 samples that is none -- parameters, moments and predictions stay as they were, the
+    errors are finite and equal -- and from 128 on the parameters move."""
+    from mjrl_amd.baselines.mlp_baseline import MLPBaseline
+    spec = type("Spec", (), dict(observation_dim=5, action_dim=2, horizon=50))
+    rng = np.random.RandomState(N)
+    bl = MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3)
+    paths = [dict(observations=rng.randn(N, 5), rewards=rng.randn(N), returns=rng.randn(N))]
+    before = np.array(bl.params, copy=True)
+    pred0 = np.array(bl.predict(paths[0]), copy=True)
+    e0, e1 = bl.fit(paths, return_errors=True)
+    assert np.isfinite(e0) and np.isfinite(e1) and np.all(np.isfinite(bl.params))
+    if N < 128:
+        assert np.array_equal(bl.params, before) and e0 == e1 and np.array_equal(bl.predict(paths[0]), pred0)
+    else:
+        assert not np.array_equal(bl.params, before)
+
+
 def test_scans_on_edge_lengths_vs_oracle():
     """K5 on the trajectory lengths that sit on the scan kernel's seams -- one block of 256 threads per trajectory, the trajectory
     cut into 256 segments (csrc/vecops.h k_traj_scan): 1, 2, 255, 256, 257, 511, 512, 513, 1000, 4099 steps, terminated and
