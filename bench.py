@@ -65,6 +65,50 @@ def initial_params():
     return (th + 0.1 * np.random.RandomState(1).randn(th.size)).astype(np.float32)
 
 
+# the per-GPU shards of the 8-GPU configs (BASELINE configs[3] / [4]) the layer-wise numbers are quoted on: seeded host
+# inputs, so that tests/golden/make_golden_big.py can run the UNMODIFIED reference on exactly these rows
+LW_SHARDS = {
+    "configs3_humanoid_256x256": dict(n=376, m=17, hidden=(256, 256), n_traj=500, T=1000, cg_iters=25, algo="npg", seed=31,
+                                      fixture="npg_cfg4_shard"),
+    "configs4_adroit_512x512": dict(n=39, m=28, hidden=(512, 512), n_traj=5000, T=200, cg_iters=10, algo="dapg", seed=41,
+                                    demo_rows=5000, kl_dist=0.025, lam_0=1e-2, fixture="dapg_cfg5_shard"),
+}
+
+
+def lw_initial_params(n, m, hid):
+    """nn.Linear-style random init (last layer x 1e-2, log_std -0.5) + 0.02 N(0,1), like initial_params()"""
+    rng = np.random.RandomState(1)
+    sizes = (n,) + tuple(hid) + (m,)
+    flat = []
+    for i in range(len(sizes) - 1):
+        k = 1.0 / np.sqrt(sizes[i])
+        flat += [rng.uniform(-k, k, (sizes[i + 1], sizes[i])).ravel() * (1e-2 if i == len(sizes) - 2 else 1.0), rng.uniform(-k, k, sizes[i + 1])]
+    flat.append(np.full(m, -0.5))
+    th = np.concatenate(flat).astype(np.float32)
+    return (th + 0.02 * np.random.RandomState(1).randn(th.size)).astype(np.float32)
+
+
+def lw_shard_inputs(name):
+    """-> dict(theta, obs (N, n) f32, act (N, m) f32, adv (N,) f64 un-whitened[, demo_obs, demo_act]) of one LW_SHARDS entry,
+    from a PCG64 stream (float32 ziggurat draws: 0.2 G samples in a second or two on one core)"""
+    c = LW_SHARDS[name]
+    N = c["n_traj"] * c["T"]
+    g = np.random.Generator(np.random.PCG64(c["seed"]))
+    out = dict(theta=lw_initial_params(c["n"], c["m"], c["hidden"]),
+               obs=g.standard_normal((N, c["n"]), dtype=np.float32), act=g.standard_normal((N, c["m"]), dtype=np.float32),
+               adv=g.standard_normal(N))
+    if c.get("demo_rows"):
+        out["demo_obs"] = g.standard_normal((c["demo_rows"], c["n"]), dtype=np.float32)
+        out["demo_act"] = g.standard_normal((c["demo_rows"], c["m"]), dtype=np.float32)
+    return out
+
+
+def lw_inputs_digest(inp):
+    """a few numbers that pin the generated rows (the fixtures carry them: a different numpy stream must not pass silently)"""
+    return np.array([float(inp["obs"][::997].astype(np.float64).sum()), float(inp["act"][::997].astype(np.float64).sum()),
+                     float(inp["adv"][::997].sum()), float(inp["theta"].astype(np.float64).sum())])
+
+
 def cpu_baseline(theta0, sample_traj):
     """The CPU path timed on this box's host cores, rank 0, N = 1.
 

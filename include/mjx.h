@@ -45,6 +45,13 @@ int mjx_version(void);
 /* number of visible HIP devices (0 when there is none; never fails) */
 int mjx_device_count(void);
 
+/* Fork guard.  The reference's sampler forks its workers from the training process (mjrl/samplers/core.py:189-210, mp.Pool) and
+ * pickles the policy into them (:196); a child forked from a process that holds HIP state cannot use the device.  out2[0] = number
+ * of device-touching entries (mjx_device_count / mjx_create / mjx_malloc / mjx_stage_async) THIS process has made -- zeroed in a
+ * forked child; out2[1] = 1 when this process was forked from one that had made any.  In such a child mjx_create / mjx_malloc /
+ * mjx_stage_async fail with MJX_ERR_STATE and mjx_device_count returns 0 (nothing hangs inside the runtime). */
+int mjx_process_state(int64_t* out2);
+
 /* Create a context for a tanh-MLP Gaussian policy obs(n) -> hidden[...] -> act(m)
  * on HIP device `device`.  Replaces the torch modules built in
  * mjrl/policies/gaussian_mlp.py:8-56 (MLP) and gaussian_linear.py:9-56

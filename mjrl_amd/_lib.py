@@ -20,6 +20,7 @@ PROTOTYPES = {
     "mjx_last_error": (ctypes.c_char_p, []),
     "mjx_version": (c_int, []),
     "mjx_device_count": (c_int, []),
+    "mjx_process_state": (c_int, [ctypes.POINTER(c_int64)]),
     "mjx_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, ctypes.POINTER(c_int), c_int]),
     "mjx_destroy": (None, [c_void_p]),
     "mjx_num_params": (c_int64, [c_void_p]),

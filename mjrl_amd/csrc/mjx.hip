@@ -9,7 +9,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <pthread.h>
 #include <unistd.h>
+#include <atomic>
 #include <string>
 #include <condition_variable>
 #include <functional>
@@ -43,6 +45,27 @@ int fail(int code, const char* fmt, ...) {
   do {                                                                                   \
     hipError_t e_ = (expr);                                                              \
     if (e_ != hipSuccess) return fail((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// ---- fork guard.  Sampler workers are FORKED from the training process (mjrl/samplers/core.py:189-210: mp.Pool under a parent
+// that holds an mjx_ctx, page-locked staging blocks and libmjx's gather threads).  None of that survives a fork in a usable
+// state, so a forked child of a process that touched the device through this library may not touch it again: every entry that
+// creates device state refuses there, loudly, instead of hanging inside the HIP runtime.  mjx_process_state() lets a test (or
+// a worker) prove that it never tried.
+std::atomic<long long> g_device_calls{0};     // entries that reach the HIP runtime, made by THIS process (zeroed in a forked child)
+std::atomic<int> g_forked_child{0};           // 1: this process was forked from one whose g_device_calls was > 0
+void atfork_child() {
+  if (g_device_calls.load() > 0) g_forked_child.store(1);
+  g_device_calls.store(0);
+}
+struct ForkGuardInit { ForkGuardInit() { pthread_atfork(nullptr, nullptr, atfork_child); } } g_fork_guard_init;
+
+#define MJX_DEVICE_ENTRY()                                                                                                          \
+  do {                                                                                                                              \
+    if (g_forked_child.load())                                                                                                      \
+      return fail(MJX_ERR_STATE, "libmjx: this process was forked from one that holds HIP state; device work belongs to the "      \
+                                 "training process (sampler workers stay on the host, mjrl/samplers/core.py)");                     \
+    g_device_calls.fetch_add(1);                                                                                                    \
   } while (0)
 
 }  // namespace
@@ -216,7 +239,16 @@ extern "C" {
 const char* mjx_last_error(void) { return g_err.c_str(); }
 int mjx_version(void) { return 1; }
 
+int mjx_process_state(int64_t* out2) {
+  if (!out2) return fail(MJX_ERR_ARG, "null output");
+  out2[0] = (int64_t)g_device_calls.load();
+  out2[1] = (int64_t)g_forked_child.load();
+  return MJX_OK;
+}
+
 int mjx_device_count(void) {
+  if (g_forked_child.load()) return 0;            // (never fails: a forked child simply sees no device through this library)
+  g_device_calls.fetch_add(1);
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
@@ -224,6 +256,7 @@ int mjx_device_count(void) {
 
 int mjx_create(mjx_ctx** out, int device, int n, int m, const int* hidden, int n_hidden) {
   if (!out || n <= 0 || m <= 0 || n_hidden < 0 || (n_hidden > 0 && !hidden)) return fail(MJX_ERR_ARG, "bad arguments");
+  MJX_DEVICE_ENTRY();
   if (mjx_device_count() <= device) return fail(MJX_ERR_NOGPU, "HIP device %d not available", device);
   HIPCHK(hipSetDevice(device));
   mjx_ctx* c = new mjx_ctx();
@@ -280,6 +313,7 @@ int64_t mjx_num_params(const mjx_ctx* c) { return c ? c->d : -1; }
 int mjx_uses_fused_path(const mjx_ctx* c) { return c ? (c->fused != 0) : 0; }
 
 int mjx_malloc(void** p, int64_t bytes) {
+  MJX_DEVICE_ENTRY();
   if (!p || bytes < 0) return fail(MJX_ERR_ARG, "bad arguments");
   HIPCHK(hipMalloc(p, (size_t)bytes + 16));      // + one 16-byte granule: the tail reads of mjx_bind_batch's observation block stay inside
   return MJX_OK;
@@ -1369,6 +1403,7 @@ int mjx_stage_async(void** job_out, const void* const* src, const int64_t* lens,
   if (!job_out || !src || !lens || count < 0 || row_elems <= 0 || (src_itemsize != 4 && src_itemsize != 8) || !pinned || !device_raw ||
       group_rows <= 0 || (hostcast && src_itemsize != 8))
     return fail(MJX_ERR_ARG, "bad arguments");
+  MJX_DEVICE_ENTRY();
   StageJob* job = new StageJob();
   job->src.assign(src, src + count);                       // (the caller's pointer / length arrays need not outlive the call)
   job->offs.resize(count + 1);

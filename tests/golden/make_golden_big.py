@@ -10,6 +10,8 @@ Run in the build container only (minutes of CPU time):   python tests/golden/mak
                     demonstration steps, DAPG, 10 CG iterations (mjrl/algos/dapg.py:92-121 at configs[4] shapes)
   bench_ref_1m      the same 1M-timestep batch through the UNMODIFIED reference: NPG.train_from_paths (configs[1]) and
                     TRPO.train_from_paths with kl_dist 0.025 (configs[2], 3 line-search trials); whole vectors stored
+  npg_cfg4_shard    bench.py's configs[3] shard (500 000 x (376, 17), 256x256, 25 CG) through the reference's NPG.train_from_paths
+  dapg_cfg5_shard   bench.py's configs[4] shard (1M x (39, 28), 512x512 + 5 000 demonstration rows) through DAPG.train_from_paths
   bench_cfg2_1m     the 1M-timestep batch bench.py runs (configs[1]): alpha / kl / surr_improvement of one NPG update
                     from the fp64 oracle (the reference needs ~20 s and agrees to 1e-6)
 
@@ -224,6 +226,78 @@ def bench_reference_case(name):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def shard_case(key):
+    """The UNMODIFIED reference at the per-GPU shard sizes bench.py quotes the layer-wise numbers on (bench.LW_SHARDS, seeded
+    host inputs): NPG.train_from_paths on 500 k x (376, 17, 256^2, 25 CG) -- mjrl/algos/npg_cg.py:91-163 -- and
+    DAPG.train_from_paths on 1M x (39, 28, 512^2) + 5 000 demonstration rows -- mjrl/algos/dapg.py:54-141.  Stored: strided
+    samples of the gradient and of the update step, alpha / KL / surrogate improvement, a digest of the inputs; then (unless
+    MJX_GOLDEN_NO_F64=1) the fp64 oracle's step on the same rows and the reference's distance from it."""
+    import bench
+    c = bench.LW_SHARDS[key]
+    name = c["fixture"]
+    n, m, hidden, T = c["n"], c["m"], c["hidden"], c["T"]
+    inp = bench.lw_shard_inputs(key)
+    theta0 = inp["theta"]
+    N = inp["obs"].shape[0]
+    spec = EnvSpec(n, m, T)
+    pol = MLP(spec, hidden_sizes=hidden, seed=1, init_log_std=-0.5)
+    pol.set_param_values(theta0.copy())
+    assert np.array_equal(pol.get_param_values(), theta0)
+    obs64, act64 = inp["obs"].astype(np.float64), inp["act"].astype(np.float64)
+    paths = [dict(observations=obs64[i * T:(i + 1) * T], actions=act64[i * T:(i + 1) * T], rewards=np.zeros(T),
+                  advantages=inp["adv"][i * T:(i + 1) * T].copy(), terminated=False) for i in range(c["n_traj"])]
+    kw = dict(FIM_invert_args={'iters': c["cg_iters"], 'damping': 1e-4}, save_logs=True)
+    adv_w = (inp["adv"] - np.mean(inp["adv"])) / (np.std(inp["adv"]) + 1e-6)
+    out = dict(N=N, n=n, m=m, hidden=np.array(hidden, dtype=np.int64), cg_iters=c["cg_iters"], damping=1e-4, algo=c["algo"],
+               stride=STRIDE, digest=bench.lw_inputs_digest(inp), torch_threads=torch.get_num_threads(), key=key)
+    if c["algo"] == "npg":
+        agent = NPG(None, pol, None, normalized_step_size=0.05, **kw)
+        out["step"] = 0.05
+        g_args = (obs64, act64, adv_w)
+        coef = 1.0
+    else:
+        Td = 200
+        dpaths = [dict(observations=inp["demo_obs"][i * Td:(i + 1) * Td].astype(np.float64),
+                       actions=inp["demo_act"][i * Td:(i + 1) * Td].astype(np.float64)) for i in range(c["demo_rows"] // Td)]
+        agent = DAPG(None, pol, None, demo_paths=dpaths, kl_dist=c["kl_dist"], lam_0=c["lam_0"], lam_1=0.95, **kw)
+        out.update(kl_dist=c["kl_dist"], lam_0=c["lam_0"], lam_1=0.95, demo_rows=c["demo_rows"])
+        all_adv = 1e-2 * np.concatenate([adv_w / (np.std(adv_w) + 1e-8), c["lam_0"] * np.ones(c["demo_rows"])])
+        g_args = (np.concatenate([obs64, inp["demo_obs"].astype(np.float64)]), np.concatenate([act64, inp["demo_act"].astype(np.float64)]), all_adv)
+        coef = all_adv.shape[0] / adv_w.shape[0]
+    agent.logger = DataLog()
+    t0 = time.time()
+    g = coef * agent.flat_vpg(*g_args)
+    print(name, "reference flat_vpg %.1f s" % (time.time() - t0), flush=True)
+    del g_args
+    t0 = time.time()
+    agent.train_from_paths(paths)
+    out["reference_update_seconds"] = time.time() - t0
+    log = agent.logger.log
+    step_ref = pol.get_param_values().astype(np.float64) - theta0.astype(np.float64)
+    out.update(alpha=log['alpha'][-1], kl=log['kl_dist'][-1], surr_improvement=log['surr_improvement'][-1],
+               vpg_sub=np.asarray(g)[::STRIDE].astype(np.float32), vpg_norm=float(np.linalg.norm(np.asarray(g, np.float64))),
+               update_step_sub=step_ref[::STRIDE].astype(np.float32), update_step_norm=float(np.linalg.norm(step_ref)),
+               update_step_probe=float(np.dot(step_ref, np.random.RandomState(PROBE_SEED).randn(theta0.size))))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "reference train_from_paths %.1f s: N %d d %d alpha %r kl %r surr_improvement %r"
+          % (out["reference_update_seconds"], N, theta0.size, out["alpha"], out["kl"], out["surr_improvement"]), flush=True)
+    if os.environ.get("MJX_GOLDEN_NO_F64") == "1":
+        return
+    t0 = time.time()
+    th64 = theta0.astype(np.float64)
+    if c["algo"] == "npg":
+        r64 = O.npg_update(th64, obs64, act64, adv_w, n, m, hidden, cg_iters=c["cg_iters"], damping=1e-4, delta=0.05)
+    else:
+        r64 = O.dapg_update(th64, obs64, act64, adv_w, inp["demo_obs"].astype(np.float64), inp["demo_act"].astype(np.float64), n, m, hidden,
+                            cg_iters=c["cg_iters"], damping=1e-4, kl_dist=c["kl_dist"], lam_0=c["lam_0"], lam_1=0.95, iter_count=0.0)
+    step64 = r64["new_params"] - th64
+    out.update(update_step_f64_sub=step64[::STRIDE], alpha_f64=r64["alpha"], kl_f64=float(r64["kl"]),
+               err_ref_vs_f64_update_step=rel(step_ref, step64), err_ref_vs_f64_vpg=rel(g, r64["vpg"]), oracle_seconds=time.time() - t0)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "fp64 oracle %.0f s: reference vs fp64 step %.2e vpg %.2e" % (out["oracle_seconds"], out["err_ref_vs_f64_update_step"],
+                                                                              out["err_ref_vs_f64_vpg"]), flush=True)
+
+
 def inputnorm_truth(name):
     """fp64 truth for the input_normalization fixture of make_golden.py (npg_inputnorm_32x32: the update runs with
     theta_new == theta_old but an input transform on policy.model only, npg_cg.py:101-107, i.e. the GENERAL Hessian):
@@ -260,6 +334,8 @@ CASES = {
     "dapg_cfg5_wide": lambda: big_case("dapg_cfg5_wide", 39, 28, (512, 512), 1500, 200, 10, "dapg", kl_dist=0.025, demo=(25, 200)),
     "bench_cfg2_1m": lambda: bench_case("bench_cfg2_1m"),
     "bench_ref_1m": lambda: bench_reference_case("bench_ref_1m"),
+    "npg_cfg4_shard": lambda: shard_case("configs3_humanoid_256x256"),
+    "dapg_cfg5_shard": lambda: shard_case("configs4_adroit_512x512"),
 }
 
 if __name__ == "__main__":

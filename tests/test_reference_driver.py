@@ -1,0 +1,263 @@
+"""The reference's OWN driver over this package's agent (north star: "drops into examples/policy_opt_job_script.py").
+
+``mjrl.utils.train_agent.train_agent`` (mjrl/utils/train_agent.py:62-155) and ``mjrl.samplers.core.sample_paths``
+(mjrl/samplers/core.py:99-148, mp.Pool of FORKED workers :189-210, the policy pickled into them :196) are imported UNMODIFIED
+through oracle/ref_loader (sources in the build container, oracle/_ref bytecode on the GPU box) and run
+``NPG(GymEnv(id), MLP, baseline)`` of mjrl_amd the way examples/policy_opt_job_script.py:60-101 does: deep copies of the policy every
+iteration, pickles every save_freq, evaluation rollouts, logs, a second call that resumes from the job folder -- with a worker
+pool (num_cpu = 2) forked from a parent that holds an mjx_ctx, page-locked staging blocks and libmjx's gather threads.  The env
+(tests/_driver_env.py, a NumPy point-mass behind a stand-in gym.make) reports from inside every step which process ran it and
+what that process did with libmjx.
+
+CPU lane: the harness itself (reference agent through the reference driver), and mjrl_amd.samplers' own worker pool.
+"""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from tests import _driver_env as DE  # noqa: E402
+
+SEED, NITER, NTRAJ = 7, 4, 64
+JOB = dict(seed=SEED, gamma=0.95, gae_lambda=0.97, sample_mode='trajectories', num_traj=NTRAJ, save_freq=1, evaluation_rollouts=4)
+
+
+def _need_reference():
+    ge = DE.install_fake_gym()
+    if ge is None:
+        pytest.skip("the reference is neither at /root/reference nor staged under oracle/_ref")
+    return ge
+
+
+# ------------------------------------------------------------------------------------------------------------ CPU lane
+def _policy(seed=2):
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    spec = type("Spec", (), dict(observation_dim=6, action_dim=2, horizon=25))
+    return MLP(spec, hidden_sizes=(32, 32), seed=seed, init_log_std=-0.5)
+
+
+def _same_paths(a, b):
+    assert len(a) == len(b)
+    for p, q in zip(a, b):
+        for k in ("observations", "actions", "rewards"):
+            assert np.array_equal(p[k], q[k]), k
+        assert bool(p["terminated"]) == bool(q["terminated"])
+        assert np.array_equal(p["agent_infos"]["mean"], q["agent_infos"]["mean"])
+
+
+def test_native_sampler_pool_matches_the_serial_sampler():
+    """mjrl_amd.samplers with num_cpu = 2: spawned workers, worker i seeded base_seed + i * paths_per_cpu (core.py:126-133) ==
+    the episodes of the one-process call; ceil split when num_cpu does not divide num_traj (:124); the workers are other processes
+    and never loaded libmjx"""
+    from mjrl_amd import samplers
+    pol = _policy()
+    serial = samplers.sample_paths(8, DE.make_point_mass, pol, base_seed=100, num_cpu=1)
+    pooled = samplers.sample_paths(8, DE.make_point_mass, pol, base_seed=100, num_cpu=2, suppress_print=True)
+    _same_paths(serial, pooled)
+    ev = DE.worker_evidence(pooled)
+    assert len(ev["pids"]) == 2 and os.getpid() not in ev["pids"] and ev["loaded"] == 0, ev
+    assert DE.worker_evidence(serial)["pids"] == [os.getpid()]
+    assert len(samplers.sample_paths(5, DE.make_point_mass, pol, base_seed=3, num_cpu=2, suppress_print=True)) == 6
+    # evaluation mode acts with the mean (core.py:71-72); env objects are accepted like factories
+    ev_paths = samplers.sample_paths(2, DE.PointMassGym(), pol, eval_mode=True, base_seed=5, num_cpu=1)
+    assert np.array_equal(ev_paths[0]["actions"], ev_paths[0]["agent_infos"]["evaluation"])
+    # sample_data_batch (core.py:151-186): rounds of paths_per_call * num_cpu episodes, base_seed += 12345 per round
+    a = samplers.sample_data_batch(120, DE.make_point_mass, pol, base_seed=9, num_cpu=2, paths_per_call=2)
+    b = samplers.sample_data_batch(120, DE.make_point_mass, pol, base_seed=9, num_cpu=1, paths_per_call=4)
+    assert sum(len(p["rewards"]) for p in a) >= 120
+    _same_paths(a, b)
+    with pytest.raises(RuntimeError):
+        samplers.sample_paths(2, "Hopper-v2", pol, base_seed=1)        # an env ID needs mjrl + gym (and, with them, a registered env)
+    samplers.close_pools()
+
+
+class _SlowEnv(DE.PointMassGym):
+    def step(self, a):
+        import time
+        time.sleep(0.2)
+        return super().step(a)
+
+
+def make_slow_env():
+    return _SlowEnv()
+
+
+def test_native_sampler_timeouts_retry_then_fail_loudly():
+    """core.py:189-203: a worker set that does not answer within max_process_time is torn down and the request retried,
+    max_timeouts times; then no rollouts -- an error here, not a None the caller trips over"""
+    from mjrl_amd import samplers
+    with pytest.raises(RuntimeError, match="worker timeouts"):
+        samplers.sample_paths(2, make_slow_env, _policy(), base_seed=1, num_cpu=2, max_process_time=0.5, max_timeouts=2, suppress_print=True)
+    samplers.close_pools()
+
+
+def _reference_job(tmp_path, name, num_cpu, niter=NITER):
+    """the reference's own NPG + MLP + QuadraticBaseline through the reference's train_agent (the yardstick)"""
+    ge = _need_reference()
+    from mjrl.algos.npg_cg import NPG
+    from mjrl.baselines.quadratic_baseline import QuadraticBaseline
+    from mjrl.policies.gaussian_mlp import MLP
+    from mjrl.utils.train_agent import train_agent
+    e = ge.GymEnv(DE.ENV_ID)
+    policy = MLP(e.spec, hidden_sizes=(32, 32), seed=SEED, init_log_std=-0.5)
+    agent = NPG(e, policy, QuadraticBaseline(e.spec), normalized_step_size=0.05, seed=SEED, save_logs=True)
+    train_agent(job_name=str(tmp_path / name), agent=agent, niter=niter, num_cpu=num_cpu, **JOB)
+    return agent
+
+
+def test_reference_driver_harness_on_cpu(tmp_path):
+    """the harness alone: the reference's agent through the reference's driver, 2 forked workers == 1 process"""
+    a2 = _reference_job(tmp_path, "ref2", 2, niter=2)
+    a1 = _reference_job(tmp_path, "ref1", 1, niter=2)
+    assert np.array_equal(a2.policy.get_param_values(), a1.policy.get_param_values())
+    assert os.path.exists(tmp_path / "ref2" / "logs" / "log.csv") and os.path.exists(tmp_path / "ref2" / "iterations" / "policy_1.pickle")
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU lane
+def _our_agent(ge, kind, seed=SEED, evidence=None):
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.baselines.mlp_baseline import MLPBaseline
+    from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+    from mjrl_amd.policies.gaussian_mlp import MLP
+
+    class Recording(NPG):
+        def train_from_paths(self, paths):
+            if evidence is not None:
+                evidence.append(DE.worker_evidence(paths))
+            return super().train_from_paths(paths)
+    e = ge.GymEnv(DE.ENV_ID)                                           # policy_opt_job_script.py:60
+    policy = MLP(e.spec, hidden_sizes=(32, 32), seed=SEED, init_log_std=-0.5)
+    baseline = (MLPBaseline(e.spec, reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3) if kind == "mlp"
+                else QuadraticBaseline(e.spec))
+    return Recording(e, policy, baseline, normalized_step_size=0.05, seed=seed, save_logs=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["quadratic", "mlp"])
+def test_reference_train_agent_and_fork_pool_drive_our_agent(kind, tmp_path):
+    ge = _need_reference()
+    from mjrl.utils.train_agent import train_agent
+    from mjrl_amd._lib import load
+    import ctypes
+    # ---- (A) 4 iterations, 2 forked workers, checkpoints every iteration, evaluation rollouts
+    ev = []
+    agent = _our_agent(ge, kind, evidence=ev)
+    agent.engine                                                       # the parent holds an mjx_ctx BEFORE the first fork
+    st = (ctypes.c_int64 * 2)()
+    load().mjx_process_state(st)
+    assert st[0] > 0 and st[1] == 0
+    train_agent(job_name=str(tmp_path / "A"), agent=agent, niter=NITER, num_cpu=2, **JOB)
+    final = agent.policy.get_param_values().copy()
+    assert np.all(np.isfinite(final)) and len(ev) == NITER
+    for e in ev:
+        # every env step of every iteration ran in one of two OTHER processes, forked from this one after it had created device
+        # state (flag 1), and none of them made a single device-touching libmjx call
+        assert len(e["pids"]) == 2 and os.getpid() not in e["pids"], e
+        assert e["forked"] == 1 and e["device_calls"] == 0 and e["loaded"] == 1, e
+    jobA = tmp_path / "A"
+    for f in ("logs/log.csv", "logs/log.pickle", "logs/stoc_pol_mean.png", "results.txt", "iterations/best_policy.pickle",
+              "iterations/policy_3.pickle", "iterations/baseline_3.pickle"):
+        assert os.path.exists(jobA / f), f
+    with open(jobA / "iterations" / "policy_3.pickle", "rb") as fp:
+        assert np.array_equal(pickle.load(fp).get_param_values(), final)
+    with open(jobA / "iterations" / "best_policy.pickle", "rb") as fp:
+        best = pickle.load(fp)
+    assert best.get_action(np.zeros(6))[0].shape == (2,)
+    # ---- the reference's own agent through the same driver: same log keys, same training curve
+    ref = _reference_job(tmp_path, "R", 2)
+    ours_log, ref_log = agent.logger.log, ref.logger.log
+    assert set(ref_log) <= set(ours_log), sorted(set(ref_log) - set(ours_log))
+    assert all(len(ours_log[k]) == NITER for k in ref_log)
+    if kind == "quadratic":
+        th_ref = ref.policy.get_param_values().astype(np.float64)
+        th0 = _our_agent(ge, kind).policy.get_param_values().astype(np.float64)
+        rel = np.linalg.norm(final - th_ref) / np.linalg.norm(th_ref - th0)
+        curve = np.max(np.abs(np.array(ours_log["stoc_pol_mean"]) - np.array(ref_log["stoc_pol_mean"])))
+        print("4 iterations under the reference driver: |theta - theta_ref| / |theta_ref - theta_0| = %.2e, curve diff %.2e" % (rel, curve))
+        assert rel < 2e-4, rel                                         # 4 compounded NPG steps + refits, each at the 1e-5 bar
+        assert curve < 1e-4 * max(1.0, np.max(np.abs(ref_log["stoc_pol_mean"])))
+        assert abs(ours_log["eval_score"][-1] - ref_log["eval_score"][-1]) < 1e-3 * abs(ref_log["eval_score"][-1])
+    # ---- (B) the same job in one process: per-episode seeding (core.py:52-57) makes the batches identical
+    if kind == "quadratic":                                            # (the MLP baseline's minibatch order follows the PARENT's RNG,
+        agent_b = _our_agent(ge, kind)                                 #  which in-process sampling re-seeds -- in the reference too)
+        train_agent(job_name=str(tmp_path / "B"), agent=agent_b, niter=NITER, num_cpu=1, **JOB)
+        assert np.array_equal(agent_b.policy.get_param_values(), final)
+    # ---- (C) 2 iterations, then a second call with a FRESH agent that resumes from the job folder (train_agent.py:15-60,88-93)
+    agent_c = _our_agent(ge, kind)
+    train_agent(job_name=str(tmp_path / "C"), agent=agent_c, niter=2, num_cpu=2, **JOB)
+    fresh = _our_agent(ge, kind, seed=SEED + 2 * NTRAJ)               # (the reference does not checkpoint agent.seed: batch_reinforce.py:91)
+    fresh.policy.set_param_values(np.zeros_like(final))                # whatever it held is replaced by the pickles
+    train_agent(job_name=str(tmp_path / "C"), agent=fresh, niter=NITER, num_cpu=2, **JOB)
+    assert fresh.logger.max_len == NITER
+    if kind == "quadratic":
+        assert np.array_equal(fresh.policy.get_param_values(), final)  # bit-identical continuation
+    else:
+        assert np.all(np.isfinite(fresh.policy.get_param_values()))
+    for a in (agent, agent_c, fresh):
+        a.engine.close()
+
+
+@pytest.mark.gpu
+def test_native_sampler_pool_under_a_live_context():
+    """mjrl_amd.samplers' spawned pool from a training process that holds device state: train_step(num_cpu = 2) == train_step(num_cpu = 1)"""
+    from mjrl_amd import samplers
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+    finals = []
+    for num_cpu in (2, 1):
+        ev = []
+
+        class Recording(NPG):
+            def train_from_paths(self, paths):
+                ev.append(DE.worker_evidence(paths))
+                return super().train_from_paths(paths)
+        pol = _policy(seed=4)
+        spec = type("Spec", (), dict(observation_dim=6, action_dim=2, horizon=25))
+        agent = Recording(DE.make_point_mass, pol, QuadraticBaseline(spec), normalized_step_size=0.05, seed=11, save_logs=True)
+        agent.engine
+        for _ in range(3):
+            agent.train_step(N=32, sample_mode='trajectories', gamma=0.95, gae_lambda=0.97, num_cpu=num_cpu)
+        if num_cpu == 2:
+            assert all(len(e["pids"]) == 2 and os.getpid() not in e["pids"] and e["loaded"] == 0 for e in ev), ev
+        finals.append(pol.get_param_values().copy())
+        agent.engine.close()
+    assert np.array_equal(finals[0], finals[1])
+    samplers.close_pools()
+
+
+@pytest.mark.gpu
+def test_a_forked_child_is_refused_device_work():
+    """include/mjx.h mjx_process_state: after a fork from a process that holds device state, mjx_create / mjx_malloc fail with
+    MJX_ERR_STATE (a message, not a hang inside the runtime) and mjx_device_count reports no device"""
+    import ctypes
+    from mjrl_amd._lib import load
+    from mjrl_amd.engine import UpdateEngine
+    eng = UpdateEngine(6, 2, (32, 32))
+    lib = load()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:                                                       # child: report through the pipe, leave without cleanup
+        try:
+            st = (ctypes.c_int64 * 2)()
+            lib.mjx_process_state(st)
+            ctx, p = ctypes.c_void_p(), ctypes.c_void_p()
+            hid = (ctypes.c_int * 2)(32, 32)
+            rc_create = lib.mjx_create(ctypes.byref(ctx), 0, 6, 2, hid, 2)
+            msg = lib.mjx_last_error()
+            rc_malloc = lib.mjx_malloc(ctypes.byref(p), 1024)
+            os.write(w, repr((int(st[0]), int(st[1]), rc_create, rc_malloc, lib.mjx_device_count(), b"forked" in msg)).encode())
+        finally:
+            os._exit(0)
+    os.close(w)
+    os.waitpid(pid, 0)
+    got = eval(os.read(r, 4096).decode())
+    assert got == (0, 1, -2, -2, 0, True), got
+    st = (ctypes.c_int64 * 2)()
+    lib.mjx_process_state(st)
+    assert st[0] > 0 and st[1] == 0                                   # the parent is unaffected
+    eng.close()
