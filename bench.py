@@ -156,7 +156,7 @@ def cpu_baseline(theta0, sample_traj):
         cal[k] = one_update(cal_paths)[0]
     best = min(cal, key=cal.get)
     torch.set_num_threads(best)
-    n_traj = N_TRAJ if sample_traj <= 0 or sample_traj >= N_TRAJ or sample_traj == 200 else sample_traj   # default: the whole batch
+    n_traj = N_TRAJ if sample_traj <= 0 or sample_traj >= N_TRAJ else sample_traj          # 0 (the default): the whole batch
     dt, theta_ref = one_update(paths_of(n_traj))
     torch.set_num_threads(default_threads)
     n = n_traj * T
@@ -182,6 +182,7 @@ def cpu_baseline_port(theta0, sample_traj):
     against the reference's wall time and step: tests/golden/cpu_port_vs_reference.json) on a bounded slice."""
     import torch
     from oracle import torch_port
+    sample_traj = 200 if sample_traj <= 0 else sample_traj       # (the port is a stand-in: a 200-trajectory slice unless told otherwise)
     obs, act, adv = synth_shard(0, N_TRAJ // sample_traj)        # first `sample_traj` trajectories
     obs, act = obs.astype(np.float64), act.astype(np.float64)    # the reference holds fp64 rollouts
     adv = (adv - adv.mean()) / (adv.std() + 1e-6)
@@ -266,24 +267,21 @@ def secondary_measurements(eng, theta0, theta0_dev, ref=None):
             "fixture": "tests/golden/bench_ref_1m.npz",
             "what": "the unmodified reference's TRPO.train_from_paths (mjrl/algos/trpo.py:56-146) on this batch",
             "failed": bool(max(drift.values()) > 1e-5 or not same_trials)}
-    # ---- layer-wise FVP at the shard sizes of the 8-GPU configs
+    # ---- layer-wise FVP at the shard sizes of the 8-GPU configs, on seeded host rows (lw_shard_inputs) the UNMODIFIED reference
+    # was run on as well (tests/golden/{npg_cfg4_shard,dapg_cfg5_shard}.npz, make_golden_big.py): the whole update of the shard
+    # is checked against it at the north-star's 1e-5 like the primary metric
     lw = {}
-    for name, n, m, hid, N in (("configs3_humanoid_256x256", 376, 17, (256, 256), 500000), ("configs4_adroit_512x512", 39, 28, (512, 512), 1000000)):
-        gen = torch.Generator(device="cuda"); gen.manual_seed(0)
-        e = UpdateEngine(n, m, hid)
-        rng = np.random.RandomState(1)
+    for name, cfg in LW_SHARDS.items():
+        n, m, hid = cfg["n"], cfg["m"], cfg["hidden"]
+        inp = lw_shard_inputs(name)
+        N = inp["obs"].shape[0]
+        th = inp["theta"]
+        adv_w = (inp["adv"] - inp["adv"].mean()) / (inp["adv"].std() + 1e-6)          # batch_reinforce.py:185 / dapg.py:60, fp64 on the host
         sizes = (n,) + tuple(hid) + (m,)
-        flat = []
-        for i in range(len(sizes) - 1):
-            k = 1.0 / np.sqrt(sizes[i])
-            flat += [rng.uniform(-k, k, (sizes[i + 1], sizes[i])).ravel() * (1e-2 if i == len(sizes) - 2 else 1.0), rng.uniform(-k, k, sizes[i + 1])]
-        flat.append(np.full(m, -0.5))
-        th = np.concatenate(flat).astype(np.float32)
-        th = (th + 0.02 * np.random.RandomState(1).randn(th.size)).astype(np.float32)
+        e = UpdateEngine(n, m, hid)
         ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
         e.set_policy(th, th, ident, ident)
-        e.set_batch(torch.randn((N, n), generator=gen, device="cuda"), torch.randn((N, m), generator=gen, device="cuda"),
-                    torch.randn((N,), generator=gen, device="cuda"))
+        e.set_batch(inp["obs"], inp["act"], adv_w)
         grad = e.surr_vpg()[0].clone()
         e.fvp(grad)
         torch.cuda.synchronize()
@@ -297,8 +295,11 @@ def secondary_measurements(eng, theta0, theta0_dev, ref=None):
         flop = 2 * (4 * P - 2 * n * hid[0]) * N
         ms = prof[0] / prof[1]
         # one whole NPG update of this shard (K1, the config's CG iterations, step, K3) through the one-call entry point
-        cg_iters = 25 if hid[0] == 256 else 10
-        e.npg_update(cg_iters, 1e-4, 0.05, -3.0)
+        cg_iters = cfg["cg_iters"]
+        sa, kl = e.npg_update(cg_iters, 1e-4, 0.05, -3.0)
+        late = e.deferred()
+        got = dict(alpha=late["alpha"], kl=kl, surr_improvement=sa - late["surr_before"],
+                   step=e.theta_new.cpu().numpy().astype(np.float64) - th)
         e.set_policy(th, th, ident, ident)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -308,30 +309,52 @@ def secondary_measurements(eng, theta0, theta0_dev, ref=None):
         lw[name] = {"rows": N, "fvp_ms": ms, "TFLOPs": flop / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
                     "flop_per_fvp": flop, "kernels": "k_gemm_p (persistent tangent / delta products, csrc/lw_gemm_p.h) + k_gemm<128,256> / <128,128> weight gradients + k_lw_head (one-pass output layer, csrc/lw_head.h)",
                     "timed": "4 products, HIP events around the whole chain of one product",
-                    "npg_update_ms": upd_ms, "cg_iters": cg_iters}
-        if hid[0] == 512:
+                    "npg_update_ms": upd_ms, "cg_iters": cg_iters, "inputs": "seeded host rows (bench.lw_shard_inputs, PCG64 seed %d)" % cfg["seed"]}
+        if cfg["algo"] == "dapg":
             # ... and the algorithm configs[4] names: one DAPG update (mjrl/algos/dapg.py:92-121) of the same shard with 25 x 200
             # demonstration steps appended, through the one-call entry point mjx_dapg_update (K1 over [on-policy ; demos],
             # gradient x N_all / N_on, Fisher / surrogate / KL on the on-policy prefix, 10 CG iterations, step, K3)
-            Nd = 5000
-            obs_all = torch.cat([e.obs, torch.randn((Nd, n), generator=gen, device="cuda")])
-            act_all = torch.cat([e.act, torch.randn((Nd, m), generator=gen, device="cuda")])
-            adv_on = e.adv.clone()
-            all_adv = 1e-2 * torch.cat([adv_on / (adv_on.std(unbiased=False) + 1e-8), 1e-2 * torch.ones(Nd, device="cuda")])
+            Nd = cfg["demo_rows"]
+            obs_all = torch.cat([e.obs, torch.from_numpy(inp["demo_obs"]).to(e.device)])
+            act_all = torch.cat([e.act, torch.from_numpy(inp["demo_act"]).to(e.device)])
+            all_adv = 1e-2 * np.concatenate([adv_w / (np.std(adv_w) + 1e-8), cfg["lam_0"] * np.ones(Nd)])          # dapg.py:65-70, iteration 0
             dapg_ms = []
             for rep in range(2):
                 e.set_policy(th, th, ident, ident)
                 e.set_batch(obs_all, act_all, all_adv)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                res = e.dapg_update(cg_iters, 1e-4, 2.0 * 0.025, -3.0, N, adv_on, N_on_global=N)
+                res = e.dapg_update(cg_iters, 1e-4, 2.0 * cfg["kl_dist"], -3.0, N, adv_w, N_on_global=N)
                 torch.cuda.synchronize()
                 dapg_ms.append(1e3 * (time.perf_counter() - t0))
+                if rep == 0:
+                    late = e.deferred()
+                    got = dict(alpha=late["alpha"], kl=res[1], surr_improvement=res[0] - late["surr_before"],
+                               step=e.theta_new.cpu().numpy().astype(np.float64) - th)
             assert res is not None and np.isfinite(res[1]) and res[1] > 0
             lw[name].update(dapg_update_ms=dapg_ms[-1], dapg_kl=res[1], dapg_demo_rows=Nd,
                             dapg="one mjx_dapg_update call: [1M on-policy ; 5 000 demonstration] rows, kl_dist 0.025")
+        fx = os.path.join(ROOT, "tests", "golden", cfg["fixture"] + ".npz")
+        if os.path.exists(fx):
+            g = np.load(fx)
+            S = int(g["stride"])
+            same_rows = bool(np.allclose(lw_inputs_digest(inp), g["digest"], rtol=1e-12, atol=1e-9))
+            rs = g["update_step_sub"].astype(np.float64)
+            drift = {"alpha": abs(got["alpha"] - float(g["alpha"])) / float(g["alpha"]),
+                     "kl": abs(got["kl"] - float(g["kl"])) / float(g["kl"]),
+                     "surr_improvement": abs(got["surr_improvement"] - float(g["surr_improvement"])) / abs(float(g["surr_improvement"])),
+                     "step_rel_l2": float(np.linalg.norm(got["step"][::S] - rs) / np.linalg.norm(rs))}
+            chk = {"rel_error": drift, "bar": 1e-5, "fixture": "tests/golden/%s.npz" % cfg["fixture"], "same_rows_as_the_fixture": same_rows,
+                   "what": "the unmodified reference's %s.train_from_paths on these %d rows (%.0f s of CPU; every %d-th entry of the step)"
+                           % ("DAPG" if cfg["algo"] == "dapg" else "NPG", N, float(g["reference_update_seconds"]), S),
+                   # the scalars are fp32 sums over 0.5-1M samples on both sides: the step DIRECTION carries the north-star's bar,
+                   # alpha with it; KL / surrogate improvement are reported (and asserted at 1e-4 in the tests)
+                   "failed": bool(not same_rows or drift["step_rel_l2"] > 1e-5 or drift["alpha"] > 1e-5)}
+            if "err_ref_vs_f64_update_step" in g.files:
+                chk["reference_vs_fp64_oracle_step_rel_l2"] = float(g["err_ref_vs_f64_update_step"])
+            lw[name]["check_vs_reference"] = chk
         e.close()
-        del e
+        del e, inp
         torch.cuda.empty_cache()
     out["roofline_lw"] = lw
     out.update(user_level_measurements())
@@ -469,9 +492,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fvp-event-stride", type=int, default=11,
                     help="bracket every k-th Fisher-vector-product launch with HIP events (k coprime to the CG iteration count: every CG position is sampled equally); 0: none")
-    ap.add_argument("--cpu-sample-traj", type=int, default=200,
-                    help="cpu_baseline: with the reference staged (oracle/_ref) the default times it on the whole 1M batch (~20 s); "
-                         "any other value: that many trajectories, scaled linearly.  Without it: the slice the torch port runs")
+    ap.add_argument("--cpu-sample-traj", type=int, default=0,
+                    help="cpu_baseline: 0 (default) = the whole 1M-timestep batch through the staged reference (oracle/_ref, ~20 s) -- "
+                         "or, without it, a 200-trajectory slice through the torch port; k > 0: exactly k trajectories, scaled linearly")
     ap.add_argument("--repeats", type=int, default=3,
                     help="the timed region (barrier + synchronize, EXACTLY --steps updates, barrier + synchronize) is run this many "
                          "times; `value` is the median repeat, all repeats are reported")
@@ -679,6 +702,11 @@ def main():
                 print(json.dumps({"error": "TRPO update differs from the reference beyond 1e-5",
                                   "check": out["secondary"]["trpo_configs2"]["check_vs_reference"]}), file=sys.stderr, flush=True)
                 failed = True
+            for lw_name, lw_res in out["secondary"]["roofline_lw"].items():
+                if lw_res.get("check_vs_reference", {}).get("failed"):
+                    print(json.dumps({"error": "%s: the shard's update differs from the reference beyond 1e-5" % lw_name,
+                                      "check": lw_res["check_vs_reference"]}), file=sys.stderr, flush=True)
+                    failed = True
         if world == 1 and not args.no_cpu_baseline and args.rehearse_world <= 1:
             out["cpu_baseline"] = cpu_baseline(theta0, args.cpu_sample_traj)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -87,9 +87,13 @@ class BatchREINFORCE:
             raise ValueError("sample_mode must be either 'trajectories' or 'samples'")
         t0 = timer.time()
         # One process per GPU (torch.distributed initialised): N is the size of the WHOLE batch and every rank samples its
-        # contiguous share of it with the seeds a single process would have used for those episodes (base_seed + episode index,
-        # samplers/core.py:44-57) -- the ranks' path lists, in rank order, are the batch of the one-process run.  Everything
-        # after sampling sums over the ranks (returns statistics, advantage whitening, the update, ONE baseline fit).
+        # contiguous share of it.  In sample_mode 'trajectories' the share is a range of EPISODES seeded as a single process
+        # would have seeded them (base_seed + episode index, samplers/core.py:44-57): with a sampler that returns exactly the
+        # episodes asked for (num_cpu dividing the share -- core.py:124 rounds each worker's count UP otherwise) the ranks' path
+        # lists, in rank order, ARE the batch of the one-process run.  In 'samples' mode the share is a number of TIMESTEPS and
+        # the seeds are offsets into nothing a single process would have drawn: the ranks still hold disjoint, reproducible
+        # batches of the right total size, but not the one-process batch.  Everything after sampling sums over
+        # the ranks (returns statistics, advantage whitening, the update, ONE baseline fit).
         n_mine, seed_mine = N, self.seed
         d = _dist()
         if d is not None:

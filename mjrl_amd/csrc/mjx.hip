@@ -119,6 +119,7 @@ struct mjx_ctx {
     char* buf = nullptr; char* map[16] = {nullptr};
     size_t slot_bytes = 0; uint32_t seq = 0;
     unsigned long long timeout_ticks = 500000000ull;   // 100 MHz ticks a consumer waits for a peer (MJX_PEER_TIMEOUT_MS; default 5 s)
+    int fault = 0;                                     // MJX_PEER_FAULT (tests): 1 = "slot" (vectors land in the wrong slot at the peers), 2 = "flag" (arrival flags never raised)
   } peer;
   unsigned* ticket = nullptr;                      // workgroup ticket of the producer kernels (ordinary device memory, zero between launches)
   mjx::LayerwiseWS lw;             // layer-wise path workspace
@@ -770,6 +771,10 @@ PeerPush peer_push(const mjx_ctx* c, int par, uint32_t seq) {
     pp.dst[q] = peer_slot(c, q, par, c->peer.rank);
     // the flag rank q polls for this rank; loop-back rehearsal (every peer is the own buffer): the flag this rank polls for "peer" q
     pp.flag[q] = c->peer.loopback ? peer_flags(c, c->peer.rank) + q : peer_flags(c, q) + c->peer.rank;
+    // fault injection (MJX_PEER_FAULT, tests/test_gpu_multirank.py): what a mis-mapped buffer or a lost flag store would look like
+    // to the known-answer sum the host runs before it trusts a transport (engine._transport_self_test)
+    if (q != c->peer.rank && c->peer.fault == 1) pp.dst[q] = peer_slot(c, q, par, (c->peer.rank + 1) % c->peer.world);
+    if (q != c->peer.rank && c->peer.fault == 2) pp.flag[q] = peer_flags(c, c->peer.rank) + 40;     // an unused word of the OWN flag block
   }
   return pp;
 }
@@ -922,6 +927,10 @@ int mjx_peer_export(mjx_ctx* c, int rank, int world, char* handle_out) {
   static_assert(sizeof(hipIpcMemHandle_t) == MJX_PEER_HANDLE_BYTES, "handle size");
   memcpy(handle_out, &h, sizeof h);
   c->peer.buf = (char*)p; c->peer.slot_bytes = slot; c->peer.rank = rank; c->peer.world = world; c->peer.seq = 0;
+  if (const char* f = getenv("MJX_PEER_FAULT")) {
+    const char* only = getenv("MJX_PEER_FAULT_RANK");               // (default: every rank misbehaves)
+    if (!only || atoi(only) == rank) c->peer.fault = !strcmp(f, "slot") ? 1 : !strcmp(f, "flag") ? 2 : 0;
+  }
   if (const char* ms = getenv("MJX_PEER_TIMEOUT_MS")) {             // how long a consumer kernel waits for a peer's vector
     const double v = atof(ms);
     if (v > 0.0) c->peer.timeout_ticks = (unsigned long long)(v * 1e5);

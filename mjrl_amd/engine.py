@@ -391,13 +391,20 @@ class UpdateEngine:
                 order = ["rccl", "hook"]         # (a communicator libmjx cannot create itself: the same loops over torch's own RCCL group)
             else:
                 order = ["hook"]
+            if os.environ.get("MJX_TRANSPORT_ORDER"):     # (tests: walk a given chain whatever the process group is)
+                order = [k for k in os.environ["MJX_TRANSPORT_ORDER"].split(",") if k in ("rccl", "peer", "hook")]
             # every rank walks the same list and the ranks agree after each attempt (all or none): RCCL inside libmjx and the
             # one-call loops on some ranks, torch.distributed calls on others would issue different collectives and hang
             for kind in order:
                 mine = self._attach_transport(kind, d)
                 if self._all_ranks(d, mine):
-                    ok, self.comm_kind = True, kind
-                    break
+                    # attached everywhere -- now a known-answer rank sum through it, before any update trusts it: a transport
+                    # that delivers finite but wrong sums (a mis-mapped peer buffer, a flag that overtakes its data) would
+                    # otherwise be silent
+                    self.comm_kind = kind
+                    if self._all_ranks(d, self._transport_self_test(d, kind)):
+                        ok = True
+                        break
                 self._detach_transport()
         self._comm_state = ok
         return ok
@@ -407,9 +414,19 @@ class UpdateEngine:
             if kind == "peer":
                 self.backend.peer_connect_all(d)
             elif kind == "rccl":
-                box = [self.backend.comm_unique_id() if d.get_rank() == 0 else None]
+                # rank 0 makes the communicator id.  If it cannot (librccl missing, MJX_RCCL_DISABLE=1) it still takes part in
+                # the broadcast -- with None -- so that every rank leaves this attempt through the same collectives (ADVICE r04:
+                # raising before the broadcast left the others blocked in it while rank 0 went on to the agreement round)
+                box, err = [None], None
+                if d.get_rank() == 0:
+                    try:
+                        box = [self.backend.comm_unique_id()]
+                    except Exception as e:
+                        err = e
                 if d.get_world_size() > 1:
                     d.broadcast_object_list(box, src=0)
+                if box[0] is None:
+                    raise err if err is not None else _lib.MjxError("rank 0 could not create an RCCL communicator id")
                 with _stdout_to_stderr():         # RCCL prints a version banner to stdout when a communicator is created
                     self.backend.comm_init(d.get_rank(), d.get_world_size(), box[0])
             else:                                # same C loops, transport hooked to dist.all_reduce (a host synchronisation per sum)
@@ -419,6 +436,39 @@ class UpdateEngine:
             import warnings
             warnings.warn("mjrl_amd: rank sums inside libmjx over '%s' unavailable (%s)" % (kind, e))
             return False
+
+    def _transport_self_test(self, d, kind):
+        """One known-answer rank sum of d floats + 4 doubles through the freshly attached transport, twice (the peer exchange
+        alternates between two slot sets): rank r contributes (r + 1) x pattern, every term and every partial sum exactly
+        representable, so the result must equal the closed form BIT FOR BIT whatever the order; then the ranks compare a
+        digest of what they received through the side channel (torch.distributed).  -> this rank's verdict."""
+        W, r = d.get_world_size(), d.get_rank()
+        if W <= 1 or os.environ.get("MJX_TRANSPORT_SELF_TEST", "1") == "0":
+            return True
+        torch = self.torch
+        try:
+            base = ((torch.arange(self.d, dtype=torch.float64, device=self.device) % 251) - 125.0) / 8.0
+            tri = W * (W + 1) / 2.0
+            ok, digest = True, []
+            for rep in range(2):
+                v = ((r + 1) * (rep + 1) * base).to(torch.float32)
+                s = torch.tensor([r + 1.0, (r + 1.0) ** 2, -0.5 * (r + 1), 1.0], dtype=torch.float64, device=self.device)
+                self.backend.allreduce(v)
+                self.backend.allreduce(s)
+                want_s = torch.tensor([tri, W * (W + 1) * (2 * W + 1) / 6.0, -0.5 * tri, float(W)], dtype=torch.float64, device=self.device)
+                ok = ok and bool(torch.equal(v, (tri * (rep + 1) * base).to(torch.float32))) and bool(torch.equal(s, want_s))
+                digest.append(v.cpu().numpy().tobytes() + s.cpu().numpy().tobytes())
+            import hashlib
+            mine = hashlib.sha1(b"".join(digest)).hexdigest()
+        except Exception as e:                   # pragma: no cover - a transport that errors out is simply not trusted
+            ok, mine = False, "error: %s" % e
+        every = [None] * W
+        d.all_gather_object(every, mine)
+        ok = ok and all(h == every[0] for h in every)
+        if not ok:
+            import warnings
+            warnings.warn("mjrl_amd: the rank-sum transport '%s' failed its known-answer test on rank %d; trying the next one" % (kind, r))
+        return ok
 
     def _all_ranks(self, d, flag):
         if d.get_world_size() <= 1:
@@ -592,16 +642,24 @@ class UpdateEngine:
         call-by-call line searches, trpo.py:107-120 / batch_reinforce.py:153-160 -- raises for a timed-out exchange only and
         otherwise hands the values on as they are, like the reference's `kl < kl_dist` on a NaN)."""
         if not np.all(np.isfinite(s[list(fields)])):
-            timeouts = self.backend.peer_timeouts() if (self.comm_kind == "peer" and hasattr(self.backend, "peer_timeouts")) else 0
-            if timeouts:
-                self._comm_state, self.comm_kind = False, None       # the ranks' exchange sequences are out of step from here on
+            peer = self.comm_kind == "peer" and hasattr(self.backend, "peer_timeouts")
+            timeouts = self.backend.peer_timeouts() if peer else 0
+            if timeouts or (peer and not timeouts_only):
+                # a rank whose wait timed out poisons its sums with NaN, and the poison reaches every other rank through the very
+                # next exchange: all live ranks arrive here at the same update -- the ones that waited in vain with `timeouts`, the
+                # others without -- and ALL of them drop the transport (their exchange sequences are out of step from here on)
+                self._comm_state, self.comm_kind = False, None
                 try:
                     check(self.lib.mjx_comm_destroy(self.ctx))
                 except Exception:                    # pragma: no cover
                     pass
-                raise _lib.MjxError("peer exchange: %d wait(s) for another rank's vector timed out (MJX_PEER_TIMEOUT_MS, default 5000); "
-                                    "the update is invalid and the transport was torn down" % timeouts)
-            if not timeouts_only:
+                if timeouts:
+                    raise _lib.MjxError("peer exchange: %d wait(s) for another rank's vector timed out (MJX_PEER_TIMEOUT_MS, default 5000); "
+                                        "the update is invalid and the transport was torn down" % timeouts)
+                raise _lib.MjxError("non-finite update results under the peer exchange (%s): another rank's wait timed out and its NaN "
+                                    "arrived through the rank sums, or the update itself diverged; the transport was torn down" % (s[:10],))
+            if not timeouts_only and os.environ.get("MJX_ALLOW_NONFINITE") != "1":
+                # (the reference carries NaN into set_param_values without a word; MJX_ALLOW_NONFINITE=1 restores that -- INTEGRATION.md)
                 raise _lib.MjxError("the policy update produced non-finite results (surrogate / KL / g.x / step length: %s)" % (s[:10],))
         return s
 

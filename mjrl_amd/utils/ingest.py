@@ -549,6 +549,22 @@ _DEFERRED = []                # entries handed out by stage_shared(defer=True) w
 _DEFERRED_LOCK = threading.Lock()
 
 
+def _retire_deferred(match=None):
+    """take deferred hand-outs off the list without ordering any stream after them (their consumer will never come: the batch
+    is being replaced or dropped) -- the native staging job is joined so that nothing still writes into blocks about to be reused.
+    match: only entries for which match(ent) holds (None: all).  (entries nobody settled kept a whole batch alive.)"""
+    with _DEFERRED_LOCK:
+        gone = [e for e in _DEFERRED if match is None or match(e)]
+        _DEFERRED[:] = [e for e in _DEFERRED if not (match is None or match(e))]
+    for e in gone:
+        st = e.get("active")
+        if st is not None and getattr(st, "on_gpu", False):
+            try:
+                st.join()
+            except Exception:                     # pragma: no cover
+                pass
+
+
 def settle(backend):
     """order the caller's current stream after every block that stage_shared(defer=True) handed out: joins the native staging
     jobs (their copies are then queued) and makes the stream wait for the stagers' copy streams.  MUST run before the first
@@ -605,7 +621,9 @@ def stage_shared(backend, paths, keys, raw=None, defer=False):
                 new = dict(stager=ent.get("stager") if ent else None, stager32=ent.get("stager32") if ent else None, f32=f32,
                            raw=st.raw(k), paths=paths, arrays=arrays, probes=_probes(arrays), ready=ready)
                 new[skey] = new["active"] = st
-                ent = new
+                old_ent, ent = ent, new
+                if old_ent is not None:
+                    _retire_deferred(lambda e: e is old_ent)        # a hand-out of the batch this one replaces: nobody will settle it
                 with _SHARED_LOCK:
                     reg[k] = ent
             if defer:
@@ -719,6 +737,7 @@ def derived(backend, paths, anchor_key, name, build):
 def drop_shared_batch():
     """forget WHICH batch is staged (the stagers and their page-locked blocks stay): the next stage_shared uploads
     again whatever it is given, and the host trajectories of the finished iteration are released."""
+    _retire_deferred()
     with _SHARED_LOCK:
         for reg in _SHARED.values():
             for ent in reg.values():

@@ -92,11 +92,64 @@ def compute_returns(paths, gamma):
     # (r03 staged them before the rewards: with a Python helper thread per block that was 2-3 ms better; with native jobs the
     # rewards' copies then sit behind 2.6 ms of observation transfers in the DMA queue.)
     off = _offsets(paths)
+    if np.ndim(paths[0]["rewards"]) == 2:
+        return _returns_by_column(h, paths, off, gamma)
     r = _rewards_block(h, paths)
     ingest.prefetch(h, paths, ("observations", "actions"))
     y = h.torch.empty_like(r)
     check(h.lib.mjx_discount_scan(ptr(r), ptr(_offsets_dev(h, paths, off)), len(paths), float(gamma), ptr(y), _stream(h)))
     ingest.publish(h, paths, "returns", y, _hand_out(h, paths, "returns", y, off))
+
+
+# ---- vector-valued rewards / baselines (process_samples.py:26-27: b.ndim == 2).  The reference's expressions are row-wise array
+# arithmetic, so K reward / value components are K independent scans: the same kernels, column by column (a rare path: one small
+# upload, one launch and one read-back per column; nothing is registered for the rest of the iteration).
+def _dev_offsets_plain(h, off):
+    return h.torch.from_numpy(off).to(h.device)
+
+
+def _column_blocks(h, paths, key):
+    """-> (N, K) host block of paths[.][key] (1-D arrays count as K = 1)"""
+    return np.concatenate([np.asarray(p[key], np.float64).reshape(len(p["rewards"]), -1) for p in paths])
+
+
+def _returns_by_column(h, paths, off, gamma):
+    R = _column_blocks(h, paths, "rewards")
+    offd = _dev_offsets_plain(h, off)
+    out = np.empty_like(R)
+    for k in range(R.shape[1]):
+        x = ingest.upload(h, np.ascontiguousarray(R[:, k]))
+        y = h.torch.empty_like(x)
+        check(h.lib.mjx_discount_scan(ptr(x), ptr(offd), len(paths), float(gamma), ptr(y), _stream(h)))
+        out[:, k] = y.cpu().numpy()
+    for i, p in enumerate(paths):
+        p["returns"] = out[off[i]:off[i + 1]]
+
+
+def _advantages_by_column(h, paths, B, off, gamma, gae_lambda, use_gae, normalize):
+    """B: (N, K) baseline values.  GAE: td = rewards + gamma b1[1:] - b1[:-1] with NumPy's broadcasting of `rewards` against the
+    (T, K) block (process_samples.py:26-29: (T, K) or (T, 1) rewards; a 1-D reward vector only broadcasts when T == K, as there);
+    otherwise returns - baseline (:10-13)."""
+    K = B.shape[1]
+    X = _column_blocks(h, paths, "rewards" if use_gae else "returns")
+    if X.shape[1] not in (1, K) or (X.shape[1] == 1 and K > 1 and np.ndim(paths[0]["rewards" if use_gae else "returns"]) == 1):
+        raise ValueError("operands could not be broadcast together: %s of shape (T%s) against a (T, %d) baseline"
+                         % ("rewards" if use_gae else "returns", "" if X.shape[1] == 1 else ", %d" % X.shape[1], K))
+    offd = _dev_offsets_plain(h, off)
+    term = h.torch.from_numpy(np.fromiter((1 if p.get("terminated", False) else 0 for p in paths), dtype=np.uint8, count=len(paths))).to(h.device)
+    A = np.empty_like(B)
+    lam = float(gae_lambda) if use_gae else -1.0
+    for k in range(K):
+        x = ingest.upload(h, np.ascontiguousarray(X[:, min(k, X.shape[1] - 1)]))
+        b = ingest.upload(h, np.ascontiguousarray(B[:, k]))
+        a = h.torch.empty_like(x)
+        check(h.lib.mjx_gae(ptr(x), ptr(b), ptr(offd), ptr(term), len(paths), float(gamma), lam, ptr(a), _stream(h)))
+        A[:, k] = a.cpu().numpy()
+    if normalize:
+        mean, std = ranks.mean_std(A.reshape(-1))                 # (the reference: over ALL entries, :30-35)
+        A = (A - mean) / (std + 1e-8)
+    for i, p in enumerate(paths):
+        p["advantages"] = A[off[i]:off[i + 1]]
 
 
 def _baseline_block(h, paths, baseline, off):
@@ -118,12 +171,12 @@ def _baseline_block(h, paths, baseline, off):
             p["baseline"] = baseline.predict(p)
         flat = np.concatenate([np.asarray(p["baseline"], np.float64) for p in paths])
     if flat.ndim != 1:
-        raise NotImplementedError("vector-valued baselines (process_samples.py:26-27) are not supported on the device path")
+        return flat                                      # vector-valued: compute_advantages goes column by column
     return ingest.upload(h, flat)
 
 
 def compute_advantages(paths, baseline, gamma, gae_lambda=None, normalize=False):
-    """process_samples.py:7-35 (1-D baselines).  GAE when 0 <= gae_lambda <= 1, else
+    """process_samples.py:7-35 (vector-valued baselines, :26-27: column by column).  GAE when 0 <= gae_lambda <= 1, else
     advantages = returns - baseline."""
     if not paths:
         if normalize:
@@ -134,6 +187,8 @@ def compute_advantages(paths, baseline, gamma, gae_lambda=None, normalize=False)
     off = _offsets(paths)
     b = _baseline_block(h, paths, baseline, off)
     use_gae = not (gae_lambda is None or gae_lambda < 0.0 or gae_lambda > 1.0)
+    if isinstance(b, np.ndarray):                        # (N, K) baseline values, process_samples.py:26-27
+        return _advantages_by_column(h, paths, b, off, gamma, gae_lambda, use_gae, normalize)
     if use_gae:
         x = _rewards_block(h, paths)
     else:

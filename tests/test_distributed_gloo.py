@@ -81,3 +81,54 @@ def test_two_ranks_match_one(algo, tmp_path):
     assert abs(float(r0["kl"]) - float(one["kl"])) < 1e-4 * abs(float(one["kl"])) + 1e-8
     np.testing.assert_allclose(r0["stats"], one["stats"], rtol=1e-12)      # return statistics over ALL ranks' paths
     np.testing.assert_allclose(r1["stats"], one["stats"], rtol=1e-12)
+
+
+def _chain_worker(rank, world, port, outdir):
+    """transport chain of engine._native_comm on two gloo ranks with a stand-in backend whose in-library RCCL cannot produce a
+    communicator id on rank 0 (what MJX_RCCL_DISABLE=1 / a missing librccl does)"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MJX_TRANSPORT_ORDER="rccl,hook")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mjrl_amd.engine import UpdateEngine
+    from tests._cpu_backend import OracleBackend
+
+    class Stub(OracleBackend):
+        hooked = False
+
+        def comm_unique_id(self):
+            raise RuntimeError("librccl.so could not be loaded (stand-in)")
+
+        def comm_init(self, rank, world, uid):
+            raise AssertionError("no rank may get here: there is no communicator id")
+
+        def comm_set_callback(self, d, world):
+            self.hooked = True
+
+        def allreduce(self, t):
+            dist.all_reduce(t)
+    eng = UpdateEngine(5, 2, (16, 16), backend=Stub(5, 2, (16, 16)))
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        ok = eng._native_comm()
+    np.savez(os.path.join(outdir, "chain_r%d.npz" % rank), ok=np.array([ok]), kind=np.array([str(eng.comm_kind)]),
+             hooked=np.array([eng.backend.hooked]), warned=np.array([sum("rccl" in str(w.message) for w in caught)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_rccl_id_failure_on_rank0_does_not_strand_the_other_ranks(tmp_path):
+    """rank 0 failing to create the RCCL communicator id used to raise BEFORE the broadcast the other ranks were
+    blocked in, then went on to the agreement all-reduce -- mismatched collectives, a hang.  Now the failure travels through the
+    broadcast as None, every rank drops the attempt, and the chain continues with the hook (known-answer sum included)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    mp.start_processes(_chain_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    for r in (0, 1):
+        g = np.load(os.path.join(out, "chain_r%d.npz" % r))
+        assert bool(g["ok"][0]) and str(g["kind"][0]) == "hook" and bool(g["hooked"][0]), dict(g)
+        assert int(g["warned"][0]) == 1

@@ -99,3 +99,23 @@ def test_nccl_group_without_in_library_rccl_falls_back_to_the_hook(tmp_path):
     r = np.load(out)
     assert str(r["kind"][0]) == "hook", r["kind"]
     assert bool(r["same"][0])
+
+
+@pytest.mark.parametrize("world,fault", [(2, "slot"), (2, "flag"), (3, "slot")])
+def test_a_corrupted_peer_transport_is_rejected_before_the_first_update(tmp_path, world, fault):
+    """engine._transport_self_test: at attach, one known-answer rank sum (d floats + 4 doubles, rank-dependent, exactly summable)
+    through the transport, compared with the closed form bit for bit and across the ranks.  MJX_PEER_FAULT makes ONE rank's producer
+    misbehave -- `slot`: its vectors land in another rank's slot at the peers (a mis-mapped buffer); `flag`: it never raises its
+    arrival flags (a lost flag store; the consumers' bounded wait ends in NaN).  Every rank must reject the peer exchange, fall
+    through to the hook, and the update must be the clean run's (which runs on the peer exchange)."""
+    clean, bad = str(tmp_path / "clean.npz"), str(tmp_path / "bad.npz")
+    port = 29400 + (os.getpid() % 150) + 7 * world + (3 if fault == "flag" else 0)
+    _run("_peer_fault_worker.py", [clean], world, port)
+    _run("_peer_fault_worker.py", [bad], world, port + 1,
+         extra_env={"MJX_PEER_FAULT": fault, "MJX_PEER_FAULT_RANK": str(world - 1), "MJX_PEER_TIMEOUT_MS": "200"})
+    a, b = np.load(clean), np.load(bad)
+    assert str(a["comm_kind"][0]) == "peer" and not bool(a["warned"][0])
+    assert str(b["comm_kind"][0]) == "hook" and bool(b["warned"][0]), (b["comm_kind"], b["warned"])
+    assert bool(a["ranks_identical"][0]) and bool(b["ranks_identical"][0])
+    assert np.all(np.isfinite(b["theta"]))
+    assert rel(b["theta"], a["theta"]) < 1e-6, rel(b["theta"], a["theta"])          # the same update over the other transport

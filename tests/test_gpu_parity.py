@@ -195,6 +195,55 @@ def test_dapg_cfg5_wide_vs_reference():
     agent.engine.close()
 
 
+@pytest.mark.parametrize("key", ["configs3_humanoid_256x256", "configs4_adroit_512x512"])
+def test_shard_size_update_vs_reference(key):
+    """The sizes bench.py's layer-wise numbers are quoted on -- the per-GPU shards of BASELINE configs[3] / [4]: 500 000 x
+    (376, 17, 256^2, NPG, 25 CG) and 1M x (39, 28, 512^2) + 5 000 demonstration rows (DAPG, 10 CG) -- through
+    NPG / DAPG.train_from_paths on the path list, against the UNMODIFIED reference's run on the same seeded rows
+    (tests/golden/make_golden_big.py npg_cfg4_shard / dapg_cfg5_shard; mjrl/algos/npg_cg.py:91-163, dapg.py:54-141)."""
+    import bench
+    from mjrl_amd.algos.dapg import DAPG
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    c = bench.LW_SHARDS[key]
+    fx = os.path.join(ROOT, "tests", "golden", c["fixture"] + ".npz")
+    if not os.path.exists(fx):
+        pytest.skip("fixture %s not generated" % c["fixture"])
+    g = np.load(fx)
+    inp = bench.lw_shard_inputs(key)
+    np.testing.assert_allclose(bench.lw_inputs_digest(inp), g["digest"], rtol=1e-12, atol=1e-9)      # the rows the reference saw
+    n, m, hid, T = c["n"], c["m"], c["hidden"], c["T"]
+    spec = type("Spec", (), dict(observation_dim=n, action_dim=m, horizon=T))
+    pol = MLP(spec, hidden_sizes=hid, seed=1, init_log_std=-0.5)
+    pol.set_param_values(inp["theta"])
+    obs64, act64 = inp["obs"].astype(np.float64), inp["act"].astype(np.float64)
+    paths = [dict(observations=obs64[i * T:(i + 1) * T], actions=act64[i * T:(i + 1) * T], rewards=np.zeros(T),
+                  advantages=inp["adv"][i * T:(i + 1) * T].copy(), terminated=False) for i in range(c["n_traj"])]
+    kw = dict(FIM_invert_args={'iters': c["cg_iters"], 'damping': 1e-4})
+    if c["algo"] == "npg":
+        agent = NPG(None, pol, None, normalized_step_size=0.05, **kw)
+    else:
+        Td = 200
+        demos = [dict(observations=inp["demo_obs"][i * Td:(i + 1) * Td].astype(np.float64),
+                      actions=inp["demo_act"][i * Td:(i + 1) * Td].astype(np.float64)) for i in range(c["demo_rows"] // Td)]
+        agent = DAPG(None, pol, None, demo_paths=demos, kl_dist=c["kl_dist"], lam_0=c["lam_0"], lam_1=0.95, **kw)
+    assert not agent.engine.fused
+    agent.train_from_paths(paths)
+    S = int(g["stride"])
+    step = (pol.get_param_values().astype(np.float64) - inp["theta"])[::S]
+    ref = g["update_step_sub"].astype(np.float64)
+    err = float(np.linalg.norm(step - ref) / np.linalg.norm(ref))
+    lu = agent.last_update
+    print("%s: step %.2e from the reference (reference vs fp64 oracle: %s), alpha %.2e, kl %.2e"
+          % (c["fixture"], err, ("%.2e" % float(g["err_ref_vs_f64_update_step"])) if "err_ref_vs_f64_update_step" in g.files else "n/a",
+             abs(lu["alpha"] - float(g["alpha"])) / float(g["alpha"]), abs(lu["kl_dist"] - float(g["kl"])) / float(g["kl"])))
+    assert err < TOL_STEP, err
+    assert abs(lu["alpha"] - float(g["alpha"])) < 1e-5 * float(g["alpha"])
+    assert abs(lu["kl_dist"] - float(g["kl"])) < 1e-4 * float(g["kl"])
+    assert abs((lu["surr_after"] - lu["surr_before"]) - float(g["surr_improvement"])) < 1e-4 * abs(float(g["surr_improvement"])) + 2e-6
+    agent.engine.close()
+
+
 @pytest.mark.parametrize("N", [1, 31, 32, 33, 1000, 4097])
 def test_ragged_tails_vs_oracle(N):
     """N not a multiple of the 32-sample tile, N smaller than one tile, N == 1."""
@@ -539,6 +588,48 @@ def test_scans_on_edge_lengths_vs_oracle():
     process_samples.compute_advantages(paths, Frozen(), gamma, None)
     for p, b in zip(paths, base):
         np.testing.assert_allclose(p["advantages"], p["returns"] - b, rtol=1e-12, atol=1e-12)
+
+
+def test_vector_valued_rewards_and_baselines_vs_reference():
+    """process_samples.py:26-27 (b.ndim == 2): (T, K) rewards against a (T, K) baseline -- K independent scans, column by column on
+    the device -- against the UNMODIFIED reference's compute_returns / compute_advantages (oracle/ref_loader: sources or staged
+    bytecode), GAE and plain, with and without normalisation, ragged and terminated paths."""
+    import copy
+    from mjrl_amd.utils import process_samples
+    from oracle import ref_loader
+    if ref_loader.install() is None:
+        pytest.skip("reference not available")
+    from mjrl.utils import process_samples as ref_ps
+    rng = np.random.RandomState(4)
+    K, lens = 3, [1, 7, 256, 300, 25]
+    paths = [dict(observations=rng.randn(T, 5), actions=rng.randn(T, 2), rewards=rng.randn(T, K), terminated=bool(i % 2)) for i, T in enumerate(lens)]
+    base = [rng.randn(T, K) for T in lens]
+
+    class Frozen:
+        def __init__(self):
+            self.k = 0
+        def predict(self, path):
+            self.k += 1
+            return base[self.k - 1]
+    for lam, normalize in ((0.97, False), (0.97, True), (None, False), (None, True)):
+        ours, ref = copy.deepcopy(paths), copy.deepcopy(paths)
+        process_samples.compute_returns(ours, 0.99)
+        ref_ps.compute_returns(ref, 0.99)
+        process_samples.compute_advantages(ours, Frozen(), 0.99, lam, normalize=normalize)
+        ref_ps.compute_advantages(ref, Frozen(), 0.99, lam, normalize=normalize)
+        for a, b in zip(ours, ref):
+            assert a["returns"].shape == b["returns"].shape and a["advantages"].shape == b["advantages"].shape == (len(a["rewards"]), K)
+            np.testing.assert_allclose(a["returns"], b["returns"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(a["advantages"], b["advantages"], rtol=1e-10, atol=1e-10)
+    # a 1-D reward vector against a (T, K) baseline broadcasts in the reference only when T == K: an error there, an error here
+    bad = [dict(observations=rng.randn(9, 5), rewards=rng.randn(9), terminated=False)]
+    process_samples.compute_returns(bad, 0.99)
+
+    class Two:
+        def predict(self, path):
+            return np.zeros((9, 2))
+    with pytest.raises(ValueError):
+        process_samples.compute_advantages(bad, Two(), 0.99, 0.97)
 
 
 def test_scan_full_size_properties():
