@@ -7,6 +7,7 @@ whitening + return statistics), the surrogate / KL / vanilla-gradient operators 
 vanilla-PG ``train_from_paths``.  All batch arithmetic runs in libmjx through
 ``mjrl_amd.engine.UpdateEngine``; this class only orchestrates.
 """
+import os
 import time as timer
 
 import numpy as np
@@ -119,17 +120,50 @@ class BatchREINFORCE:
             process_samples.compute_advantages(paths, self.baseline, gamma, gae_lambda)
             eval_statistics = self.train_from_paths(paths)
             eval_statistics.append(N)
+            # The fitted baseline is not read before the NEXT iteration's compute_advantages, and sampling comes first
+            # (batch_reinforce.py:78-112): a baseline that can fit in the background (MLPBaseline.fit_async: 0.6 s of a one-
+            # workgroup Adam chain per 1M timesteps) is started here and left running under the next rollouts; its errors and
+            # duration enter the log as pending entries that turn into numbers when the fit is over (utils/logger.py).
+            fit_async = getattr(self.baseline, "fit_async", None) if os.environ.get("MJX_ASYNC_FIT", "1") != "0" else None
             if self.save_logs:
                 self.logger.log_kv('num_samples', self.engine.global_count(int(np.sum([p["rewards"].shape[0] for p in paths]))))
                 t0 = timer.time()
-                error_before, error_after = self.baseline.fit(paths, return_errors=True)
-                self.logger.log_kv('time_VF', timer.time() - t0)
-                self.logger.log_kv('VF_error_before', error_before)
-                self.logger.log_kv('VF_error_after', error_after)
+                if fit_async is not None:
+                    self._log_fit_when_done(fit_async(paths, return_errors=True), t0)
+                else:
+                    error_before, error_after = self.baseline.fit(paths, return_errors=True)
+                    self.logger.log_kv('time_VF', timer.time() - t0)
+                    self.logger.log_kv('VF_error_before', error_before)
+                    self.logger.log_kv('VF_error_after', error_after)
+            elif fit_async is not None:
+                fit_async(paths)
             else:
                 self.baseline.fit(paths)
         drop_shared_batch()                     # the iteration's one upload served predict, update and fit; nothing may outlive it
         return eval_statistics
+
+    def _log_fit_when_done(self, pend, t0):
+        """time_VF / VF_error_before / VF_error_after of a fit that is still running: pending log entries, delivered by the
+        fit's settlement (whoever touches the baseline next, or save_log) and then REPLACED in the log by plain floats"""
+        from ..utils.logger import PendingValue
+        enqueue_s = timer.time() - t0
+        slots = {}
+        for key in ('time_VF', 'VF_error_before', 'VF_error_after'):
+            slots[key] = PendingValue(pend)
+            self.logger.log_kv(key, slots[key])
+        log = self.logger.log
+        where = {key: len(log[key]) - 1 for key in slots}
+
+        def deliver(errors, device_ms):
+            vals = dict(time_VF=enqueue_s + 1e-3 * device_ms, VF_error_before=errors[0], VF_error_after=errors[1])
+            for key, ph in slots.items():
+                ph.deliver(vals[key])
+                series = self.logger.log.get(key)
+                if series is not None and where[key] < len(series) and series[where[key]] is ph:
+                    series[where[key]] = ph.value
+        pend.hooks.append(deliver)
+        if pend.done:                                    # (nothing was in flight: a baseline whose fit_async is synchronous)
+            deliver(pend.value, pend.device_ms or 0.0)
 
     # ------------------------------------------------------------------ vanilla PG update
     def train_from_paths(self, paths):

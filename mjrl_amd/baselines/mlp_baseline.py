@@ -15,7 +15,41 @@ from ..utils import ingest, ranks
 from ._features import DeviceBlock, DeviceOnly
 
 
+_FIT_STREAMS = {}            # device -> the side stream the asynchronous fits run on
+
+
+def _fit_stream(torch, dev):
+    key = (dev.type, dev.index)
+    if key not in _FIT_STREAMS:
+        _FIT_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _FIT_STREAMS[key]
+
+
+class PendingFit:
+    """One fit in flight on the side stream (MLPBaseline.fit_async): the device tensors it reads and writes, the page-locked
+    blocks its results land in, and what to do with them once it is over.  ``result()`` waits for it (once), writes parameters /
+    moments / losses into the baseline, and -> (error_before, error_after) when errors were asked for, else None."""
+
+    def __init__(self, baseline):
+        self.baseline, self.done, self.value = baseline, False, None
+        self.keep, self.start_ev, self.end_ev = [], None, None
+        self.returns = self.pred_before = self.pred_after = self.host = None
+        self.hooks = []                                   # callables run with (errors, device_seconds) at settlement (deferred log entries)
+        self.device_ms = None
+
+    def finished(self):
+        """has the side stream got through it? (never waits)"""
+        return self.done or self.end_ev is None or bool(self.end_ev.query())
+
+    def result(self):
+        if not self.done:
+            self.baseline._settle()
+        return self.value
+
+
 class MLPBaseline:
+    _STATE = ("params", "adam_m", "adam_v", "adam_steps", "epoch_losses")
+
     def __init__(self, env_spec, inp_dim=None, inp='obs', learn_rate=1e-3, reg_coef=0.0, batch_size=64, epochs=1,
                  use_gpu=False, hidden_sizes=(128, 128)):
         self.n = inp_dim if inp_dim is not None else env_spec.observation_dim
@@ -38,6 +72,51 @@ class MLPBaseline:
         self.adam_steps = 0
         self.epoch_losses = []
 
+    # ---- state access settles a fit in flight first: whoever reads (or replaces) parameters, moments, step count or losses --
+    #      predict, the next fit, pickle.dump / copy.deepcopy (train_agent.py:83,102,129-131), a test -- sees the finished fit
+    def __getattribute__(self, name):
+        if name in MLPBaseline._STATE:
+            d = object.__getattribute__(self, "__dict__")
+            if d.get("_pending") is not None:
+                object.__getattribute__(self, "_settle")()
+        return object.__getattribute__(self, name)
+
+    def __setattr__(self, name, value):
+        if name in MLPBaseline._STATE and self.__dict__.get("_pending") is not None:
+            self._settle()
+        object.__setattr__(self, name, value)
+
+    def __getstate__(self):
+        self._settle()
+        state = dict(self.__dict__)
+        state.pop("_pending", None)
+        state.pop("_pins", None)
+        return state
+
+    def _settle(self):
+        """wait for the fit in flight (if any) and take its results over"""
+        pend = self.__dict__.get("_pending")
+        if pend is None:
+            return
+        d = self.__dict__
+        d["_pending"] = None                              # (first: the assignments below must not recurse)
+        pend.end_ev.synchronize()
+        h = pend.host
+        n = d["params"].size
+        d["params"], d["adam_m"], d["adam_v"] = (h["pmv"][i * pend.seg:i * pend.seg + n].copy() for i in range(3))
+        d["epoch_losses"] = list(h["losses"][:self.epochs].astype(np.float64) / max(pend.steps, 1))
+        pend.device_ms = float(pend.start_ev.elapsed_time(pend.end_ev))
+        if pend.returns is not None:
+            r = pend.returns[:pend.num_samples]
+            e0, e1 = r - pend.pred_before[:pend.num_samples], r - pend.pred_after[:pend.num_samples]
+            den = np.sum(r ** 2) + 1e-8
+            pend.value = (np.sum(e0 ** 2) / den, np.sum(e1 ** 2) / den)        # mlp_baseline.py:83,94
+        pend.done = True
+        pend.keep = []
+        for hook in pend.hooks:
+            hook(pend.value, pend.device_ms)
+        pend.hooks = []
+
     def _hid(self):
         return (ctypes.c_int * max(1, len(self.hidden_sizes)))(*self.hidden_sizes)
 
@@ -47,8 +126,26 @@ class MLPBaseline:
         check(blk.lib.mjx_mlp_predict(ptr(feat), N, self.n + 4, self._hid(), len(self.hidden_sizes), ptr(params_t), ptr(out), blk.st()))
         return out
 
+    def _pinned(self, torch, name, count, dtype):
+        """page-locked result blocks, kept per baseline and size (allocating them costs more than the copies they receive)"""
+        pins = self.__dict__.setdefault("_pins", {})
+        ent = pins.get(name)
+        if ent is None or ent.numel() < count or ent.dtype != dtype:
+            ent = pins[name] = torch.empty(max(int(count), 1), dtype=dtype, pin_memory=True)
+        return ent
+
     def fit(self, paths, return_errors=False):
-        """mlp_baseline.py:61-95 + optimize_model.py:7-36.  With torch.distributed initialised `paths` is this rank's trajectory
+        """mlp_baseline.py:61-95 + optimize_model.py:7-36: fit_async + wait.  -> (error_before, error_after) when asked."""
+        return self.fit_async(paths, return_errors).result()
+
+    def fit_async(self, paths, return_errors=False):
+        """mlp_baseline.py:61-95 + optimize_model.py:7-36, OFF the caller's critical path: inputs are prepared on the caller's
+        stream, the persistent trainer (one workgroup, 18 us per Adam step: 0.6 s per 1M timesteps x 2 epochs), the error
+        evaluations and the read-backs run on a side stream, and the call returns a PendingFit at once.  The fitted baseline is
+        not needed before the next iteration's compute_advantages (batch_reinforce.py:94-112: sampling comes first), so the fit
+        hides under the next rollouts; any access to the baseline's state -- predict, fit, pickle, deepcopy -- waits for it.
+
+        With torch.distributed initialised `paths` is this rank's trajectory
         shard; the reference fits ONE network on all paths of the iteration (batch_reinforce.py:94-110), and minibatch Adam is a
         sequential chain, not a sum over samples -- so the ranks' fp32 feature blocks and returns are concatenated in rank order
         (one all-gather of N x (n + 5) floats) and EVERY rank runs the identical persistent trainer on the whole block from the
@@ -57,6 +154,7 @@ class MLPBaseline:
         alike).  The
         trainer is one workgroup whatever the batch size: running it redundantly costs no wall time over running it once and
         broadcasting, and the ranks' baselines stay bit-identical -- equal to a one-rank fit on the rank-ordered paths."""
+        self._settle()
         if paths:
             blk = DeviceBlock(paths, self.inp)
             torch = blk.torch
@@ -72,34 +170,51 @@ class MLPBaseline:
         if ranks.group() is not None:
             feat, y = ranks.gather_rows(feat).contiguous(), ranks.gather_rows(y).contiguous()
         num_samples = int(y.shape[0])
-        if return_errors:
-            returns = ingest.download(blk.handle, y)
-        p = torch.from_numpy(self.params).to(blk.dev)
-        if return_errors:
-            errors = returns - ingest.download(blk.handle, self._forward(blk, feat, p))
-            error_before = np.sum(errors ** 2) / (np.sum(returns ** 2) + 1e-8)
-        m, v = torch.from_numpy(self.adam_m).to(blk.dev), torch.from_numpy(self.adam_v).to(blk.dev)
+        npar = self.params.size
+        seg = (npar + 63) // 64 * 64                            # (256-byte aligned segments: the trainer reads them with wide loads)
+        stacked = np.zeros(3 * seg, np.float32)
+        for i, a in enumerate((self.params, self.adam_m, self.adam_v)):
+            stacked[i * seg:i * seg + npar] = a
+        pmv = torch.from_numpy(stacked).to(blk.dev)             # one upload: parameters | m | v
+        p, m, v = pmv[:npar], pmv[seg:seg + npar], pmv[2 * seg:2 * seg + npar]
         perm = np.concatenate([np.random.permutation(num_samples) for _ in range(self.epochs)]).astype(np.int32) \
             if self.epochs > 0 else np.zeros(1, np.int32)
         perm = ranks.broadcast_host(perm, src=-1)               # (one process: itself)
         perm_t = ingest.upload(blk.handle, perm)
         losses = torch.zeros(max(self.epochs, 1), dtype=torch.float64, device=blk.dev)
-        check(blk.lib.mjx_mlp_fit_adam(ptr(feat), ptr(y), num_samples, self.n + 4, self._hid(), len(self.hidden_sizes), ptr(p), ptr(m),
-                                       ptr(v), self.adam_steps, ptr(perm_t), int(self.epochs), int(self.batch_size),
-                                       float(self.learn_rate), float(self.reg_coef), ptr(losses), blk.st()))
         steps = max(int(num_samples / self.batch_size) - 1, 0)
-        self.adam_steps += steps * self.epochs
-        self.params, self.adam_m, self.adam_v = (ingest.download(blk.handle, t) for t in (p, m, v))
-        self.epoch_losses = list(losses.cpu().numpy()[:self.epochs] / max(steps, 1))
-        if return_errors:
-            errors = returns - ingest.download(blk.handle, self._forward(blk, feat, p))
-            error_after = np.sum(errors ** 2) / (np.sum(returns ** 2) + 1e-8)
-            return error_before, error_after
+        pend = PendingFit(self)
+        pend.steps, pend.num_samples, pend.seg = steps, num_samples, seg
+        main, side = torch.cuda.current_stream(blk.dev), _fit_stream(torch, blk.dev)
+        side.wait_stream(main)                                  # everything above is queued on the caller's stream
+        host = dict(pmv=self._pinned(torch, "pmv", 3 * seg, torch.float32), losses=self._pinned(torch, "losses", max(self.epochs, 1), torch.float64))
+        with torch.cuda.stream(side):
+            pend.start_ev, pend.end_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pend.start_ev.record(side)
+            before = self._forward(blk, feat, p) if return_errors else None
+            check(blk.lib.mjx_mlp_fit_adam(ptr(feat), ptr(y), num_samples, self.n + 4, self._hid(), len(self.hidden_sizes), ptr(p), ptr(m),
+                                           ptr(v), self.adam_steps, ptr(perm_t), int(self.epochs), int(self.batch_size),
+                                           float(self.learn_rate), float(self.reg_coef), ptr(losses), blk.st()))
+            after = self._forward(blk, feat, p) if return_errors else None
+            host["pmv"][:3 * seg].copy_(pmv, non_blocking=True)
+            host["losses"][:max(self.epochs, 1)].copy_(losses, non_blocking=True)
+            if return_errors:
+                for name, t in (("returns", y), ("pred_before", before), ("pred_after", after)):
+                    pin = self._pinned(torch, name, num_samples, torch.float32)
+                    pin[:num_samples].copy_(t, non_blocking=True)
+                    setattr(pend, name, pin.numpy())
+            pend.end_ev.record(side)
+        pend.host = dict(pmv=host["pmv"].numpy(), losses=host["losses"].numpy())
+        pend.keep = [feat, y, pmv, perm_t, losses, before, after]          # alive until the side stream is through with them
+        d = self.__dict__
+        d["adam_steps"] = d["adam_steps"] + steps * self.epochs            # (known now; everything else at settlement)
+        d["_pending"] = pend
+        return pend
 
     def predict_batch_device(self, paths, shared=True):
         """fp32 predictions of all timesteps as a device block (the GAE chain of utils/process_samples stays there)"""
         blk = DeviceBlock(paths, self.inp, shared)
-        p = blk.torch.from_numpy(self.params).to(blk.dev)
+        p = blk.torch.from_numpy(self.params).to(blk.dev)            # (reading self.params waits for a fit in flight)
         return self._forward(blk, blk.mlp_features(), p)
 
     def predict_batch(self, paths, shared=True):

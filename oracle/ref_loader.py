@@ -29,7 +29,7 @@ def install():
         return None
     pkg = sys.modules.get("mjrl")
     if pkg is not None and getattr(pkg, "__ref_stub__", False):
-        return pkg.__ref_root__
+        return getattr(pkg, "__ref_root__", r)          # (tests/golden/_ref_import.py installs the same stubs without the tag)
     sys.dont_write_bytecode = True
     pkg = types.ModuleType("mjrl")
     pkg.__path__ = [os.path.join(r, "mjrl")]          # skip mjrl/__init__.py (imports gym + mujoco_py)

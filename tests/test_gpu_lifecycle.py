@@ -168,3 +168,37 @@ def test_bc_dapg_quadratic_baseline_pipeline_vs_reference():
     assert rel(r0["coeffs"], g["bl_coeffs_it0"]) < 1e-5
     assert rel(sync[1]["step"][::S], g["step_it1_sub"]) < 1e-5                    # (measured 6.7e-6)
     assert rel(pol2.get_param_values()[::S], g["theta_it1_sub"]) < 1e-5
+
+
+def test_background_fit_equals_the_blocking_fit_and_fills_the_log(tmp_path, monkeypatch):
+    """BatchREINFORCE.train_step starts MLPBaseline's fit on a side stream and returns (the fitted baseline is not read before the
+    next iteration's compute_advantages, batch_reinforce.py:94-112).  Same training run as with the blocking fit, bit for bit;
+    VF_error_* / time_VF enter the log as pending entries and are plain floats once anything settles the fit -- the next
+    iteration, a deep copy / pickle of the baseline (train_agent.py:102,129-131), save_log."""
+    from mjrl_amd.utils.logger import PendingValue
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MJX_ASYNC_FIT", mode)
+        np.random.seed(0)
+        agent = make("mlp", "npg")
+        pending_seen = 0
+        for i in range(3):
+            agent.train_step(**STEP)
+            last = agent.logger.log["VF_error_after"][-1]
+            pending_seen += isinstance(last, PendingValue)
+            if i == 1:
+                snap = copy.deepcopy(agent.baseline)                    # waits for the fit in flight; the copy carries its result
+                assert snap.__dict__.get("_pending") is None and np.array_equal(snap.params, agent.baseline.params)
+                assert not isinstance(agent.logger.log["VF_error_after"][-1], PendingValue)      # ... and the log entry was delivered
+        agent.logger.save_log(str(tmp_path))                            # settles whatever is left
+        log = agent.logger.log
+        assert all(isinstance(v, float) or np.isscalar(v) for k in ("time_VF", "VF_error_before", "VF_error_after") for v in log[k])
+        assert all(0.0 < v < 10.0 for v in log["VF_error_after"]) and all(v > 0 for v in log["time_VF"])
+        runs[mode] = dict(theta=agent.policy.get_param_values().copy(), bl=agent.baseline.params.copy(), m=agent.baseline.adam_m.copy(),
+                          steps=agent.baseline.adam_steps, err=[float(v) for v in log["VF_error_after"]], pending=pending_seen,
+                          pickled=pickle.loads(pickle.dumps(agent.baseline)).params.copy())
+        agent.engine.close()
+    a, b = runs["1"], runs["0"]
+    assert a["pending"] >= 1 and b["pending"] == 0                      # the background mode really deferred something
+    assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["bl"], b["bl"]) and np.array_equal(a["m"], b["m"])
+    assert a["steps"] == b["steps"] and a["err"] == b["err"] and np.array_equal(a["pickled"], a["bl"])
