@@ -1037,6 +1037,20 @@ struct LayerwiseWS {
   // Weight gradients with 33..128 columns (the first layer of a narrow observation: 512 x 40 at configs[4]) are bound by the
   // bytes they keep in flight, not by the matrix cores (3.3 us per k-tile against 1 us of MFMAs): 128 x 128 tiles in
   // 256-thread workgroups, two per CU (MJX_LW_THIN=0: one 512-thread workgroup per CU as for the wide ones)
+  // samples one workgroup of a weight-gradient launch accumulates in ONE fp32 MFMA chain before its partial goes to the fp64
+  // split reduction (MJX_LW_CHAIN), and the workgroup budget that caps the number of splits (MJX_LW_WG_CAP).  r05: at 1M rows x
+  // 512^2 the r04 values (2 048 samples, 1 024 workgroups -> chains of 7 800 samples) left the DAPG step 1.5e-5 from the
+  // reference (which itself sits 3.2e-6 from fp64 truth): round-off of a sequential fp32 chain grows with its length.  Chains of
+  // 1 024 samples (up to 8 192 workgroups, 1 GB of partial slabs at that size): 7.2e-6, and the Fisher-vector product is 1 %
+  // FASTER (19.27 -> 19.01 ms, tools/probe_chain_error.py: more, shorter workgroups fill the last round better).
+  static int wgrad_chain() {
+    static const int v = [] { const char* e = getenv("MJX_LW_CHAIN"); const int x = e ? atoi(e) : 0; return x >= 256 ? x : 1024; }();
+    return v;
+  }
+  static int wgrad_wg_cap() {
+    static const int v = [] { const char* e = getenv("MJX_LW_WG_CAP"); const int x = e ? atoi(e) : 0; return x >= 64 ? x : 8192; }();
+    return v;
+  }
   static bool thin_wgrad(int ncols) {
     static const bool on = [] { const char* e = getenv("MJX_LW_THIN"); return !(e && e[0] == '0'); }();
     return on && ncols > 32 && ncols <= 128 && tile_mode() == 1;
@@ -1197,8 +1211,8 @@ struct LayerwiseWS {
       const int rowblocks = (int)((N + 127) / 128);      // of the delta GEMM below (its column sums; sample-major launches use 128-row tiles)
       const int tbm = (narrow || hi_ <= 32) ? 128 : bm_of(ho, true);
       int tiles = narrow ? (hi_ + tbm - 1) / tbm : ((ho + tbm - 1) / tbm) * col_blocks(hi_);
-      int splits = (int)((N + 2047) / 2048);
-      int maxs = (1024 + tiles - 1) / tiles;
+      int splits = (int)((N + wgrad_chain() - 1) / wgrad_chain());
+      int maxs = (wgrad_wg_cap() + tiles - 1) / tiles;
       if (splits > maxs) splits = maxs;
       if (splits < 1) splits = 1;
       splits = pick_splits(N, narrow ? (hi_ + tbm - 1) / tbm : (ho + tbm - 1) / tbm, narrow ? ho : hi_, splits);
@@ -1428,8 +1442,8 @@ struct LayerwiseWS {
       const float* tinl = (l == 0) ? nullptr : T[l - 1];
       const int tbm = hi_ <= 32 ? 128 : bm_of(ho, true);
       int tiles = ((ho + tbm - 1) / tbm) * col_blocks(hi_);
-      int splits = (int)((N + 2047) / 2048);
-      int maxs = (1024 + tiles - 1) / tiles;
+      int splits = (int)((N + wgrad_chain() - 1) / wgrad_chain());
+      int maxs = (wgrad_wg_cap() + tiles - 1) / tiles;
       if (splits > maxs) splits = maxs;
       if (splits < 1) splits = 1;
       splits = pick_splits(N, (ho + tbm - 1) / tbm, hi_, splits);
