@@ -628,6 +628,9 @@ def main():
         dts.append(time.perf_counter() - t0)
     prof = (ctypes.c_double * 2)()
     check(eng.lib.mjx_profile_read(eng.ctx, prof))
+    samples_buf, samples_n = (ctypes.c_double * 4096)(), ctypes.c_int(0)
+    check(eng.lib.mjx_profile_samples(eng.ctx, samples_buf, 4096, ctypes.byref(samples_n)))
+    fvp_samples = [float(samples_buf[i]) for i in range(min(samples_n.value, 4096))]
     check(eng.lib.mjx_profile_enable(eng.ctx, 0))
     tmax = torch.tensor(dts, dtype=torch.float64, device="cuda")
     if world > 1:
@@ -681,6 +684,11 @@ def main():
                          "achieved": achieved_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP32_MFMA_PEAK_TF, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": fvp_ms, "launches": int(prof[1]),
+                         "launch_ms_samples": {"sorted": sorted(round(x, 5) for x in fvp_samples),
+                                               "min": min(fvp_samples) if fvp_samples else None,
+                                               "median": sorted(fvp_samples)[len(fvp_samples) // 2] if fvp_samples else None,
+                                               "max": max(fvp_samples) if fvp_samples else None,
+                                               "what": "every bracketed launch's HIP-event time (mjx_profile_samples); avg_launch_ms is their mean"},
                          "launches_timed": "every %d-th of %d (HIP events on the launch stream, inside the timed regions)" % (max(args.fvp_event_stride, 1), args.steps * CG_ITERS * len(dts)),
                          "flop_per_launch": flop_per_sample * n_loc,
                          "algorithmic_bytes_per_launch": bytes_per_sample * n_loc,

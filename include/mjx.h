@@ -377,6 +377,9 @@ int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, con
  * on = 0 switches the events off. */
 int mjx_profile_enable(mjx_ctx* ctx, int on);
 int mjx_profile_read(mjx_ctx* ctx, double* out_host);
+/* every bracketed launch's HIP-event time on its own (milliseconds, launch order; at most `cap` of them are written,
+ * *count_out = how many were measured): the distribution behind mjx_profile_read's total */
+int mjx_profile_samples(mjx_ctx* ctx, double* ms_out_host, int cap, int* count_out);
 
 /* ---- debugging aid (tests only) ------------------------------------------ */
 /* When non-NULL, the fused kernels dump the first tile's intermediates here. */

@@ -82,6 +82,7 @@ PROTOTYPES = {
                                  c_int64, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     "mjx_profile_enable": (c_int, [c_void_p, c_int]),
     "mjx_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_double)]),
+    "mjx_profile_samples": (c_int, [c_void_p, ctypes.POINTER(c_double), c_int, ctypes.POINTER(c_int)]),
     "mjx_set_debug_buffer": (c_int, [c_void_p, c_void_p, c_int64]),
     "mjx_set_clock_buffer": (c_int, [c_void_p, c_void_p]),
 }

@@ -177,10 +177,16 @@ class MLPBaseline:
             stacked[i * seg:i * seg + npar] = a
         pmv = torch.from_numpy(stacked).to(blk.dev)             # one upload: parameters | m | v
         p, m, v = pmv[:npar], pmv[seg:seg + npar], pmv[2 * seg:2 * seg + npar]
-        perm = np.concatenate([np.random.permutation(num_samples) for _ in range(self.epochs)]).astype(np.int32) \
-            if self.epochs > 0 else np.zeros(1, np.int32)
-        perm = ranks.broadcast_host(perm, src=-1)               # (one process: itself)
-        perm_t = ingest.upload(blk.handle, perm)
+        # every epoch's row order from NumPy's global stream like fit_data (optimize_model.py:22), written straight into a page-
+        # locked int32 block (one conversion pass per epoch instead of concatenate + astype over the lot)
+        perm_pin = self._pinned(torch, "perm", max(self.epochs, 1) * max(num_samples, 1), torch.int32)
+        perm = perm_pin.numpy()[:max(self.epochs * num_samples, 1)]
+        perm[:] = 0
+        for ep in range(self.epochs):
+            perm[ep * num_samples:(ep + 1) * num_samples] = np.random.permutation(num_samples)
+        if ranks.group() is not None:
+            perm[:] = ranks.broadcast_host(perm, src=-1)        # the LAST rank's draw (see above)
+        perm_t = perm_pin[:perm.shape[0]].to(blk.dev, non_blocking=True)
         losses = torch.zeros(max(self.epochs, 1), dtype=torch.float64, device=blk.dev)
         steps = max(int(num_samples / self.batch_size) - 1, 0)
         pend = PendingFit(self)

@@ -1,0 +1,271 @@
+// host_ingest.h -- the HOST side of rollout ingestion: persistent gather pools, the fp64 -> fp32 converting gather,
+// per-path sums, and the asynchronous staging jobs (one native thread per block: gather group by group, queue each group's
+// host-to-device copy behind it).  Plain C++17 + pthreads, no HIP types: mjx.hip includes it with the three device hooks below
+// bound to the HIP runtime; tests/c/host_san.cpp includes it with the hooks bound to memcpy and builds it under
+// -fsanitize=address,undefined and -fsanitize=thread (tests/test_host_sanitizers.py: the CPU lane runs both).
+//
+// The includer provides, before the #include:
+//   int fail(int code, const char* fmt, ...)                 -> records the thread's error message, returns code
+//   MJX_DEVICE_ENTRY()                                        -> fork guard + call counter (may `return` an error)
+//   bool MJX_HI_SET_DEVICE(int index)
+//   int  MJX_HI_H2D_ASYNC(void* dst_dev, const void* src_host, size_t bytes, void* stream, const char** what)   (0 = ok)
+//   int  MJX_HI_CAST_F64_F32(const double* x_dev, int64_t count, float* out_dev, void* stream)                  (MJX_OK = ok)
+#pragma once
+#include <unistd.h>
+
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+// Persistent host workers for mjx_host_gather: a training iteration issues ~12 gathers of 8-50 MB, and creating 7-15
+// std::threads for each (20-50 us apiece) cost as much as the copies they performed.  Workers sleep on a condition variable;
+// one job at a time (a second caller -- the prefetch thread and the trainer may overlap -- falls back to its own threads).
+// The pool is leaked on purpose (no joins in static destructors; a forked child simply finds no workers and copies inline).
+struct HostPool {
+  static constexpr int MAXW = 31;
+  std::mutex m, run_m;
+  std::condition_variable cv, done_cv;
+  const std::function<void(int)>* job = nullptr;
+  int active = 0, pending = 0;
+  uint64_t gen = 0;
+  int nworkers = 0;
+  pid_t owner = 0;
+  void ensure(int n) {
+    if (n > MAXW) n = MAXW;
+    while (nworkers < n) {
+      const int t = ++nworkers;
+      std::thread([this, t] {
+        uint64_t seen = 0;
+        for (;;) {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return gen != seen; });
+          seen = gen;
+          const bool mine = t < active;
+          const std::function<void(int)>* j = job;
+          lk.unlock();
+          if (mine) {
+            (*j)(t);
+            lk.lock();
+            if (--pending == 0) done_cv.notify_one();
+          }
+        }
+      }).detach();
+    }
+  }
+  // run fn(0 .. nt-1), fn(0) on the calling thread; false if the pool is busy or unusable (the caller uses its own threads)
+  bool run(int nt, const std::function<void(int)>& fn) {
+    std::unique_lock<std::mutex> rl(run_m, std::try_to_lock);
+    if (!rl.owns_lock()) return false;
+    // (under the run lock: two first-time callers raced on `owner` -- found by the ThreadSanitizer build, tests/c/host_san.cpp)
+    if (owner != getpid()) { if (owner != 0) return false; owner = getpid(); }
+    {
+      std::lock_guard<std::mutex> lk(m);
+      ensure(nt - 1);
+      job = &fn; active = nt; pending = nt - 1; ++gen;
+    }
+    cv.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lk(m);
+    done_cv.wait(lk, [&] { return pending == 0; });
+    job = nullptr; active = 0;
+    return true;
+  }
+};
+// three pools: the observation and the action block of a batch are staged by two helper threads at the same time (r04) while the
+// training thread stages its 8 MB of advantages; a fourth concurrent caller falls back to its own threads
+struct HostPools {
+  HostPool a, b, c;                                // (c: the advantage / reward block the training thread stages meanwhile)
+  bool run(int nt, const std::function<void(int)>& fn) { return a.run(nt, fn) || b.run(nt, fn) || c.run(nt, fn); }
+};
+HostPools& host_pool() { static HostPools* p = new HostPools(); return *p; }
+}  // namespace
+
+extern "C" {
+
+int mjx_host_gather(void* dst, const void* const* src, const int64_t* offsets, int64_t first, int64_t count,
+                    int64_t row_bytes, int n_threads) {
+  if (!dst || !src || !offsets || first < 0 || count < 0 || row_bytes <= 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (count == 0) return MJX_OK;
+  const int64_t total = (offsets[first + count] - offsets[first]) * row_bytes;
+  int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+  if (total < (int64_t)(1 << 20)) nt = 1;
+  else if (total < (int64_t)(16 << 20) && nt > 8) nt = 8;      // a few MB: waking 31 workers costs more than they save
+  // every thread takes a contiguous byte range of the destination (blocks are split where the range ends)
+  auto work = [&](int t) {
+    const int64_t lo = total * t / nt, hi = total * (t + 1) / nt;
+    const int64_t base = offsets[first] * row_bytes;
+    for (int64_t i = first; i < first + count; ++i) {
+      const int64_t b0 = offsets[i] * row_bytes - base, b1 = offsets[i + 1] * row_bytes - base;
+      const int64_t c0 = b0 > lo ? b0 : lo, c1 = b1 < hi ? b1 : hi;
+      if (c1 > c0) memcpy((char*)dst + base + c0, (const char*)src[i] + (c0 - b0), (size_t)(c1 - c0));
+      if (b0 >= hi) break;
+    }
+  };
+  if (nt == 1) { work(0); return MJX_OK; }
+  if (nt > HostPool::MAXW + 1) nt = HostPool::MAXW + 1;
+  {
+    const std::function<void(int)> fn = work;
+    if (host_pool().run(nt, fn)) return MJX_OK;
+  }
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  return MJX_OK;
+}
+
+// fp64 -> fp32 while gathering (round to nearest even, the bits of NumPy's astype and of mjx_cast_f64_f32): the blocks leave the
+// host at half their size.  Every thread converts a contiguous element range of the destination.
+namespace {
+void cvt_range_generic(float* __restrict__ d, const double* __restrict__ s, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) d[i] = (float)s[i];
+}
+__attribute__((target("avx2"))) void cvt_range_avx2(float* __restrict__ d, const double* __restrict__ s, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) d[i] = (float)s[i];        // (vcvtpd2ps on 4-wide vectors: the loop vectorises under this target)
+}
+}  // namespace
+
+int mjx_host_gather_f64_f32(float* dst, const double* const* src, const int64_t* offsets, int64_t first, int64_t count,
+                            int64_t row_elems, int n_threads) {
+  if (!dst || !src || !offsets || first < 0 || count < 0 || row_elems <= 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (count == 0) return MJX_OK;
+  const int64_t total = (offsets[first + count] - offsets[first]) * row_elems;      // elements
+  int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+  if (total < (int64_t)(1 << 17)) nt = 1;
+  else if (total < (int64_t)(2 << 20) && nt > 8) nt = 8;
+  const char* no_avx2 = getenv("MJX_NO_AVX2");             // (tests: the portable loop on an AVX2 host)
+  const bool avx2 = __builtin_cpu_supports("avx2") && !(no_avx2 && no_avx2[0] == '1');
+  auto work = [&](int t) {
+    const int64_t lo = total * t / nt, hi = total * (t + 1) / nt;
+    const int64_t base = offsets[first] * row_elems;
+    for (int64_t i = first; i < first + count; ++i) {
+      const int64_t b0 = offsets[i] * row_elems - base, b1 = offsets[i + 1] * row_elems - base;
+      const int64_t c0 = b0 > lo ? b0 : lo, c1 = b1 < hi ? b1 : hi;
+      if (c1 > c0) {
+        if (avx2) cvt_range_avx2(dst + base + c0, src[i] + (c0 - b0), c1 - c0);
+        else cvt_range_generic(dst + base + c0, src[i] + (c0 - b0), c1 - c0);
+      }
+      if (b0 >= hi) break;
+    }
+  };
+  if (nt == 1) { work(0); return MJX_OK; }
+  if (nt > HostPool::MAXW + 1) nt = HostPool::MAXW + 1;
+  {
+    const std::function<void(int)> fn = work;
+    if (host_pool().run(nt, fn)) return MJX_OK;
+  }
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  return MJX_OK;
+}
+
+// per-trajectory sums of a 1-D fp64 quantity (path returns, batch_reinforce.py:187): out[i] = src[i][0] + src[i][1] + ... in that
+// order -- the order of Python's sum() over the array, which is what the reference calls -- the trajectories spread over threads
+int mjx_host_segment_sums(const double* const* src, const int64_t* lens, int64_t count, double* out, int n_threads) {
+  if (!src || !lens || !out || count < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  if (count == 0) return MJX_OK;
+  int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+  if (count < 64) nt = 1;
+  auto work = [&](int t) {
+    const int64_t lo = count * t / nt, hi = count * (t + 1) / nt;
+    for (int64_t i = lo; i < hi; ++i) {
+      const double* p = src[i];
+      double a = 0.0;                                  // (sum() starts from int 0: 0 + x == x exactly)
+      for (int64_t k = 0; k < lens[i]; ++k) a += p[k];
+      out[i] = a;
+    }
+  };
+  if (nt == 1) { work(0); return MJX_OK; }
+  if (nt > HostPool::MAXW + 1) nt = HostPool::MAXW + 1;
+  {
+    const std::function<void(int)> fn = work;
+    if (host_pool().run(nt, fn)) return MJX_OK;
+  }
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  return MJX_OK;
+}
+
+// ---- asynchronous staging of one block of a rollout batch (r04): gather (+ fp64 -> fp32 conversion) group by group on the host
+// pools and the group's host-to-device copy queued right behind it -- all on a native thread, so the caller (a Python training
+// loop) gets control back at once and no interpreter lock is involved while 184 MB of rollouts move.  mjx_stage_wait joins.
+namespace {
+struct StageJob {
+  std::thread th;
+  int rc = MJX_OK;
+  std::string err;
+  std::vector<const void*> src;
+  std::vector<int64_t> offs;
+};
+}  // namespace
+
+int mjx_stage_async(void** job_out, const void* const* src, const int64_t* lens, int64_t count, int64_t row_elems, int src_itemsize,
+                    int hostcast, void* pinned, void* device_raw, float* device_f32, int64_t group_rows, int n_threads,
+                    int device_index, void* stream) {
+  if (!job_out || !src || !lens || count < 0 || row_elems <= 0 || (src_itemsize != 4 && src_itemsize != 8) || !pinned || !device_raw ||
+      group_rows <= 0 || (hostcast && src_itemsize != 8))
+    return fail(MJX_ERR_ARG, "bad arguments");
+  MJX_DEVICE_ENTRY();
+  StageJob* job = new StageJob();
+  job->src.assign(src, src + count);                       // (the caller's pointer / length arrays need not outlive the call)
+  job->offs.resize(count + 1);
+  job->offs[0] = 0;
+  for (int64_t i = 0; i < count; ++i) {
+    if (lens[i] < 0) { delete job; return fail(MJX_ERR_ARG, "negative length"); }
+    job->offs[i + 1] = job->offs[i] + lens[i];
+  }
+  const int64_t dst_item = hostcast ? 4 : src_itemsize;
+  job->th = std::thread([=] {
+    const int64_t* offs = job->offs.data();
+    const void* const* sp = job->src.data();
+    if (!MJX_HI_SET_DEVICE(device_index)) { job->rc = MJX_ERR_STATE; job->err = "hipSetDevice failed in the staging thread"; return; }
+    int64_t first = 0;
+    while (first < count) {
+      int64_t last = first;
+      while (last < count && offs[last] - offs[first] < group_rows) ++last;     // whole trajectories, at least group_rows rows
+      if (last == first) last = first + 1;
+      int rc;
+      if (hostcast) rc = mjx_host_gather_f64_f32((float*)pinned, (const double* const*)sp, offs, first, last - first, row_elems, n_threads);
+      else rc = mjx_host_gather(pinned, sp, offs, first, last - first, row_elems * src_itemsize, n_threads);
+      if (rc != MJX_OK) { job->rc = rc; job->err = mjx_last_error(); return; }
+      const int64_t lo = offs[first] * row_elems, hi = offs[last] * row_elems;   // elements
+      if (hi > lo) {
+        const char* what = nullptr;
+        const int e = MJX_HI_H2D_ASYNC((char*)device_raw + lo * dst_item, (const char*)pinned + lo * dst_item, (size_t)((hi - lo) * dst_item), stream, &what);
+        if (e != 0) { job->rc = e; job->err = std::string("hipMemcpyAsync: ") + (what ? what : "?"); return; }
+        if (device_f32 && !hostcast && src_itemsize == 8) {                     // raw fp64 block + its fp32 image (cast on the device)
+          rc = MJX_HI_CAST_F64_F32((const double*)device_raw + lo, hi - lo, device_f32 + lo, stream);
+          if (rc != MJX_OK) { job->rc = rc; job->err = mjx_last_error(); return; }
+        }
+      }
+      first = last;
+    }
+  });
+  *job_out = job;
+  return MJX_OK;
+}
+
+int mjx_stage_wait(void* job_) {
+  if (!job_) return fail(MJX_ERR_ARG, "null job");
+  StageJob* job = (StageJob*)job_;
+  if (job->th.joinable()) job->th.join();
+  const int rc = job->rc;
+  const std::string err = job->err;
+  delete job;
+  return rc == MJX_OK ? MJX_OK : fail(rc, "staging job failed: %s", err.c_str());
+}
+
+}  // extern "C"

@@ -1368,7 +1368,9 @@ struct LayerwiseWS {
     };
     auto launch8 = [&](auto ch) {             // 256 / 512 units: the eight-wave build (two waves per SIMD)
       constexpr int CH = decltype(ch)::value;
-      void (*const kern)(HeadArgs) = k_lw_head8<CH>;
+      // the delta product's contraction over the actions in ceil(m / 2) steps: 9 (m <= 18: Humanoid's 17), 12 (<= 24), else all 16
+      static const bool trim = [] { const char* e = getenv("MJX_LW_HEAD_KTRIM"); return !(e && e[0] == '0'); }();
+      void (*const kern)(HeadArgs) = !trim ? k_lw_head8<CH, 16> : m <= 18 ? k_lw_head8<CH, 9> : m <= 24 ? k_lw_head8<CH, 12> : k_lw_head8<CH, 16>;
       lw_set_dyn_lds((const void*)kern, (int)lw_head8_lds_bytes());
       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lw_head8_lds_bytes(), st, a);
     };

@@ -241,7 +241,12 @@ __global__ __launch_bounds__(256, 1) void k_lw_head(HeadArgs a) {
 // each other's memory latency.
 constexpr size_t lw_head8_lds_bytes() { return sizeof(float) * (size_t)(2 * 2 * LH_R * LH_LD + 2 * 2 * 32 * LH_LD + 4 * LH_R * LH_MS); }
 
-template <int CH>       // h = 256 * CH
+// KS: k-steps (two actions each) of the delta product of phase 2, whose contraction runs over the ACTIONS: ceil(m / 2) of the 16
+// steps a 32-action padding allows are enough -- the fragments of the actions >= m are zero (r05: 9 steps at the 17 actions of
+// BASELINE configs[3] instead of 16: 14 of a tile's 128 matrix instructions per wave gone, and as many weight-fragment loads).
+// Phase 1 (N dimension = actions) and the gW3 product (M dimension = actions) keep their 32-wide padding: the 32 x 32 matrix
+// instruction has no narrower output.
+template <int CH, int KS = 16>       // h = 256 * CH
 __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lhs[];
   float* Abuf = lhs;                                   // [pair][buf][64][36]
@@ -364,11 +369,11 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
       for (int i = 0; i < CH; ++i) {
         const int cb = 32 * (8 * i + wv);
         __builtin_amdgcn_sched_barrier(0);
-        float w3f[16];
+        float w3f[KS];
         uint32_t w3o = ((uint32_t)hi * (uint32_t)h + (uint32_t)j) * 4u;     // lane part of W3[2 s + hi][cb + j]; laundered: keeps these loads
         asm volatile("" : "+v"(w3o));                                       // inside the tile loop (hoisted, CH x 16 fragments stay live: spills)
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+        for (int s = 0; s < KS; ++s)
           w3f[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rW3, (int)w3o, (int)((uint32_t)(2 * s * h + cb) * 4u), 0));   // rows >= m: 0
 #pragma unroll 1
         for (int rb = 0; rb < 2; ++rb) {
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
           }
           f32x16 dacc = (f32x16)(0.f);
 #pragma unroll
-          for (int s = 0; s < 16; ++s) dacc = MJX_MFMA(mud[(32 * rb + j) * LH_MS + 2 * s + hi], w3f[s], dacc);
+          for (int s = 0; s < KS; ++s) dacc = MJX_MFMA(mud[(32 * rb + j) * LH_MS + 2 * s + hi], w3f[s], dacc);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float dv = dacc[r] * fmaf(-y[r], y[r], 1.0f);

@@ -8,6 +8,9 @@ from mjrl_amd import _lib
 _lib.LIB_PATH = os.environ.get("MJX_LIB", _lib.LIB_PATH)
 from mjrl_amd.engine import UpdateEngine
 import bench
+json_out = None
+if "--json" in sys.argv:
+    k = sys.argv.index("--json"); json_out = sys.argv[k + 1]; del sys.argv[k:k + 2]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 theta0 = bench.initial_params()
 obs, act, adv = bench.synth_shard(0, 1)
@@ -56,3 +59,11 @@ for _ in range(10):
 _lib.check(eng.lib.mjx_set_clock_buffer(eng.ctx, None))
 print("%s  fvp+reduce ms: min %.4f median %.4f | workgroup 0: %d cycles, %.3f GHz" % (os.environ.get("MJX_LIB", "product"), min(best), sorted(best)[len(best) // 2],
                                                                              int(np.median(cyc)), float(np.median(ghz))))
+if json_out:
+    import json
+    json.dump({"what": "cached Fisher-vector-product kernel (+ its reduction launch) on bench.py's 1M-timestep batch: HIP-event time of "
+                       "blocks of 20 back-to-back products, and workgroup 0's own clock (mjx_set_clock_buffer: s_memtime cycles over "
+                       "s_memrealtime 100 MHz ticks -> sustained shader clock) for 10 single launches",
+               "fvp_plus_reduce_ms_blocks_of_20": best, "fvp_plus_reduce_ms_min": min(best), "workgroup0_cycles": cyc, "sustained_GHz": [float(x) for x in ghz],
+               "workgroup0_ms_from_cycles": [c / (g * 1e6) for c, g in zip(cyc, ghz)], "K1_plus_reduce_ms": k1, "K3_plus_reduce_ms": k3},
+              open(json_out, "w"), indent=1)
