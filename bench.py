@@ -465,31 +465,40 @@ def user_level_measurements():
                       "ingest.trusted_iteration() like BatchREINFORCE.train_step; the median iteration's stage times")
     out["iteration"] = it_out
     ingest.drop_shared()
-    # ---- the MLP-baseline trainer alone
-    d_in, steps = N_OBS + 4, 8000
-    Nf = 64 * (steps + 1)
+    # ---- the MLP-baseline trainer alone: HalfCheetah's 17 + 4 inputs (one workgroup) and Humanoid's 376 + 4 (BASELINE configs[3]:
+    # eight workgroups of the same persistent kernel, one grid barrier per 32-sample half -- csrc/mlp_fit.h MULTI)
     dev = torch.device("cuda", torch.cuda.current_device())
     from mjrl_amd import _lib
     lib = _lib.load()
-    r2 = np.random.RandomState(0)
-    feat = torch.from_numpy(r2.randn(Nf, d_in).astype(np.float32)).to(dev)
-    y = torch.from_numpy(r2.randn(Nf).astype(np.float32)).to(dev)
-    Pn = 128 * d_in + 128 + 128 * 128 + 128 + 128 + 1
-    params = torch.from_numpy((0.1 * r2.randn(Pn)).astype(np.float32)).to(dev)
-    m_, v_ = torch.zeros(Pn, device=dev), torch.zeros(Pn, device=dev)
-    perm = torch.from_numpy(r2.permutation(Nf).astype(np.int32)).to(dev)
-    loss = torch.zeros(32, dtype=torch.float64, device=dev)
-    hid = (ctypes.c_int * 2)(128, 128)
-    tt = []
-    for rep in range(3):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        check(lib.mjx_mlp_fit_adam(ptr(feat), ptr(y), Nf, d_in, hid, 2, ptr(params), ptr(m_), ptr(v_), 0, ptr(perm), 1, 64, 1e-3, 0.0,
-                                   ptr(loss), None))
-        torch.cuda.synchronize(); tt.append(time.perf_counter() - t0)
-    out["mlp_fit_us_per_step"] = {"value": 1e6 * min(tt) / steps, "steps": steps, "inputs": d_in, "hidden": [128, 128], "batch": 64,
+    fit_out = {}
+    for d_in, steps in ((N_OBS + 4, 8000), (376 + 4, 4000)):
+        Nf = 64 * (steps + 1)
+        r2 = np.random.RandomState(0)
+        feat = torch.from_numpy(r2.randn(Nf, d_in).astype(np.float32)).to(dev)
+        y = torch.from_numpy(r2.randn(Nf).astype(np.float32)).to(dev)
+        Pn = 128 * d_in + 128 + 128 * 128 + 128 + 128 + 1
+        params = torch.from_numpy((0.1 * r2.randn(Pn)).astype(np.float32)).to(dev)
+        m_, v_ = torch.zeros(Pn, device=dev), torch.zeros(Pn, device=dev)
+        perm = torch.from_numpy(r2.permutation(Nf).astype(np.int32)).to(dev)
+        loss = torch.zeros(32, dtype=torch.float64, device=dev)
+        hid = (ctypes.c_int * 2)(128, 128)
+        tt = []
+        for rep in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            check(lib.mjx_mlp_fit_adam(ptr(feat), ptr(y), Nf, d_in, hid, 2, ptr(params), ptr(m_), ptr(v_), 0, ptr(perm), 1, 64, 1e-3, 0.0,
+                                       ptr(loss), None))
+            torch.cuda.synchronize(); tt.append(time.perf_counter() - t0)
+        fit_out[d_in] = 1e6 * min(tt) / steps
+        del feat, y, perm
+    d21 = N_OBS + 4
+    out["mlp_fit_us_per_step"] = {"value": fit_out[d21], "steps": 8000, "inputs": d21, "hidden": [128, 128], "batch": 64,
                                   "kernel": "k_mlp_fit1p<128> (csrc/mlp_fit.h): one persistent workgroup, the whole Adam chain in one launch, one pass per 64-row "
                                             "step, Adam moments register-resident, pinned LDS addressing (r03: k_mlp_fit<128,1>, 23.3 us)",
-                                  "per_1M_timesteps_2_epochs_s": 1e-6 * (1e6 * min(tt) / steps) * 2 * (N_TRAJ * T // 64 - 1)}
+                                  "per_1M_timesteps_2_epochs_s": 1e-6 * fit_out[d21] * 2 * (N_TRAJ * T // 64 - 1),
+                                  "at_380_inputs": {"value": fit_out[380], "steps": 4000, "workgroups": 8,
+                                                    "kernel": "k_mlp_fit<128,2,REGMOM,MULTI>: 8 workgroups (48-feature slices of the first layer), partial pre-activations "
+                                                              "exchanged through an uncached block, one grid barrier per 32-sample half, the rest of the step replicated "
+                                                              "(r04: ~14 launches per step, 115-155 us)"}}
     return out
 
 

@@ -105,6 +105,11 @@ class MLPBaseline:
         n = d["params"].size
         d["params"], d["adam_m"], d["adam_v"] = (h["pmv"][i * pend.seg:i * pend.seg + n].copy() for i in range(3))
         d["epoch_losses"] = list(h["losses"][:self.epochs].astype(np.float64) / max(pend.steps, 1))
+        if self.epochs > 0 and np.isnan(h["losses"][:self.epochs]).any() and pend.num_samples > 0:
+            # the several-workgroup trainer (csrc/mlp_fit.h, MULTI) poisons the losses when a workgroup waited ~2 s for another
+            from .._lib import MjxError
+            raise MjxError("MLPBaseline.fit: non-finite epoch losses (a workgroup of the persistent trainer gave up waiting for "
+                           "the others, or the fit diverged); parameters of this fit are not to be trusted")
         pend.device_ms = float(pend.start_ev.elapsed_time(pend.end_ev))
         if pend.returns is not None:
             r = pend.returns[:pend.num_samples]

@@ -533,6 +533,50 @@ int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, con
       return MJX_OK;
     }
   }
+  {
+    // r05: wider inputs (Ant 111 + 4, Humanoid 376 + 4 = BASELINE configs[3]) on SEVERAL workgroups of the same persistent trainer:
+    // feature slices of 48, one workgroup (= one CU) per slice, one grid barrier per 32-sample half (k_mlp_fit<.., MULTI>, mlp_fit.h)
+    const char* force = getenv("MJX_MLP_FIT_LAUNCHES");
+    const char* wide = getenv("MJX_FIT_WIDE");
+    const int64_t steps_ = N / batch - 1;
+    constexpr int FS = 48, GMAX = 16;
+    const int G = (d_in + FS - 1) / FS;
+    if (!(force && force[0] == '1') && !(wide && wide[0] == '0') && n_hidden == 2 && hidden[0] == 128 && hidden[1] == 128 && batch == 64 &&
+        d_in > 48 && G <= GMAX && steps_ > 0 && epochs > 0) {
+      MlpFitLayout<128> Lw(FS, true);
+      static thread_local Scratch mvws;
+      const int64_t P = (int64_t)128 * d_in + 128 + 128 * 128 + 128 + 128 + 1;
+      if (int rc = get_scratch(mvws, (size_t)G * P * 2 * sizeof(float))) return rc;
+      // the exchange block and the arrival counter: UNCACHED device memory (stores are acknowledged by memory, loads bypass the
+      // per-XCD L2s -- the workgroups of one grid sit on different XCDs), allocated once per thread and device
+      static thread_local std::vector<std::pair<int, char*>> xch_by_dev;
+      int dev = 0;
+      HIPCHK(hipGetDevice(&dev));
+      char* xch = nullptr;
+      for (auto& e : xch_by_dev) if (e.first == dev) xch = e.second;
+      const size_t xbytes = (size_t)2 * GMAX * 128 * 32 * sizeof(float);
+      if (!xch) {
+        void* q = nullptr;
+        HIPCHK(hipExtMallocWithFlags(&q, xbytes + 256, hipDeviceMallocUncached));
+        xch = (char*)q;
+        xch_by_dev.push_back({dev, xch});
+      }
+      HIPCHK(hipMemsetAsync(xch + xbytes, 0, 256, st));                       // the counter (the exchange block needs no clearing)
+      MlpFitArgs a{feat, y, perm, N, d_in, epochs, steps_, params, m, v, (float*)mvws.p, step0, lr, wd, epoch_loss_out};
+      a.xch = (float*)xch; a.bar = (unsigned*)(xch + xbytes); a.G = G; a.FS = FS;
+      static thread_local bool configured = false;
+      if (!configured) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        configured = true;
+      }
+      const char* rm = getenv("MJX_FIT_REGMOM");
+      if (!(rm && rm[0] == '0')) hipLaunchKernelGGL((k_mlp_fit<128, 2, true, true>), dim3(G), dim3(256), Lw.bytes(), st, a);
+      else hipLaunchKernelGGL((k_mlp_fit<128, 2, false, true>), dim3(G), dim3(256), Lw.bytes(), st, a);
+      HIPCHK(hipGetLastError());
+      return MJX_OK;
+    }
+  }
   MlpRegressor net; net.init(d_in, hidden, n_hidden);
   const int L = net.nL(), bs = batch;
   size_t hsum = 0; for (int i = 0; i < n_hidden; ++i) hsum += hidden[i];

@@ -81,6 +81,10 @@ struct MlpFitArgs {
   int64_t step0;           // Adam steps taken before this call
   float lr, wd;
   double* epoch_loss;      // [epochs] sum over steps of the minibatch MSE
+  // ---- several workgroups (k_mlp_fit<.., MULTI = true>: inputs wider than one workgroup's LDS holds; see the kernel)
+  float* xch = nullptr;    // UNCACHED exchange block [2 parities][G][H][32]: every workgroup's partial first-layer pre-activations
+  unsigned* bar = nullptr; // UNCACHED arrival counter (zero at launch)
+  int G = 1, FS = 0;       // workgroups; features per workgroup (the last one takes what is left + the bias column)
 };
 
 template <int H>
@@ -112,34 +116,53 @@ struct MlpFitLayout {
 // loaded once before the first step, written back after the last -- instead of streaming 2 x 156 KB through the CU's L2 path in
 // every step (r02 measured the Adam phase as bound by exactly that traffic, not by its arithmetic).  The compute phase needs
 // ~250 of the 512 registers of a one-wave-per-SIMD kernel; the pairs take 166 more (the allocator parks them in AGPRs).
-template <int H, int NF1 = 1, bool REGMOM = false>
+//
+// MULTI (r05): inputs wider than one workgroup can hold (the 55-input limit above: Ant's 115, Humanoid's 380 = BASELINE configs[3])
+// used to fall to ~14 launches per step.  Now G workgroups -- one per CU, launched as ONE grid -- share a step: workgroup g keeps
+// the first-layer weights (and their Adam moments) of features [g FS, (g + 1) FS) in its LDS, forms the partial pre-activations
+// W1[:, slice] x[slice] of every half, publishes them in an uncached exchange block, and after one grid barrier every workgroup
+// sums all G partials IN WORKGROUP ORDER -- the same bits everywhere.  From there on the step is REPLICATED: every workgroup
+// runs layers 2 / 3, the loss, delta2, delta1 and the Adam update of W2 / b2 / W3 / b3 on identical data with identical
+// instructions (the copies stay bit-identical; no second exchange), and updates its own slice of W1 from delta1 x[slice]^T.
+// One barrier per 32-sample half; the exchange block is double-buffered by barrier parity (a workgroup is at most one phase
+// ahead of another).  The last workgroup carries the bias column b1.  A wait that exceeds ~2 s poisons the epoch losses with NaN
+// and leaves (no hung GPU if a workgroup never gets a CU).
+template <int H, int NF1 = 1, bool REGMOM = false, bool MULTI = false>
 __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   static_assert(H == 128, "wave w owns unit tile w: 4 waves x 32 units");
   using LT = MlpFitLayout<H>;
   constexpr int ST = LT::ST, S2 = LT::S2, NT = H / 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const LT L(A.d_in, NF1 > 1);
+  const int g_id = MULTI ? (int)blockIdx.x : 0;
+  const int dG = A.d_in;                                              // width of a feature row / of a W1 row in global memory
+  const int f_off = MULTI ? g_id * A.FS : 0;                          // first feature of this workgroup's slice
+  const bool has_b1 = !MULTI || g_id == A.G - 1;                      // who carries the bias column of layer 1
+  const LT L(MULTI ? A.FS : A.d_in, NF1 > 1);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 31, hi = lane >> 5;
-  const int d_in = A.d_in, K1 = L.K1, S1 = L.S1;
+  const int d_in = MULTI ? (dG - f_off < A.FS ? dG - f_off : A.FS) : dG;      // LOCAL width from here on
+  const int K1 = L.K1, S1 = L.S1;
+  unsigned phase = 0;                                                 // grid barriers passed (MULTI)
+  bool timed_out = false;
   float* sW1 = lds + L.oW1; float* sW2 = lds + L.oW2; float* sW3 = lds + L.oW3; float* sB2 = lds + L.oB2;
   float* sB3 = sB2 + H;
   float* xs = lds + L.oXS; float* xT = lds + L.oXT; float* h1T = lds + L.oH1; float* h2T = lds + L.oH2; float* d2T = lds + L.oD2;
   float* sY = lds + L.oY; float* sPart = lds + L.oPART; float* sDY = lds + L.oDY;
-  const int64_t oW1g = 0, oB1g = (int64_t)H * d_in, oW2g = oB1g + H, oB2g = oW2g + (int64_t)H * H, oW3g = oB2g + H, oB3g = oW3g + H;
+  const int64_t oW1g = 0, oB1g = (int64_t)H * dG, oW2g = oB1g + H, oB2g = oW2g + (int64_t)H * H, oW3g = oB2g + H, oB3g = oW3g + H;
 
   // ---- load parameters into LDS (b1 rides as the "ones" column of W1)
   for (int i = tid; i < L.TOTAL; i += 256) lds[i] = 0.f;
   __syncthreads();
   for (int i = tid; i < H * (d_in + 1); i += 256) {
     int u = i / (d_in + 1), f = i - u * (d_in + 1);
-    sW1[u * S1 + f] = (f < d_in) ? A.params[oW1g + (int64_t)u * d_in + f] : A.params[oB1g + u];
+    sW1[u * S1 + f] = (f < d_in) ? A.params[oW1g + (int64_t)u * dG + f_off + f] : (has_b1 ? A.params[oB1g + u] : 0.f);
   }
   for (int i = tid; i < H * H; i += 256) sW2[(i / H) * S2 + (i % H)] = A.params[oW2g + i];
   for (int i = tid; i < H; i += 256) { sW3[i] = A.params[oW3g + i]; sB2[i] = A.params[oB2g + i]; }
   if (tid == 0) sB3[0] = A.params[oB3g];
-  if (tid < 32) { if (NF1 == 1) xs[tid * S1 + d_in] = 1.0f; xT[d_in * ST + tid] = 1.0f; }
+  if (tid < 32) { if (NF1 == 1) xs[tid * S1 + d_in] = 1.0f; xT[d_in * ST + tid] = has_b1 ? 1.0f : 0.f; }
   const int64_t Ptot = oB3g + 1;
-  for (int64_t i = tid; i < Ptot; i += 256) { A.mv[2 * i] = A.m[i]; A.mv[2 * i + 1] = A.v[i]; }
+  float* const mvbase = A.mv + (MULTI ? (int64_t)g_id * 2 * Ptot : 0);          // (MULTI: every workgroup its own copy of the pairs)
+  for (int64_t i = tid; i < Ptot; i += 256) { mvbase[2 * i] = A.m[i]; mvbase[2 * i + 1] = A.v[i]; }
   __syncthreads();
 
   const float b1c = 0.9f, b2c = 0.999f, eps = 1e-8f;
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   };
   auto gather_load = [&]() {
 #pragma unroll
-    for (int c = 0; c < GL; ++c) gx[c] = A.feat[gs[c] >= 0 ? (int64_t)gidx[c] * d_in + gf[c] : 0];
+    for (int c = 0; c < GL; ++c) gx[c] = A.feat[gs[c] >= 0 ? (int64_t)gidx[c] * dG + f_off + gf[c] : 0];
     gy = A.y[gyi];
   };
   auto gather_store = [&]() {
@@ -184,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   // weights, its 16 W1 / b1 entries, its b2 / W3 / b3 entry -- are requested at the top of every Adam phase (the backward pass's
   // registers are free by then), so the L2 latency is paid once per step and not once per block; then update, write the weight to
   // LDS and the pair back.  Threads that do not own an entry of a block read a valid dummy pair and store nothing.
-  f32x2* __restrict__ MV = (f32x2*)A.mv;
+  f32x2* __restrict__ MV = (f32x2*)mvbase;
   const int64_t gbase2 = oW2g + (int64_t)(32 * w + 4 * hi) * H + j;
   f32x2* __restrict__ mvW2 = MV + gbase2;
   float* pW2 = sW2 + (32 * w + 4 * hi) * S2 + j;
@@ -197,9 +220,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   for (int fb = 0; fb < NF1; ++fb) {
     const int f = 32 * fb + j;
     const bool isw = f < d_in;
-    own1[fb] = f <= d_in;
-    stg[fb] = isw ? d_in : 1;
-    const int64_t gbase1 = isw ? oW1g + (int64_t)(32 * w + 4 * hi) * d_in + f : oB1g + 32 * w + 4 * hi;
+    own1[fb] = isw || (f == d_in && has_b1);
+    stg[fb] = isw ? dG : 1;
+    const int64_t gbase1 = isw ? oW1g + (int64_t)(32 * w + 4 * hi) * dG + f_off + f : oB1g + 32 * w + 4 * hi;
     mvW1[fb] = MV + (own1[fb] ? gbase1 : 0);
     pW1[fb] = sW1 + (32 * w + 4 * hi) * S1 + (isw ? f : d_in);
   }
@@ -274,6 +297,49 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
           else b = f32x2{xT[f0 * ST + j], xT[(f0 + 1) * ST + j]};
           z1 = MJX_MFMA(a.x, b.x, z1);
           z1 = MJX_MFMA(a.y, b.y, z1);
+        }
+        if constexpr (MULTI) {
+          // this workgroup's partial W1[:, slice] x[slice] -> its slot of the exchange block; one grid barrier; the sum of all
+          // G partials in workgroup order (identical bits on every workgroup: the replicated rest of the step depends on it)
+          // slot layout [wave][quad q][lane][4]: register r = 4 q + t of lane `lane` of wave w -- the same matrix element on every
+          // workgroup -- so a lane moves its 16 values as four 16-byte accesses (coalesced 1 KB per wave and quad) instead of
+          // sixteen 4-byte ones: the first version read G x 16 dwords per lane one after the other, 7 us per workgroup and step
+          const size_t slot = (size_t)H * 32;
+          f32x4* xo = (f32x4*)(A.xch + ((size_t)(phase & 1u) * (size_t)A.G + (size_t)g_id) * slot) + (size_t)(w * 4) * 64 + lane;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xo[q * 64] = f32x4{z1[4 * q], z1[4 * q + 1], z1[4 * q + 2], z1[4 * q + 3]};
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // uncached stores: acknowledged by memory, nothing holds them back
+          __syncthreads();
+          if (tid == 0) {
+            __hip_atomic_fetch_add(A.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)A.G * (phase + 1u);
+            const unsigned long long t0 = wall_clock64();             // 100 MHz
+            while ((int)(__hip_atomic_load(A.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+              __builtin_amdgcn_s_sleep(1);
+              if (timed_out || wall_clock64() - t0 > 200000000ull) { timed_out = true; break; }      // ~2 s: give up (once), poison the losses
+            }
+          }
+          __syncthreads();
+          const f32x4* xi = (const f32x4*)(A.xch + (size_t)(phase & 1u) * (size_t)A.G * slot) + (size_t)(w * 4) * 64 + lane;
+          asm volatile("" : "+v"(xi) :: "memory");                    // (a fresh look at memory every phase: nothing cached in registers)
+          f32x16 zs = (f32x16)(0.f);
+          for (int g0 = 0; g0 < A.G; g0 += 4) {                       // four workgroups' partials in flight, summed in workgroup order
+            f32x4 t[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int gg = g0 + u < A.G ? g0 + u : g0;              // (surplus entries re-read a valid slot and are not added)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) t[u][q] = xi[(size_t)gg * (slot / 4) + q * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (g0 + u < A.G) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { zs[4 * q] += t[u][q].x; zs[4 * q + 1] += t[u][q].y; zs[4 * q + 2] += t[u][q].z; zs[4 * q + 3] += t[u][q].w; }
+              }
+          }
+          z1 = zs;
+          ++phase;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -550,7 +616,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
       __syncthreads();
       { const int hb = 0; MJX_FIT_STAMP(10); }
     }
-    if (tid == 0) A.epoch_loss[ep] = ep_loss;
+    if (tid == 0 && g_id == 0) A.epoch_loss[ep] = ep_loss;
+    if (MULTI && tid == 0 && timed_out) A.epoch_loss[ep] = (double)__builtin_nanf("");      // (any workgroup that gave up says so)
   }
   // ---- write the trained parameters and the moments back
   if constexpr (REGMOM) {
@@ -575,14 +642,26 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
     if (ownb3) MV[gb3i] = qb3;
   }
   __syncthreads();
-  for (int64_t i = tid; i < Ptot; i += 256) { A.m[i] = A.mv[2 * i]; A.v[i] = A.mv[2 * i + 1]; }
+  // (MULTI: a workgroup writes what it alone holds -- its W1 slice, b1 on the last one -- and workgroup 0 the replicated rest)
+  for (int64_t i = tid; i < Ptot; i += 256) {
+    bool mine = true;
+    if constexpr (MULTI) {
+      if (i < oB1g) { const int f = (int)(i % dG); mine = f >= f_off && f < f_off + d_in; }
+      else if (i < oW2g) mine = has_b1;
+      else mine = g_id == 0;
+    }
+    if (mine) { A.m[i] = mvbase[2 * i]; A.v[i] = mvbase[2 * i + 1]; }
+  }
   for (int i = tid; i < H * (d_in + 1); i += 256) {
     int u = i / (d_in + 1), f = i - u * (d_in + 1);
-    if (f < d_in) A.params[oW1g + (int64_t)u * d_in + f] = sW1[u * S1 + f]; else A.params[oB1g + u] = sW1[u * S1 + d_in];
+    if (f < d_in) A.params[oW1g + (int64_t)u * dG + f_off + f] = sW1[u * S1 + f];
+    else if (has_b1) A.params[oB1g + u] = sW1[u * S1 + d_in];
   }
-  for (int i = tid; i < H * H; i += 256) A.params[oW2g + i] = sW2[(i / H) * S2 + (i % H)];
-  for (int i = tid; i < H; i += 256) { A.params[oW3g + i] = sW3[i]; A.params[oB2g + i] = sB2[i]; }
-  if (tid == 0) A.params[oB3g] = sB3[0];
+  if (!MULTI || g_id == 0) {
+    for (int i = tid; i < H * H; i += 256) A.params[oW2g + i] = sW2[(i / H) * S2 + (i % H)];
+    for (int i = tid; i < H; i += 256) { A.params[oW3g + i] = sW3[i]; A.params[oB2g + i] = sB2[i]; }
+    if (tid == 0) A.params[oB3g] = sB3[0];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
