@@ -701,6 +701,64 @@ def test_mlp_baseline_vs_reference():
     np.testing.assert_array_equal(bl2.predict(paths[0]), bl.predict(paths[0]))
 
 
+@pytest.mark.parametrize("n", [60, 111, 376])
+def test_wide_mlp_baseline_vs_the_reference_run_live(n):
+    """MLPBaseline at observation widths beyond one workgroup's LDS (Ant 111, Humanoid 376 = BASELINE configs[3]; 60 + 4 = two
+    workgroups): the several-workgroup persistent trainer (csrc/mlp_fit.h, MULTI) through the host class against the UNMODIFIED
+    reference's MLPBaseline (mjrl/baselines/mlp_baseline.py:61-105, utils/optimize_model.py:7-36; oracle/ref_loader: sources or staged
+    bytecode) run here on the CPU with the same seeds -- same initial weights, same predictions, and after 2 epochs x 39 Adam steps
+    on the same permutations the same parameters to fp32 round-off."""
+    import torch
+    from mjrl_amd.baselines.mlp_baseline import MLPBaseline
+    from mjrl_amd.utils import process_samples
+    from oracle import ref_loader
+    if ref_loader.install() is None:
+        pytest.skip("reference not available")
+    from mjrl.baselines.mlp_baseline import MLPBaseline as RefBaseline
+    from mjrl.utils import process_samples as ref_ps
+    rng = np.random.RandomState(n)
+    w = rng.randn(n) / np.sqrt(n)
+    paths = []
+    for _ in range(20):
+        obs = np.cumsum(0.1 * rng.randn(128, n), axis=0) + rng.randn(n)
+        paths.append(dict(observations=obs, rewards=np.tanh(obs @ w) + 0.1 * rng.randn(128), terminated=False))
+    ref_paths = [dict(p) for p in paths]
+    ref_ps.compute_returns(ref_paths, 0.995)
+    process_samples.compute_returns(paths, 0.995)
+    spec = type("Spec", (), dict(observation_dim=n, action_dim=3, horizon=128))
+    kw = dict(reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3)
+    flat_of = lambda b: np.concatenate([p.data.numpy().ravel() for p in b.model.parameters()])
+    # the yardstick: how far the REFERENCE lands from itself when its initial weights move by 1e-7 (a ReLU / Adam chain is stable
+    # on most data -- 1e-7 -> 1e-7 -- and chaotic on some: the width-111 instance of this test ends 1.3e-3 apart, a unit's sign
+    # flips and Adam's normalised steps amplify it)
+    torch.manual_seed(4); np.random.seed(4)
+    twin = RefBaseline(spec, **kw)
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for p_ in twin.model.parameters():
+            p_.mul_(1 + 1e-7 * torch.randn(p_.shape, generator=gen))
+    np.random.seed(11)
+    twin.fit([dict(p) for p in ref_paths])
+    torch.manual_seed(4); np.random.seed(4)
+    ref = RefBaseline(spec, **kw)
+    torch.manual_seed(4); np.random.seed(4)
+    bl = MLPBaseline(spec, **kw)
+    ref_flat = lambda: flat_of(ref)
+    assert np.array_equal(bl.params, ref_flat())
+    np.testing.assert_allclose(bl.predict_batch(paths), np.concatenate([ref.predict(p) for p in ref_paths]), rtol=2e-5, atol=2e-6)
+    np.random.seed(11)
+    r0, r1 = ref.fit(ref_paths, return_errors=True)
+    np.random.seed(11)
+    e0, e1 = bl.fit(paths, return_errors=True)
+    sens = rel(flat_of(twin), ref_flat())
+    print("width %d: parameters %.2e from the reference's after 78 Adam steps (the reference from itself under a 1e-7 perturbation: %.2e)"
+          % (n, rel(bl.params, ref_flat()), sens))
+    assert abs(e0 - r0) < 2e-6 * max(1.0, abs(r0)) and abs(e1 - r1) < (5e-4 + 10 * sens) * abs(r1), (e0, r0, e1, r1)
+    assert rel(bl.params, ref_flat()) < max(2e-4, 10 * sens), (rel(bl.params, ref_flat()), sens)
+    assert bl.adam_steps == 2 * (20 * 128 // 64 - 1)
+    np.testing.assert_allclose(bl.predict(paths[0]), ref.predict(ref_paths[0]), rtol=2e-3 + 10 * sens, atol=2e-3 + 10 * sens)
+
+
 def test_mlp_baseline_fit_quality_at_iteration_scale_vs_reference():
     """The persistent minibatch-Adam trainer against the UNMODIFIED reference at iteration scale (300 000 timesteps, 2 epochs =
     9 372 Adam steps on the same NumPy permutations; tests/golden/make_golden_mlpfit.py): after thousands of chaotic ReLU / Adam
