@@ -746,6 +746,16 @@ def drop_shared_batch():
                 ent.pop("derived", None)
 
 
+def release_if_standalone():
+    """end of a train_from_paths that runs on its own (not inside train_step's trusted_iteration, which drops the batch itself
+    once predict, update and fit have shared the upload): let go of the host trajectories NOW.  Left in the registry they are
+    released when the NEXT batch replaces them -- inside the next call, with both batches alive while the new one is allocated --
+    and that next call ran 20 ms instead of 7.8 (every other call of a back-to-back loop: tools/probe_e2e_outlier.py; the
+    release itself takes 0.4 ms here)."""
+    if not _trusted():
+        drop_shared_batch()
+
+
 def drop_shared():
     """forget the staged batches (tests; releasing device memory)"""
     with _SHARED_LOCK:
