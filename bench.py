@@ -399,7 +399,7 @@ def user_level_measurements():
                      terminated=False) for p in base]
     ts = []
     b = None
-    for it in range(7):
+    for it in range(10):
         # like train_step, whose rollouts die when it returns: the previous batch is gone before the next one is allocated.  (With
         # both alive the new arrays land in fresh mappings instead of recycled memory and every other call ran 12-20 ms instead
         # of 8: tools/probe_e2e_outlier.py; r05: train_from_paths also lets go of the staging registry's references itself.)
@@ -408,12 +408,13 @@ def user_level_measurements():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         agent.train_from_paths(b)
         torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
-    ts = sorted(ts[2:])
-    out["end_to_end"] = {"npg_train_from_paths_ms_median": ts[len(ts) // 2], "ms_min": ts[0], "ms_each_sorted": ts,
+    in_order = [round(x, 3) for x in ts]
+    ts = sorted(ts[4:])                       # (the first calls allocate page-locked blocks and grow the hand-out pool)
+    out["end_to_end"] = {"npg_train_from_paths_ms_median": ts[len(ts) // 2], "ms_min": ts[0], "ms_each_sorted": ts, "ms_all_calls_in_order": in_order,
                          "updates_per_s": 1e3 / ts[len(ts) // 2],
                          "what": "NPG.train_from_paths on 1000 x 1000-step fp64 host trajectories (184 MB): path statistics || page-locked "
                                  "staging + upload (fp64 -> fp32 on the gather threads), mjx_npg_update, read-back, policy.set_param_values; "
-                                 "median of 5 fresh batches after 2 warm-ups"}
+                                 "median of 6 fresh batches after 4 warm-ups"}
     agent.engine.close()
     del agent, base
     # ---- a whole post-sampling iteration
