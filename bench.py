@@ -375,7 +375,7 @@ def user_level_measurements():
     """What a caller of the mjrl-shaped classes sees at the metric's size (SURVEY 8d "One update" (ii)), all
     from fp64 HOST trajectories -- PCIe-inclusive, so none of this is `value`:
     * end_to_end: one NPG.train_from_paths (host path statistics || page-locked staging + upload, the update, parameter
-      read-back + set_param_values), median of 5 fresh batches after 2 warm-ups;
+      read-back + set_param_values), median of 6 fresh batches after 4 warm-ups;
     * iteration: everything train_step does after sampling (batch_reinforce.py:93-114: returns, baseline prediction + GAE, the
       update, the baseline fit) with the quadratic and with the MLP baseline (2 epochs, batch 64: policy_opt_job_script's setting);
     * mlp_fit_us_per_step: the persistent minibatch-Adam trainer alone (k_mlp_fit, 21 inputs, 8 000 steps, best of 3)."""
