@@ -54,9 +54,7 @@ class PPO(BatchREINFORCE):
     def train_from_paths(self, paths):
         """ppo_clip.py:59-110"""
         from ..engine import _dist
-        if _dist() is not None:
-            raise NotImplementedError("PPO's minibatch epochs run on one rank (every rank would draw its own minibatches and the "
-                                      "parameter copies would drift apart); shard trajectories with NPG / TRPO / DAPG instead")
+        from ..utils import ranks
         base_stats = self._process_and_bind(paths)             # concatenation-free ingestion, whitened advantages, statistics
         if self.save_logs:
             self.log_rollout_statistics(paths)
@@ -64,17 +62,26 @@ class PPO(BatchREINFORCE):
         torch = eng.torch
         surr_before = eng.eval_surr_kl()[0]
         ts = timer.time()
-        num_samples = eng.N_local
+        # One process per GPU (r05): minibatch Adam is a sequential chain over rows drawn from the WHOLE batch, not a sum over
+        # samples -- like the MLP baseline's fit, every rank gathers all ranks' fp32 rows (rank order = the one-process batch) and
+        # runs the IDENTICAL chain from the same index draws (the last rank's: it sampled the batch's last episodes, so its NumPy
+        # stream stands where a single process's would; every rank draws, the streams advance alike).  The copies stay
+        # bit-identical; surrogate / KL before and after are rank sums over the shards as everywhere else.
+        obs_b, act_b, adv_b = eng.obs, eng.act, eng.adv
+        if _dist() is not None:
+            obs_b, act_b, adv_b = (ranks.gather_rows(t[:eng.N_local]).contiguous() for t in (eng.obs, eng.act, eng.adv))
+        num_samples = int(obs_b.shape[0])
         steps = self.epochs * int(num_samples / self.mb_size)
         if steps > 0:
             idx = np.stack([np.random.choice(num_samples, size=self.mb_size) for _ in range(steps)]).astype(np.int32)
+            idx = ranks.broadcast_host(idx, src=-1)
             if self._adam is None:
                 self._adam = [torch.zeros_like(eng.theta_new), torch.zeros_like(eng.theta_new), 0]
             didx = upload(eng.backend, idx)
             # reference_aliasing: reproduce what the reference computes once its new / old network tensors share memory
             # (policies/gaussian_mlp.py set_param_values); False = the old policy stays fixed during the epochs
             track = int(bool(self.reference_aliasing and getattr(self.policy, "reference_new_old_alias", False)))
-            check(eng.lib.mjx_policy_minibatch_adam(eng.ctx, 2, ptr(eng.obs), ptr(eng.act), ptr(eng.adv), ptr(didx), steps,
+            check(eng.lib.mjx_policy_minibatch_adam(eng.ctx, 2, ptr(obs_b), ptr(act_b), ptr(adv_b), ptr(didx), steps,
                                                     self.mb_size, ptr(eng.theta_new), ptr(eng.tr_new), ptr(eng.theta_old),
                                                     ptr(eng.tr_old), track, ptr(self._adam[0]), ptr(self._adam[1]), self._adam[2],
                                                     self.learn_rate, self.clip_coef, None, eng.stream()))

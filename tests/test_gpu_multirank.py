@@ -119,3 +119,23 @@ def test_a_corrupted_peer_transport_is_rejected_before_the_first_update(tmp_path
     assert bool(a["ranks_identical"][0]) and bool(b["ranks_identical"][0])
     assert np.all(np.isfinite(b["theta"]))
     assert rel(b["theta"], a["theta"]) < 1e-6, rel(b["theta"], a["theta"])          # the same update over the other transport
+
+
+def test_two_rank_ppo_equals_one_rank(tmp_path):
+    """PPO under a process group (r05; it refused before): the minibatch epochs are a sequential chain over rows of the WHOLE batch,
+    so every rank gathers all ranks' rows and runs the identical chain from the same index draws -- two ranks holding 17 + 23
+    trajectories end two iterations with the parameters of the one-process run (the advantage whitening is a rank sum: fp64
+    statistics, the fp32 advantages agree to the last bit or one), bit-identical on both ranks."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    port = 29250 + (os.getpid() % 100)
+    _run("_two_rank_ppo_worker.py", [one], 1, port)
+    _run("_two_rank_ppo_worker.py", [two], 2, port)
+    a, b = np.load(one), np.load(two)
+    assert bool(b["ranks_identical"][0])
+    th0 = None
+    for k in ("theta1", "theta2"):
+        d = rel(b[k], a[k])
+        assert d < 1e-6, (k, d)
+    np.testing.assert_allclose(b["stats"], a["stats"], rtol=1e-12)
+    np.testing.assert_allclose(b["kl"], a["kl"], rtol=1e-4)
+    np.testing.assert_allclose(b["surr"], a["surr"], rtol=1e-4, atol=1e-7)
