@@ -22,6 +22,17 @@ def root():
     return None
 
 
+def example_script(name="policy_opt_job_script"):
+    """path of one of the reference's example scripts: the source in the build container, the staged bytecode elsewhere (or None)"""
+    r = root()
+    if r is None:
+        return None
+    for p in (os.path.join(r, "examples", name + ".py"), os.path.join(r, "examples", name + ".pyc")):
+        if os.path.exists(p):
+            return p
+    return None
+
+
 def install():
     """-> the root the reference was bound to, or None when it is not available here"""
     r = root()
@@ -40,4 +51,5 @@ def install():
     gym.make = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no gym here"))
     sys.modules.setdefault("gym", gym)
     sys.modules.setdefault("mjrl.samplers.batch_sampler", types.ModuleType("mjrl.samplers.batch_sampler"))
+    sys.modules.setdefault("mjrl.envs", types.ModuleType("mjrl.envs"))       # (`import mjrl.envs` of the job scripts: gym registrations + mujoco_py)
     return r

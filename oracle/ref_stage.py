@@ -31,6 +31,9 @@ MODULES = [
 ]
 
 
+EXAMPLES = ["examples/policy_opt_job_script"]
+
+
 def stage(verbose=True):
     """-> number of modules compiled (0 when the reference is not present: the GPU box)"""
     src_root = os.path.join(REF, "mjrl")
@@ -48,6 +51,17 @@ def stage(verbose=True):
             py_compile.compile(src, cfile=dst, dfile="<reference>/mjrl/%s.py" % mod, doraise=True,
                                invalidation_mode=py_compile.PycInvalidationMode.UNCHECKED_HASH)
         n += 1
+    # the job script the north star names (examples/policy_opt_job_script.py): run UNMODIFIED by tests/test_reference_driver.py
+    # through mjrl_amd.dropin -- bytecode only, like the modules above
+    for rel in EXAMPLES:
+        src = os.path.join(REF, rel + ".py")
+        if os.path.exists(src):
+            dst = os.path.join(OUT, rel + ".pyc")
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
+                py_compile.compile(src, cfile=dst, dfile="<reference>/%s.py" % rel, doraise=True,
+                                   invalidation_mode=py_compile.PycInvalidationMode.UNCHECKED_HASH)
+            n += 1
     with open(os.path.join(OUT, "STAGED"), "w") as f:
         f.write("python %d.%d bytecode of %d modules of %s/mjrl (oracle/ref_stage.py); build output, not source\n"
                 % (sys.version_info[0], sys.version_info[1], n, REF))
