@@ -398,12 +398,9 @@ def user_level_measurements():
         return [dict(observations=p["observations"].copy(), actions=p["actions"].copy(), rewards=p["rewards"], advantages=p["advantages"],
                      terminated=False) for p in base]
     ts = []
-    b = None
     for it in range(10):
-        # like train_step, whose rollouts die when it returns: the previous batch is gone before the next one is allocated.  (With
-        # both alive the new arrays land in fresh mappings instead of recycled memory and every other call ran 12-20 ms instead
-        # of 8: tools/probe_e2e_outlier.py; r05: train_from_paths also lets go of the staging registry's references itself.)
-        b = None
+        # (r05: a call used to run 12-20 ms instead of 8 whenever the previous batch's 2 000 host arrays were released inside it --
+        # glibc unmapping / trimming them one by one; the training process's allocator is tuned now, utils/ingest._tune_malloc)
         b = fresh()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         agent.train_from_paths(b)

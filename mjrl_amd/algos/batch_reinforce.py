@@ -8,7 +8,6 @@ vanilla-PG ``train_from_paths``.  All batch arithmetic runs in libmjx through
 ``mjrl_amd.engine.UpdateEngine``; this class only orchestrates.
 """
 import os
-import threading
 import time as timer
 
 import numpy as np
@@ -19,36 +18,7 @@ from ..utils import process_samples
 from ..utils.logger import DataLog
 
 
-_TFP_DEPTH = threading.local()
-
-
-def _releasing(fn):
-    """train_from_paths wrapper: when the OUTERMOST train_from_paths of a thread returns outside train_step, the staging registry
-    lets go of the batch's host trajectories (utils/ingest.release_if_standalone: a batch left there is released inside the next
-    call -- which then runs 20 ms instead of 7.8)."""
-    import functools
-
-    @functools.wraps(fn)
-    def wrapper(self, paths, *a, **k):
-        _TFP_DEPTH.n = getattr(_TFP_DEPTH, "n", 0) + 1
-        try:
-            return fn(self, paths, *a, **k)
-        finally:
-            _TFP_DEPTH.n -= 1
-            if _TFP_DEPTH.n == 0:
-                from ..utils import ingest
-                ingest.release_if_standalone()
-    wrapper._mjx_releases = True
-    return wrapper
-
-
 class BatchREINFORCE:
-    def __init_subclass__(cls, **kw):
-        super().__init_subclass__(**kw)
-        fn = cls.__dict__.get("train_from_paths")
-        if fn is not None and not getattr(fn, "_mjx_releases", False):
-            cls.train_from_paths = _releasing(fn)
-
     def __init__(self, env, policy, baseline, learn_rate=0.01, seed=123, desired_kl=None, save_logs=False, **kwargs):
         self.env = env
         self.policy = policy
@@ -431,6 +401,3 @@ class BatchREINFORCE:
                 self.logger.log_kv('success_rate', self.env.env.env.evaluate_success(paths))
             except Exception:
                 pass
-
-
-BatchREINFORCE.train_from_paths = _releasing(BatchREINFORCE.__dict__["train_from_paths"])

@@ -7,35 +7,42 @@ policy / baselines / agents and hands them to mjrl's own ``train_agent`` and sam
 (``mjrl.utils.*``, ``mjrl.samplers.*``, ``mjrl.envs`` are not touched).  Editing the import block by hand
 does the same thing; this is the zero-edit form.
 """
-import importlib
 import runpy
 import sys
 
-# reference module -> the module of this package that exports the same class names with the same constructor arguments
-ALIASES = {
-    "mjrl.policies.gaussian_mlp": "mjrl_amd.policies.gaussian_mlp",          # MLP
-    "mjrl.policies.gaussian_linear": "mjrl_amd.policies.gaussian_linear",    # LinearPolicy
-    "mjrl.baselines.quadratic_baseline": "mjrl_amd.baselines.quadratic_baseline",
-    "mjrl.baselines.linear_baseline": "mjrl_amd.baselines.linear_baseline",
-    "mjrl.baselines.mlp_baseline": "mjrl_amd.baselines.mlp_baseline",
-    "mjrl.baselines.zero_baseline": "mjrl_amd.baselines.zero_baseline",
-    "mjrl.algos.batch_reinforce": "mjrl_amd.algos.batch_reinforce",          # BatchREINFORCE (VPG / NVPG)
-    "mjrl.algos.npg_cg": "mjrl_amd.algos.npg_cg",                            # NPG
-    "mjrl.algos.trpo": "mjrl_amd.algos.trpo",
-    "mjrl.algos.dapg": "mjrl_amd.algos.dapg",
-    "mjrl.algos.ppo_clip": "mjrl_amd.algos.ppo_clip",
-    "mjrl.algos.behavior_cloning": "mjrl_amd.algos.behavior_cloning",
-    "mjrl.utils.process_samples": "mjrl_amd.utils.process_samples",
-}
+def _aliases():
+    """reference module name -> the module of this package that exports the same class names with the same constructor arguments"""
+    from .algos import batch_reinforce, behavior_cloning, dapg, npg_cg, ppo_clip, trpo
+    from .baselines import linear_baseline, mlp_baseline, quadratic_baseline, zero_baseline
+    from .policies import gaussian_linear, gaussian_mlp
+    from .utils import process_samples
+    return {
+        "mjrl.policies.gaussian_mlp": gaussian_mlp,                  # MLP
+        "mjrl.policies.gaussian_linear": gaussian_linear,            # LinearPolicy
+        "mjrl.baselines.quadratic_baseline": quadratic_baseline,
+        "mjrl.baselines.linear_baseline": linear_baseline,
+        "mjrl.baselines.mlp_baseline": mlp_baseline,
+        "mjrl.baselines.zero_baseline": zero_baseline,
+        "mjrl.algos.batch_reinforce": batch_reinforce,               # BatchREINFORCE (VPG / NVPG)
+        "mjrl.algos.npg_cg": npg_cg,                                 # NPG
+        "mjrl.algos.trpo": trpo,
+        "mjrl.algos.dapg": dapg,
+        "mjrl.algos.ppo_clip": ppo_clip,
+        "mjrl.algos.behavior_cloning": behavior_cloning,
+        "mjrl.utils.process_samples": process_samples,
+    }
 
 
 def install(verbose=False):
     """bind the reference's class-bearing module names to this package's modules -> the list of names bound.  mjrl itself
     must be importable (its utils / samplers / envs are used as they are)."""
     import mjrl  # noqa: F401  (the package the script's other imports come from; ImportError here is the honest failure)
+    import mjrl.algos  # noqa: F401  (the parent packages first: `import mjrl.algos.npg_cg as x` binds through their attributes)
+    import mjrl.baselines  # noqa: F401
+    import mjrl.policies  # noqa: F401
+    import mjrl.utils  # noqa: F401
     bound = []
-    for ref_name, ours in ALIASES.items():
-        mod = importlib.import_module(ours)
+    for ref_name, mod in _aliases().items():
         sys.modules[ref_name] = mod
         parent, _, leaf = ref_name.rpartition(".")
         if parent in sys.modules:                       # `import mjrl.algos.npg_cg as x` resolves through the parent's attribute

@@ -27,6 +27,31 @@ except Exception:                           # pragma: no cover
     _pathwalk = None
 
 
+def _tune_malloc():
+    """Host allocator settings for a training process that turns over hundreds of MB of rollout arrays per iteration (once, at the
+    first import of this module -- the training process only; sampler workers never import it).  With glibc's defaults a rollout
+    array of 136 KB (1 000 steps x 17 observations in fp64) sits right at the mmap threshold: batches end up either as 2 000
+    separate mappings (every free an munmap) or at the top of the heap (every free a trim, an sbrk with its page-table work):
+    releasing ONE batch then costs 6-13 ms instead of 0.5 (tools/e2e_timeline.py with TL_ALTERNATE=1: the whole difference
+    between an 8 ms and a 20 ms NPG.train_from_paths), wherever in the iteration the last reference dies.  M_MMAP_THRESHOLD at its
+    maximum (32 MB: rollout arrays come from the heap) and M_TRIM_THRESHOLD at 2 GB (the heap keeps what a batch needs) make
+    that release a list insertion.  MJX_MALLOC_TUNE=0 leaves the allocator alone."""
+    if os.environ.get("MJX_MALLOC_TUNE", "1") == "0" or not sys.platform.startswith("linux"):
+        return False
+    try:
+        import ctypes
+        libc = ctypes.CDLL(None)
+        M_TRIM_THRESHOLD, M_MMAP_THRESHOLD = -1, -3
+        ok = libc.mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024) == 1
+        ok = (libc.mallopt(M_TRIM_THRESHOLD, 2 ** 31 - 1) == 1) and ok
+        return ok
+    except Exception:                       # pragma: no cover  (another libc: nothing to tune)
+        return False
+
+
+MALLOC_TUNED = _tune_malloc()
+
+
 def collect_arrays(paths, key):
     """addresses and first dimensions of paths[.][key] -> (ptrs: (n,) uint64 ndarray, lens: (n,) int64 ndarray, width, itemsize), or
     None when the arrays are not uniform C-contiguous float32 / float64 blocks (the caller converts / copies them itself).  The
@@ -575,6 +600,33 @@ def settle(backend):
         _order_after(backend, ent)
 
 
+def _release_other_batches(dev, paths):
+    """a NEW batch is about to be staged: let go of every registry entry that still points at another path list -- in one go and
+    before the new batch's staging jobs start, instead of key by key in the middle of them.  (What a release costs is the host
+    allocator's business -- 0.5 or 13 ms for the 2 000 arrays of a 1M-timestep batch with glibc's defaults, tools/e2e_timeline.py
+    with TL_ALTERNATE=1; see _tune_malloc above.)"""
+    stale = []
+    with _SHARED_LOCK:
+        for ent in _SHARED.get((dev.type, dev.index), {}).values():
+            if ent.get("paths") is not None and ent["paths"] is not paths:
+                stale.append(ent)
+    if not stale:
+        return
+    _retire_deferred(lambda e: any(e is x for x in stale))
+    with _SHARED_LOCK:
+        for ent in stale:
+            if ent.get("paths") is not None and ent["paths"] is not paths:
+                st = ent.get("active")
+                if st is not None and getattr(st, "on_gpu", False):
+                    try:
+                        st.join()                          # (nothing may still be gathering from the arrays we are about to drop)
+                    except Exception:                     # pragma: no cover
+                        pass
+                ent["paths"] = ent["arrays"] = ent["probes"] = None
+                ent["f32"] = ent["raw"] = ent["active"] = None
+                ent.pop("derived", None)
+
+
 def _prefetch_inline(backend, paths, keys, raw):
     """the staging jobs of `keys` started from the calling thread (mjx_stage_async returns at once): no helper thread needed"""
     try:
@@ -595,6 +647,7 @@ def stage_shared(backend, paths, keys, raw=None, defer=False):
     and calls settle() before it enqueues the first consumer."""
     dev = backend.device
     out = {}
+    _release_other_batches(dev, paths)
     for k in keys:
         need_raw = raw is None or k in raw
         tag = (dev.type, dev.index, k)
@@ -744,16 +797,6 @@ def drop_shared_batch():
                 ent["paths"] = ent["arrays"] = ent["probes"] = None
                 ent["f32"] = ent["raw"] = ent["active"] = None
                 ent.pop("derived", None)
-
-
-def release_if_standalone():
-    """end of a train_from_paths that runs on its own (not inside train_step's trusted_iteration, which drops the batch itself
-    once predict, update and fit have shared the upload): let go of the host trajectories NOW.  Left in the registry they are
-    released when the NEXT batch replaces them -- inside the next call, with both batches alive while the new one is allocated --
-    and that next call ran 20 ms instead of 7.8 (every other call of a back-to-back loop: tools/probe_e2e_outlier.py; the
-    release itself takes 0.4 ms here)."""
-    if not _trusted():
-        drop_shared_batch()
 
 
 def drop_shared():

@@ -34,10 +34,29 @@ _ss = ingest.stage_shared
 def ss(backend, paths_, keys, raw=None, defer=False):
     t = time.perf_counter(); r = _ss(backend, paths_, keys, raw, defer); LOG.append(("stage_shared%s" % (tuple(keys),), 1e3 * (t - T0[0]), 1e3 * (time.perf_counter() - T0[0]))); return r
 ingest.stage_shared = ss
+_rob = ingest._release_other_batches
+def rob(dev, paths_):
+    t = time.perf_counter(); _rob(dev, paths_); LOG.append(("  release of the previous batch's references", 1e3 * (t - T0[0]), 1e3 * (time.perf_counter() - T0[0])))
+ingest._release_other_batches = rob
 _settle = ingest.settle
 def settle(backend):
     t = time.perf_counter(); _settle(backend); LOG.append(("main: settle (join staging jobs)", 1e3 * (t - T0[0]), 1e3 * (time.perf_counter() - T0[0])))
 ingest.settle = settle
+if os.environ.get("TL_ALTERNATE") == "1":
+    # the caller's loop of tools/probe_e2e_outlier.py: a new batch allocated while the previous one is alive, the registry keeping
+    # the batch (MJX_KEEP_BATCH=1) -- calls alternate between ~8 and ~20 ms; print the timelines of the last two
+    os.environ["MJX_KEEP_BATCH"] = "1"
+    runs, b = [], None
+    for it in range(8):
+        b = fresh()
+        LOG.clear(); torch.cuda.synchronize(); T0[0] = time.perf_counter()
+        agent.train_from_paths(b)
+        torch.cuda.synchronize(); runs.append((1e3 * (time.perf_counter() - T0[0]), list(LOG)))
+    for total, log in runs[-2:]:
+        for tag, a, c in sorted(log, key=lambda x: x[1]):
+            print("%-44s %7.2f -> %7.2f  (%.2f ms)" % (tag, a, c, c - a))
+        print("total %.2f ms\n" % total)
+    sys.exit(0)
 batches = [fresh() for _ in range(6)]
 for b in batches:
     LOG.clear(); torch.cuda.synchronize(); T0[0] = time.perf_counter()

@@ -84,3 +84,19 @@ for r in rows[2:]:
     print("   ", r)
 ts = sorted(r[0] for r in rows[2:])
 print("    median %.2f  min %.2f  max %.2f  max/min %.2f" % (ts[len(ts) // 2], ts[0], ts[-1], ts[-1] / ts[0]), flush=True)
+
+
+# ---- the registry KEEPS the batch after the call (MJX_KEEP_BATCH=1: a baseline.fit(paths) that follows re-uses the upload) and lets
+# go of it at the START of the next batch's staging, before any gather thread runs -- the caller's loop as in the first experiment
+os.environ["MJX_KEEP_BATCH"] = "1"
+rows = []
+for it in range(14):
+    b = fresh()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    agent.train_from_paths(b)
+    torch.cuda.synchronize()
+    rows.append(round(1e3 * (time.perf_counter() - t0), 2))
+print("registry keeps the batch, released at the start of the next staging:", rows[2:])
+ts = sorted(rows[2:])
+print("    median %.2f  min %.2f  max %.2f  max/min %.2f" % (ts[len(ts) // 2], ts[0], ts[-1], ts[-1] / ts[0]), flush=True)
