@@ -21,8 +21,6 @@ LOSS_IDS = {"MSE": 0, "MLE": 1}
 class BC:
     def __init__(self, expert_paths, policy, epochs=5, batch_size=64, lr=1e-3, optimizer=None, loss_type='MSE',
                  save_logs=True, set_transforms=False, **kwargs):
-        if optimizer is not None:
-            raise NotImplementedError("a caller-supplied torch optimizer cannot drive the device loop; use the reference BC for that")
         if loss_type not in LOSS_IDS:
             raise ValueError("Please use valid loss type ('MSE' or 'MLE')")
         self.policy = policy
@@ -30,6 +28,14 @@ class BC:
         self.epochs = epochs
         self.mb_size = batch_size
         self.lr = lr
+        # behavior_cloning.py:42: `optimizer` defaults to torch.optim.Adam(policy.trainable_params, lr=lr).  A caller-supplied one
+        # is honoured when it IS that optimizer with another learning rate / an existing state -- what the device loop implements
+        # (Adam, betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad, one group over the policy's parameters): its lr and
+        # moments are taken over and written back after every fit, so the caller's object stays the optimizer's state.  Anything
+        # else cannot drive the device loop and is refused (no CPU fallback).
+        self.optimizer = optimizer
+        if optimizer is not None:
+            self.lr = self._adopt_optimizer(optimizer)
         self.logger = DataLog()
         self.loss_type = loss_type
         self.save_logs = save_logs
@@ -38,6 +44,46 @@ class BC:
             self.set_transformations(in_shift, in_scale, out_shift, out_scale)
             self.set_variance_with_data(out_scale)
         self._adam = None           # (m, v) device tensors + steps taken: the torch.optim.Adam state of the reference
+
+    def _adopt_optimizer(self, opt):
+        import torch
+        why = None
+        if type(opt) is not torch.optim.Adam:
+            why = "it is a %s, the device loop implements torch.optim.Adam" % type(opt).__name__
+        elif len(opt.param_groups) != 1:
+            why = "it has %d parameter groups" % len(opt.param_groups)
+        else:
+            g = opt.param_groups[0]
+            tp = self.policy.trainable_params
+            if len(g["params"]) != len(tp) or any(a is not b for a, b in zip(g["params"], tp)):
+                why = "its parameters are not policy.trainable_params"
+            elif tuple(g["betas"]) != (0.9, 0.999) or g["eps"] != 1e-8 or g["weight_decay"] != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+                why = "betas / eps / weight_decay / amsgrad differ from Adam's defaults (%r)" % ({k: g[k] for k in ("betas", "eps", "weight_decay")},)
+        if why is not None:
+            raise NotImplementedError("BC(optimizer=...): %s -- such an optimizer cannot drive the device loop (behavior_cloning.py:42)" % why)
+        return float(opt.param_groups[0]["lr"])
+
+    def _optimizer_state_in(self, torch, like):
+        """the caller's optimizer state (exp_avg / exp_avg_sq / step per parameter) as flat device vectors, or None when it has none"""
+        opt = self.optimizer
+        tp = self.policy.trainable_params
+        if opt is None or not all(p in opt.state and "exp_avg" in opt.state[p] for p in tp):
+            return None
+        m = torch.cat([opt.state[p]["exp_avg"].reshape(-1).float() for p in tp]).to(like.device)
+        v = torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1).float() for p in tp]).to(like.device)
+        return [m, v, int(float(opt.state[tp[0]]["step"]))]
+
+    def _optimizer_state_out(self, torch):
+        opt = self.optimizer
+        if opt is None or self._adam is None:
+            return
+        m, v, k = self._adam[0].cpu(), self._adam[1].cpu(), 0
+        for p in self.policy.trainable_params:
+            n = p.numel()
+            st = opt.state[p]
+            st["exp_avg"], st["exp_avg_sq"] = m[k:k + n].reshape(p.shape).clone(), v[k:k + n].reshape(p.shape).clone()
+            st["step"] = torch.tensor(float(self._adam[2]))
+            k += n
 
     # ------------------------------------------------------------------ data-driven transforms (behavior_cloning.py:51-75)
     def _stacked(self, key):
@@ -93,6 +139,9 @@ class BC:
             tr = torch.from_numpy(np.float32(p.model.packed_transforms())).to(eng.device)
             obs = eng.to_device_f32(data["observations"])
             act = eng.to_device_f32(data["expert_actions"])
+            if self.optimizer is not None:
+                self.lr = float(self.optimizer.param_groups[0]["lr"])          # (a scheduler may have moved it)
+                self._adam = self._optimizer_state_in(torch, theta) or self._adam
             if self._adam is None:
                 self._adam = [torch.zeros_like(theta), torch.zeros_like(theta), 0]
             didx = upload(eng.backend, idx)
@@ -101,6 +150,7 @@ class BC:
                                                     ptr(self._adam[1]), self._adam[2], self.lr, 0.0, None, eng.stream()))
             self._adam[2] += steps
             p.set_param_values(eng.to_host(theta), set_new=True, set_old=True)
+            self._optimizer_state_out(torch)
         else:
             p = self.policy
             p.set_param_values(p.get_param_values(), set_new=True, set_old=True)

@@ -1251,6 +1251,37 @@ def test_bc_minibatch_adam_vs_reference(name):
     assert bc.logger.log['loss_after'][-1] < bc.logger.log['loss_before'][-1]
 
 
+def test_bc_with_a_caller_supplied_adam():
+    """behavior_cloning.py:42: BC(optimizer=torch.optim.Adam(policy.trainable_params, lr=...)) -- the caller's optimizer drives the
+    device loop when it is the Adam the loop implements: its learning rate is used, its moments / step count are taken over and
+    written back after every fit.  Two fits with the caller's optimizer == two fits of a BC built with lr=..., bit for bit, and the
+    optimizer's state afterwards IS the device loop's state (a torch step from it continues the same chain)."""
+    import torch
+    from mjrl_amd.algos.behavior_cloning import BC
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    spec = type("Spec", (), dict(observation_dim=11, action_dim=3, horizon=40))
+    paths = synth.make_paths(12, 40, 11, 3, seed=3)
+    out = {}
+    for mode in ("own", "callers"):
+        pol = MLP(spec, hidden_sizes=(32, 32), seed=1, init_log_std=-0.5)
+        opt = torch.optim.Adam(pol.trainable_params, lr=7e-4) if mode == "callers" else None
+        bc = BC(paths, pol, epochs=2, batch_size=64, lr=7e-4, optimizer=opt, loss_type='MLE', save_logs=False)
+        np.random.seed(5)
+        bc.train(); bc.train()
+        out[mode] = (pol.get_param_values().copy(), bc, opt, pol)
+    assert np.array_equal(out["own"][0], out["callers"][0])
+    bc, opt, pol = out["callers"][1:]
+    steps = 2 * 2 * (12 * 40 // 64)
+    st = opt.state[pol.trainable_params[0]]
+    assert int(float(st["step"])) == steps and st["exp_avg"].shape == pol.trainable_params[0].shape and float(st["exp_avg_sq"].abs().sum()) > 0
+    flat_m = torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in pol.trainable_params]).numpy()
+    assert np.array_equal(flat_m, bc._adam[0].cpu().numpy())
+    with pytest.raises(NotImplementedError):
+        BC(paths, pol, optimizer=torch.optim.SGD(pol.trainable_params, lr=1e-3), save_logs=False)
+    with pytest.raises(NotImplementedError):
+        BC(paths, pol, optimizer=torch.optim.Adam(pol.trainable_params, lr=1e-3, weight_decay=1e-2), save_logs=False)
+
+
 def test_ppo_minibatch_adam_vs_reference():
     """PPO.train_from_paths twice (the Adam state carries over) == the reference (ppo_clip.py:59-110)."""
     from mjrl_amd.algos.ppo_clip import PPO

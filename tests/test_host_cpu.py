@@ -402,3 +402,18 @@ def test_path_walk_extension_and_native_path_sums():
         ref = np.array([sum(p["rewards"]) for p in paths], np.float64)
         np.testing.assert_array_equal(out, ref)
     assert any(float(np.sum(p["rewards"])) != sum(p["rewards"]) for p in paths)      # (the two orders do differ on this data)
+
+
+def test_bc_refuses_optimizers_the_device_loop_does_not_implement():
+    """behavior_cloning.py:42 `optimizer=`: torch.optim.Adam over policy.trainable_params with Adam's default betas / eps and no weight
+    decay is adopted (its lr); anything else is refused at construction -- there is no CPU training loop to fall back on"""
+    import torch
+    from mjrl_amd.algos.behavior_cloning import BC
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    spec = type("S", (), dict(observation_dim=5, action_dim=2, horizon=5))
+    pol = MLP(spec, hidden_sizes=(8, 8), seed=1)
+    assert BC([], pol, optimizer=torch.optim.Adam(pol.trainable_params, lr=3e-4), save_logs=False).lr == pytest.approx(3e-4)
+    for bad in (torch.optim.SGD(pol.trainable_params, lr=1e-3), torch.optim.Adam(pol.trainable_params, lr=1e-3, betas=(0.8, 0.9)),
+                torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))]), torch.optim.AdamW(pol.trainable_params)):
+        with pytest.raises(NotImplementedError):
+            BC([], pol, optimizer=bad, save_logs=False)
