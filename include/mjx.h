@@ -362,7 +362,11 @@ int mjx_mlp_predict(const float* feat, int64_t N, int d_in, const int* hidden, i
 /* `epochs` x (N/batch - 1) minibatch steps of torch.optim.Adam(lr, weight_decay=wd) on the MSE loss
  * (utils/optimize_model.py:7-36); perm holds epochs*N row indices (np.random.permutation per epoch,
  * drawn by the caller to keep NumPy's RNG stream); params / m / v are updated in place, step0 = number
- * of Adam steps already taken; epoch_loss_out[e] = sum of minibatch losses of epoch e (device). */
+ * of Adam steps already taken; epoch_loss_out[e] = sum of minibatch losses of epoch e (device).
+ * The reference's shape (two hidden layers of 128, batch 64) runs as ONE persistent launch: one workgroup up to 55 inputs,
+ * ceil(d_in / 48) workgroups with a grid barrier per half-step beyond (up to 768 inputs; csrc/mlp_fit.h).  A wait of ~2 s for
+ * another workgroup poisons epoch_loss_out with NaN instead of hanging.  The launch uses per-host-thread scratch (moment pairs,
+ * the uncached exchange block): fits issued by one host thread must be stream-ordered with respect to each other. */
 int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, const int* hidden, int n_hidden,
                      float* params, float* m, float* v, int64_t step0, const int32_t* perm, int epochs, int batch,
                      float lr, float wd, double* epoch_loss_out, void* stream);

@@ -600,15 +600,17 @@ def settle(backend):
         _order_after(backend, ent)
 
 
-def _release_other_batches(dev, paths):
-    """a NEW batch is about to be staged: let go of every registry entry that still points at another path list -- in one go and
-    before the new batch's staging jobs start, instead of key by key in the middle of them.  (What a release costs is the host
+def _release_other_batches(dev, paths, keys):
+    """a NEW batch is about to be staged under `keys`: let go of the entries it replaces -- in one go and before the new batch's
+    staging jobs start, instead of key by key in the middle of them.  (What a release costs is the host
     allocator's business -- 0.5 or 13 ms for the 2 000 arrays of a 1M-timestep batch with glibc's defaults, tools/e2e_timeline.py
     with TL_ALTERNATE=1; see _tune_malloc above.)"""
     stale = []
     with _SHARED_LOCK:
-        for ent in _SHARED.get((dev.type, dev.index), {}).values():
-            if ent.get("paths") is not None and ent["paths"] is not paths:
+        reg = _SHARED.get((dev.type, dev.index), {})
+        for k in keys:                                     # (only the blocks about to be replaced: DAPG stages [on-policy ; demos] as a
+            ent = reg.get(k)                               #  list of its own while the on-policy list's returns / advantages stay registered)
+            if ent is not None and ent.get("paths") is not None and ent["paths"] is not paths:
                 stale.append(ent)
     if not stale:
         return
@@ -647,7 +649,7 @@ def stage_shared(backend, paths, keys, raw=None, defer=False):
     and calls settle() before it enqueues the first consumer."""
     dev = backend.device
     out = {}
-    _release_other_batches(dev, paths)
+    _release_other_batches(dev, paths, keys)
     for k in keys:
         need_raw = raw is None or k in raw
         tag = (dev.type, dev.index, k)

@@ -35,8 +35,8 @@ def ss(backend, paths_, keys, raw=None, defer=False):
     t = time.perf_counter(); r = _ss(backend, paths_, keys, raw, defer); LOG.append(("stage_shared%s" % (tuple(keys),), 1e3 * (t - T0[0]), 1e3 * (time.perf_counter() - T0[0]))); return r
 ingest.stage_shared = ss
 _rob = ingest._release_other_batches
-def rob(dev, paths_):
-    t = time.perf_counter(); _rob(dev, paths_); LOG.append(("  release of the previous batch's references", 1e3 * (t - T0[0]), 1e3 * (time.perf_counter() - T0[0])))
+def rob(dev, paths_, keys):
+    t = time.perf_counter(); _rob(dev, paths_, keys); LOG.append(("  release of the previous batch's references", 1e3 * (t - T0[0]), 1e3 * (time.perf_counter() - T0[0])))
 ingest._release_other_batches = rob
 _settle = ingest.settle
 def settle(backend):
