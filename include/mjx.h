@@ -336,6 +336,10 @@ int mjx_stage_wait(void* job);
  * the path returns of process_paths, `path_returns = [sum(p["rewards"]) for p in paths]` (mjrl/algos/batch_reinforce.py:187; Python's
  * sum() adds left to right, so the results carry the reference's bits).  Trajectories are spread over n_threads.  No device work. */
 int mjx_host_segment_sums(const double* const* src, const int64_t* lens, int64_t count, double* out, int n_threads);
+/* np.random.permutation(n) of NumPy's legacy (RandomState / global) MT19937 stream, bit for bit, as int32: what MLPBaseline.fit draws
+ * once per epoch (mjrl/utils/optimize_model.py:22).  key624 / pos_io: the generator state as np.random.get_state() returns it
+ * (624 words + position), advanced in place -- hand it back with np.random.set_state.  n < 2^31.  Host only, any thread. */
+int mjx_host_mt19937_permutation(uint32_t* key624_host, int32_t* pos_io_host, int64_t n, int32_t* out_host);
 
 /* ---- K6: value baselines --------------------------------------------------- */
 /* Feature maps of the reference baselines over the concatenated fp64 observation block

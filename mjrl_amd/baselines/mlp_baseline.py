@@ -15,6 +15,21 @@ from ..utils import ingest, ranks
 from ._features import DeviceBlock, DeviceOnly
 
 
+def _permutation_into(lib, out):
+    """out[:] = np.random.permutation(len(out)) -- the same values, the same advance of NumPy's global stream -- drawn by libmjx
+    (mjx_host_mt19937_permutation: RandomState's algorithm on a copy of the generator state, straight into the int32 block;
+    2.5 instead of 7.5 ms per 1M rows, and these draws are what is left of the fit on the critical path)"""
+    n = int(out.shape[0])
+    st = np.random.get_state()
+    if n < 2 or st[0] != 'MT19937' or out.dtype != np.int32 or not out.flags.c_contiguous:
+        out[:] = np.random.permutation(n)
+        return
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = ctypes.c_int32(int(st[2]))
+    check(lib.mjx_host_mt19937_permutation(ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), n, ctypes.c_void_p(out.ctypes.data)))
+    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+
+
 _FIT_STREAMS = {}            # device -> the side stream the asynchronous fits run on
 
 
@@ -188,7 +203,7 @@ class MLPBaseline:
         perm = perm_pin.numpy()[:max(self.epochs * num_samples, 1)]
         perm[:] = 0
         for ep in range(self.epochs):
-            perm[ep * num_samples:(ep + 1) * num_samples] = np.random.permutation(num_samples)
+            _permutation_into(blk.lib, perm[ep * num_samples:(ep + 1) * num_samples])
         if ranks.group() is not None:
             perm[:] = ranks.broadcast_host(perm, src=-1)        # the LAST rank's draw (see above)
         perm_t = perm_pin[:perm.shape[0]].to(blk.dev, non_blocking=True)

@@ -199,6 +199,49 @@ int mjx_host_segment_sums(const double* const* src, const int64_t* lens, int64_t
   return MJX_OK;
 }
 
+// ---- NumPy's legacy permutation stream, natively (r05).  MLPBaseline.fit draws np.random.permutation(N) once per epoch
+// (utils/optimize_model.py:22) and the draws must come from NumPy's GLOBAL MT19937 stream to keep the reference's minibatch order;
+// at 1M timesteps the two draws were 15 ms of a 29 ms post-sampling iteration (the rest of the fit runs in the background).  This is
+// RandomState.permutation(n) bit for bit -- arange(n), then for i = n - 1 .. 1: j = random_interval(i) (the smallest bit mask >= i,
+// rejection on 32-bit outputs), swap(i, j) -- on the caller's copy of the generator state (np.random.get_state(): 624 key words +
+// position), which is advanced in place and handed back with np.random.set_state.  int32 indices in one pass (NumPy shuffles int64
+// and the caller converted).  n < 2^31.
+namespace {
+struct Mt19937 {
+  uint32_t* key; int pos;
+  void refill() {
+    constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MA = 0x9908b0dfu;
+    int i = 0;
+    for (; i < 624 - 397; ++i) { const uint32_t y = (key[i] & UP) | (key[i + 1] & LO); key[i] = key[i + 397] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u); }
+    for (; i < 623; ++i) { const uint32_t y = (key[i] & UP) | (key[i + 1] & LO); key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u); }
+    const uint32_t y = (key[623] & UP) | (key[0] & LO);
+    key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+    pos = 0;
+  }
+  inline uint32_t next() {
+    if (pos == 624) refill();
+    uint32_t y = key[pos++];
+    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+    return y;
+  }
+};
+}  // namespace
+
+extern "C" int mjx_host_mt19937_permutation(uint32_t* key624, int32_t* pos_io, int64_t n, int32_t* out) {
+  if (!key624 || !pos_io || !out || n < 0 || n >= ((int64_t)1 << 31) || *pos_io < 0 || *pos_io > 624) return fail(MJX_ERR_ARG, "bad arguments");
+  for (int64_t i = 0; i < n; ++i) out[i] = (int32_t)i;
+  Mt19937 g{key624, *pos_io};
+  for (int64_t i = n - 1; i >= 1; --i) {
+    uint32_t mask = (uint32_t)i;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t j;
+    while ((j = (g.next() & mask)) > (uint32_t)i) {}
+    const int32_t t = out[i]; out[i] = out[j]; out[j] = t;
+  }
+  *pos_io = g.pos;
+  return MJX_OK;
+}
+
 // ---- asynchronous staging of one block of a rollout batch (r04): gather (+ fp64 -> fp32 conversion) group by group on the host
 // pools and the group's host-to-device copy queued right behind it -- all on a native thread, so the caller (a Python training
 // loop) gets control back at once and no interpreter lock is involved while 184 MB of rollouts move.  mjx_stage_wait joins.

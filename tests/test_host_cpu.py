@@ -417,3 +417,24 @@ def test_bc_refuses_optimizers_the_device_loop_does_not_implement():
                 torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))]), torch.optim.AdamW(pol.trainable_params)):
         with pytest.raises(NotImplementedError):
             BC([], pol, optimizer=bad, save_logs=False)
+
+
+def test_native_permutation_is_numpys_stream_bit_for_bit():
+    """mjx_host_mt19937_permutation == np.random.permutation(n) of the legacy global stream (utils/optimize_model.py:22 draws one per
+    epoch): the same values AND the same generator state afterwards (a cached Gaussian included), for sizes around the mask / refill
+    boundaries"""
+    from mjrl_amd import _lib
+    from mjrl_amd.baselines.mlp_baseline import _permutation_into
+    lib = _lib.load()
+    for seed in (0, 1, 123, 2 ** 31 - 1):
+        for n in (0, 1, 2, 3, 5, 64, 623, 624, 625, 1000, 65536, 65537, 300007):
+            np.random.seed(seed); np.random.randn(3)
+            a = [np.random.permutation(n), np.random.permutation(n)]
+            tail_a = (np.random.randn(2), np.random.randint(0, 1000, 5))
+            np.random.seed(seed); np.random.randn(3)
+            b = [np.empty(n, np.int32), np.empty(n, np.int32)]
+            for o in b:
+                _permutation_into(lib, o)
+            tail_b = (np.random.randn(2), np.random.randint(0, 1000, 5))
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (seed, n)
+            assert all(np.array_equal(x, y) for x, y in zip(tail_a, tail_b)), (seed, n)
