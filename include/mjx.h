@@ -340,6 +340,10 @@ int mjx_host_segment_sums(const double* const* src, const int64_t* lens, int64_t
  * once per epoch (mjrl/utils/optimize_model.py:22).  key624 / pos_io: the generator state as np.random.get_state() returns it
  * (624 words + position), advanced in place -- hand it back with np.random.set_state.  n < 2^31.  Host only, any thread. */
 int mjx_host_mt19937_permutation(uint32_t* key624_host, int32_t* pos_io_host, int64_t n, int32_t* out_host);
+/* `count` draws of np.random.choice(n, size=...) (with replacement; == np.random.randint(0, n, size=...)) of the same stream: the
+ * minibatch row indices BC and PPO draw once per Adam step (mjrl/algos/behavior_cloning.py:113, ppo_clip.py:77); draws of any
+ * sizes concatenate, so steps x minibatch indices are ONE call.  1 <= n < 2^31. */
+int mjx_host_mt19937_randint(uint32_t* key624_host, int32_t* pos_io_host, int64_t n, int64_t count, int32_t* out_host);
 
 /* ---- K6: value baselines --------------------------------------------------- */
 /* Feature maps of the reference baselines over the concatenated fp64 observation block

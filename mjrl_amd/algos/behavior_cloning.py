@@ -12,7 +12,7 @@ import numpy as np
 
 from .._lib import check, ptr
 from ..engine import UpdateEngine
-from ..utils.ingest import upload
+from ..utils.ingest import minibatch_indices, upload
 from ..utils.logger import DataLog
 
 LOSS_IDS = {"MSE": 0, "MLE": 1}
@@ -131,7 +131,7 @@ class BC:
         steps = self.epochs * steps_per_epoch
         if steps > 0:
             # the reference draws np.random.choice(num_samples, size=mb_size) once per step, epoch after epoch
-            idx = np.stack([np.random.choice(num_samples, size=self.mb_size) for _ in range(steps)]).astype(np.int32)
+            idx = minibatch_indices(self._engine().lib, num_samples, steps, self.mb_size)
             eng = self._engine()
             torch = eng.torch
             p = self.policy

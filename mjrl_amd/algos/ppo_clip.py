@@ -17,7 +17,7 @@ import time as timer
 import numpy as np
 
 from .._lib import check, ptr
-from ..utils.ingest import upload
+from ..utils.ingest import minibatch_indices, upload
 from ..utils.logger import DataLog
 from .batch_reinforce import BatchREINFORCE
 
@@ -73,7 +73,7 @@ class PPO(BatchREINFORCE):
         num_samples = int(obs_b.shape[0])
         steps = self.epochs * int(num_samples / self.mb_size)
         if steps > 0:
-            idx = np.stack([np.random.choice(num_samples, size=self.mb_size) for _ in range(steps)]).astype(np.int32)
+            idx = minibatch_indices(eng.lib, num_samples, steps, self.mb_size)
             idx = ranks.broadcast_host(idx, src=-1)
             if self._adam is None:
                 self._adam = [torch.zeros_like(eng.theta_new), torch.zeros_like(eng.theta_new), 0]

@@ -242,6 +242,26 @@ extern "C" int mjx_host_mt19937_permutation(uint32_t* key624, int32_t* pos_io, i
   return MJX_OK;
 }
 
+// count draws of np.random.choice(n, size=...) / np.random.randint(0, n, size=...) of the same legacy stream (BC and PPO draw one
+// minibatch of row indices per Adam step, behavior_cloning.py:113, ppo_clip.py:77: 156 k Python-level calls per 1M-timestep PPO
+// iteration): value = next_uint32 & mask, rejected while > n - 1 -- RandomState's masked rejection for ranges below 2^32; calls
+// of any sizes concatenate to the same stream, so steps x minibatch indices are one native loop.
+extern "C" int mjx_host_mt19937_randint(uint32_t* key624, int32_t* pos_io, int64_t n, int64_t count, int32_t* out) {
+  if (!key624 || !pos_io || !out || n < 1 || n >= ((int64_t)1 << 31) || count < 0 || *pos_io < 0 || *pos_io > 624) return fail(MJX_ERR_ARG, "bad arguments");
+  const uint32_t rng = (uint32_t)(n - 1);
+  if (rng == 0) { for (int64_t i = 0; i < count; ++i) out[i] = 0; return MJX_OK; }          // (NumPy draws nothing for a one-value range)
+  uint32_t mask = rng;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  Mt19937 g{key624, *pos_io};
+  for (int64_t i = 0; i < count; ++i) {
+    uint32_t v;
+    while ((v = (g.next() & mask)) > rng) {}
+    out[i] = (int32_t)v;
+  }
+  *pos_io = g.pos;
+  return MJX_OK;
+}
+
 // ---- asynchronous staging of one block of a rollout batch (r04): gather (+ fp64 -> fp32 conversion) group by group on the host
 // pools and the group's host-to-device copy queued right behind it -- all on a native thread, so the caller (a Python training
 // loop) gets control back at once and no interpreter lock is involved while 184 MB of rollouts move.  mjx_stage_wait joins.

