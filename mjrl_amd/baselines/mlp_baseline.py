@@ -201,7 +201,8 @@ class MLPBaseline:
         # locked int32 block (one conversion pass per epoch instead of concatenate + astype over the lot)
         perm_pin = self._pinned(torch, "perm", max(self.epochs, 1) * max(num_samples, 1), torch.int32)
         perm = perm_pin.numpy()[:max(self.epochs * num_samples, 1)]
-        perm[:] = 0
+        if self.epochs * num_samples == 0:
+            perm[:] = 0
         for ep in range(self.epochs):
             _permutation_into(blk.lib, perm[ep * num_samples:(ep + 1) * num_samples])
         if ranks.group() is not None:
