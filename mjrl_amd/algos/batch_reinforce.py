@@ -118,6 +118,16 @@ class BatchREINFORCE:
         with trusted_iteration():               # nothing but this package touches `paths` from here to the baseline fit
             process_samples.compute_returns(paths, gamma)
             process_samples.compute_advantages(paths, self.baseline, gamma, gae_lambda)
+            # the MLP baseline's epoch permutations -- all that is left of its fit on the critical path -- start now, on a helper
+            # thread under the update's GPU time (speculative: the fit takes them over only if nobody touched NumPy's global
+            # stream in between; MLPBaseline.predraw).  Only for this package's own train_from_paths without row subsampling
+            # (which draws from the same stream), one process.
+            pre = None
+            if (os.environ.get("MJX_ASYNC_FIT", "1") != "0" and hasattr(self.baseline, "predraw") and d is None
+                    and (type(self).train_from_paths.__module__ or "").startswith("mjrl_amd.")
+                    and not (getattr(self, "hvp_subsample", None) is not None and self.hvp_subsample < 0.99)
+                    and type(self).__name__ not in ("PPO",)):
+                pre = self.baseline.predraw(sum(len(p["rewards"]) for p in paths))
             eval_statistics = self.train_from_paths(paths)
             eval_statistics.append(N)
             # The fitted baseline is not read before the NEXT iteration's compute_advantages, and sampling comes first
@@ -129,14 +139,14 @@ class BatchREINFORCE:
                 self.logger.log_kv('num_samples', self.engine.global_count(int(np.sum([p["rewards"].shape[0] for p in paths]))))
                 t0 = timer.time()
                 if fit_async is not None:
-                    self._log_fit_when_done(fit_async(paths, return_errors=True), t0)
+                    self._log_fit_when_done(fit_async(paths, return_errors=True, **({"predrawn": pre} if pre is not None else {})), t0)
                 else:
                     error_before, error_after = self.baseline.fit(paths, return_errors=True)
                     self.logger.log_kv('time_VF', timer.time() - t0)
                     self.logger.log_kv('VF_error_before', error_before)
                     self.logger.log_kv('VF_error_after', error_after)
             elif fit_async is not None:
-                fit_async(paths)
+                fit_async(paths, **({"predrawn": pre} if pre is not None else {}))
             else:
                 self.baseline.fit(paths)
         drop_shared_batch()                     # the iteration's one upload served predict, update and fit; nothing may outlive it

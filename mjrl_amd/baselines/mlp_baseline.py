@@ -106,6 +106,7 @@ class MLPBaseline:
         state = dict(self.__dict__)
         state.pop("_pending", None)
         state.pop("_pins", None)
+        state.pop("predraw_stats", None)
         return state
 
     def _settle(self):
@@ -154,11 +155,61 @@ class MLPBaseline:
             ent = pins[name] = torch.empty(max(int(count), 1), dtype=dtype, pin_memory=True)
         return ent
 
+    def predraw(self, num_samples):
+        """Start drawing the NEXT fit's epoch permutations on a helper thread, speculatively: the draws depend on NumPy's global
+        generator state and on the row count only, both known before the policy update that train_step runs in between, and the
+        native draw (mjx_host_mt19937_permutation) holds no interpreter lock -- it runs under the update's GPU time.  The draws work
+        on a COPY of the generator state; fit_async takes them over only if the global state is still what it was when they started
+        (nobody drew in between: then this is exactly the stream the reference would have consumed, optimize_model.py:22) and
+        otherwise draws again.  -> a handle for fit_async(..., predrawn=handle), or None when there is nothing to gain."""
+        import threading
+        self._settle()                                           # (the previous fit's copy out of the permutation block is long done)
+        st = np.random.get_state()
+        num_samples = int(num_samples)
+        if st[0] != 'MT19937' or self.epochs <= 0 or num_samples < 2 or ranks.group() is not None:
+            return None
+        try:
+            blk = DeviceOnly()
+        except Exception:
+            return None
+        pin = self._pinned(blk.torch, "perm", self.epochs * num_samples, blk.torch.int32)
+        key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        h = dict(n=num_samples, epochs=int(self.epochs), key0=np.array(st[1], dtype=np.uint32, copy=True), pos0=int(st[2]), gauss0=(st[3], st[4]),
+                 key=key, pos=ctypes.c_int32(int(st[2])), pin=pin, error=None)
+
+        def work():
+            try:
+                out = pin.numpy()
+                for ep in range(h["epochs"]):
+                    check(blk.lib.mjx_host_mt19937_permutation(ctypes.c_void_p(key.ctypes.data), ctypes.byref(h["pos"]), num_samples,
+                                                               ctypes.c_void_p(out[ep * num_samples:].ctypes.data)))
+            except Exception as e:                               # pragma: no cover
+                h["error"] = e
+        h["thread"] = threading.Thread(target=work, name="mjx-predraw", daemon=True)
+        h["thread"].start()
+        return h
+
+    def _take_predrawn(self, h, num_samples):
+        """-> True when the speculative draws of predraw() ARE the draws this fit would make now (and NumPy's global state has been
+        advanced past them)"""
+        if h is None:
+            return False
+        h["thread"].join()
+        st = np.random.get_state()
+        same = (h["error"] is None and h["n"] == num_samples and h["epochs"] == int(self.epochs) and st[0] == 'MT19937' and int(st[2]) == h["pos0"]
+                and (st[3], st[4]) == h["gauss0"] and np.array_equal(np.asarray(st[1], dtype=np.uint32), h["key0"])
+                and self.__dict__.get("_pins", {}).get("perm") is h["pin"])
+        if same:
+            np.random.set_state(('MT19937', h["key"], int(h["pos"].value), st[3], st[4]))
+        d = self.__dict__
+        d["predraw_stats"] = (d.get("predraw_stats", (0, 0))[0] + int(same), d.get("predraw_stats", (0, 0))[1] + int(not same))    # (taken, discarded)
+        return same
+
     def fit(self, paths, return_errors=False):
         """mlp_baseline.py:61-95 + optimize_model.py:7-36: fit_async + wait.  -> (error_before, error_after) when asked."""
         return self.fit_async(paths, return_errors).result()
 
-    def fit_async(self, paths, return_errors=False):
+    def fit_async(self, paths, return_errors=False, predrawn=None):
         """mlp_baseline.py:61-95 + optimize_model.py:7-36, OFF the caller's critical path: inputs are prepared on the caller's
         stream, the persistent trainer (one workgroup, 18 us per Adam step: 0.6 s per 1M timesteps x 2 epochs), the error
         evaluations and the read-backs run on a side stream, and the call returns a PendingFit at once.  The fitted baseline is
@@ -199,11 +250,12 @@ class MLPBaseline:
         p, m, v = pmv[:npar], pmv[seg:seg + npar], pmv[2 * seg:2 * seg + npar]
         # every epoch's row order from NumPy's global stream like fit_data (optimize_model.py:22), written straight into a page-
         # locked int32 block (one conversion pass per epoch instead of concatenate + astype over the lot)
+        have = self._take_predrawn(predrawn, num_samples)      # (speculative draws of predraw(): taken only if they ARE this fit's draws)
         perm_pin = self._pinned(torch, "perm", max(self.epochs, 1) * max(num_samples, 1), torch.int32)
         perm = perm_pin.numpy()[:max(self.epochs * num_samples, 1)]
         if self.epochs * num_samples == 0:
             perm[:] = 0
-        for ep in range(self.epochs):
+        for ep in ([] if have else range(self.epochs)):
             _permutation_into(blk.lib, perm[ep * num_samples:(ep + 1) * num_samples])
         if ranks.group() is not None:
             perm[:] = ranks.broadcast_host(perm, src=-1)        # the LAST rank's draw (see above)

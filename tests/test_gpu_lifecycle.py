@@ -194,6 +194,8 @@ def test_background_fit_equals_the_blocking_fit_and_fills_the_log(tmp_path, monk
         log = agent.logger.log
         assert all(isinstance(v, float) or np.isscalar(v) for k in ("time_VF", "VF_error_before", "VF_error_after") for v in log[k])
         assert all(0.0 < v < 10.0 for v in log["VF_error_after"]) and all(v > 0 for v in log["time_VF"])
+        if mode == "1":                                                  # the epoch permutations were drawn under the update and taken over
+            assert agent.baseline.__dict__.get("predraw_stats") == (3, 0), agent.baseline.__dict__.get("predraw_stats")
         runs[mode] = dict(theta=agent.policy.get_param_values().copy(), bl=agent.baseline.params.copy(), m=agent.baseline.adam_m.copy(),
                           steps=agent.baseline.adam_steps, err=[float(v) for v in log["VF_error_after"]], pending=pending_seen,
                           pickled=pickle.loads(pickle.dumps(agent.baseline)).params.copy())
@@ -202,3 +204,35 @@ def test_background_fit_equals_the_blocking_fit_and_fills_the_log(tmp_path, monk
     assert a["pending"] >= 1 and b["pending"] == 0                      # the background mode really deferred something
     assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["bl"], b["bl"]) and np.array_equal(a["m"], b["m"])
     assert a["steps"] == b["steps"] and a["err"] == b["err"] and np.array_equal(a["pickled"], a["bl"])
+
+
+def test_speculative_permutation_draws_are_discarded_when_the_stream_moved():
+    """MLPBaseline.predraw draws the next fit's epoch permutations from a COPY of NumPy's global generator state while the update
+    runs; fit_async takes them only if the global state is still the one they started from.  Somebody drawing in between (here: the
+    test) makes the fit draw again -- the result is the fit a plain `fit` produces from that stream position, bit for bit."""
+    from mjrl_amd.baselines.mlp_baseline import MLPBaseline
+    from mjrl_amd.utils import process_samples
+    spec = type("Spec", (), dict(observation_dim=6, action_dim=2, horizon=40))
+    rng = np.random.RandomState(1)
+    paths = [dict(observations=rng.randn(40, 6), rewards=rng.randn(40), terminated=False) for _ in range(30)]
+    process_samples.compute_returns(paths, 0.99)
+    out = {}
+    for mode in ("taken", "discarded", "plain"):
+        import torch
+        torch.manual_seed(3); np.random.seed(3)
+        bl = MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3)
+        np.random.seed(21)
+        h = bl.predraw(30 * 40) if mode != "plain" else None
+        if mode != "taken":
+            np.random.randn(7)                                           # somebody uses the global stream in between
+        e = bl.fit_async(paths, return_errors=True, predrawn=h).result()
+        out[mode] = (bl.params.copy(), e, np.random.randn(3), bl.__dict__.get("predraw_stats"))
+    assert out["taken"][3] == (1, 0) and out["discarded"][3] == (0, 1)
+    assert np.array_equal(out["discarded"][0], out["plain"][0]) and out["discarded"][1] == out["plain"][1]
+    assert np.array_equal(out["discarded"][2], out["plain"][2])          # ... and the stream stands where the plain fit leaves it
+    # the taken draws are the plain fit's draws from the UNDISTURBED stream position
+    torch.manual_seed(3); np.random.seed(3)
+    ref = MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3)
+    np.random.seed(21)
+    ref.fit(paths)
+    assert np.array_equal(out["taken"][0], ref.params) and np.array_equal(out["taken"][2], np.random.randn(3))
