@@ -438,8 +438,8 @@ def user_level_measurements():
             main.synchronize(); t0 = time.perf_counter()
             with ingest.trusted_iteration():
                 process_samples.compute_returns(paths, 0.995); t1 = time.perf_counter()
+                pre = bl.predraw(N_TRAJ * T) if name == "mlp" else None       # (train_step: the epoch permutations drawn under advantages + update)
                 process_samples.compute_advantages(paths, bl, 0.995, 0.97); t2 = time.perf_counter()
-                pre = bl.predraw(N_TRAJ * T) if name == "mlp" else None       # (train_step: the epoch permutations drawn under the update)
                 agent.train_from_paths(paths); main.synchronize(); t3 = time.perf_counter()
                 if name == "mlp":
                     pend = bl.fit_async(paths, predrawn=pre)   # what BatchREINFORCE.train_step does: started, not waited for

@@ -117,9 +117,8 @@ class BatchREINFORCE:
         from ..utils.ingest import drop_shared_batch, trusted_iteration
         with trusted_iteration():               # nothing but this package touches `paths` from here to the baseline fit
             process_samples.compute_returns(paths, gamma)
-            process_samples.compute_advantages(paths, self.baseline, gamma, gae_lambda)
             # the MLP baseline's epoch permutations -- all that is left of its fit on the critical path -- start now, on a helper
-            # thread under the update's GPU time (speculative: the fit takes them over only if nobody touched NumPy's global
+            # thread under the advantage computation and the update (speculative: the fit takes them over only if nobody touched NumPy's global
             # stream in between; MLPBaseline.predraw).  Only for this package's own train_from_paths without row subsampling
             # (which draws from the same stream), one process.
             pre = None
@@ -128,6 +127,7 @@ class BatchREINFORCE:
                     and not (getattr(self, "hvp_subsample", None) is not None and self.hvp_subsample < 0.99)
                     and type(self).__name__ not in ("PPO",)):
                 pre = self.baseline.predraw(sum(len(p["rewards"]) for p in paths))
+            process_samples.compute_advantages(paths, self.baseline, gamma, gae_lambda)
             eval_statistics = self.train_from_paths(paths)
             eval_statistics.append(N)
             # The fitted baseline is not read before the NEXT iteration's compute_advantages, and sampling comes first
