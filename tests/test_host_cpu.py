@@ -455,3 +455,65 @@ def test_native_minibatch_indices_are_numpys_choice_stream():
             b = minibatch_indices(lib, n, steps, mb)
             tb = np.random.permutation(5)
             assert np.array_equal(a, b) and np.array_equal(ta, tb), (seed, n, steps, mb)
+
+
+def test_pending_log_entries_become_numbers(tmp_path):
+    """utils/logger.py: a value logged before it exists (the errors / duration of a baseline fit still running on a side stream) --
+    float() waits for it, get_current_log hands it on, save_log settles everything so log.csv / log.pickle hold numbers only, a
+    pickle of the entry is a float"""
+    from mjrl_amd.utils.logger import DataLog, PendingValue
+
+    class Source:
+        def __init__(self):
+            self.hooks, self.is_done, self.waited = [], False, 0
+
+        def finished(self):
+            return self.is_done
+
+        def result(self):
+            self.waited += 1
+            for h in self.hooks:
+                h()
+    log, src = DataLog(), Source()
+    pv = PendingValue(src)
+    src.hooks.append(lambda: pv.deliver(0.25))
+    log.log_kv("alpha", 1.5); log.log_kv("VF_error_after", pv)
+    assert str(pv) == "(fitting)" and src.waited == 0                    # printing does not wait
+    row = log.get_current_log()
+    assert row["alpha"] == 1.5 and isinstance(row["VF_error_after"], PendingValue) and src.waited == 0
+    assert float(row["VF_error_after"]) == 0.25 and src.waited == 1      # reading the number does
+    assert pv * 2 == 0.5 and 1 - pv == 0.75 and pickle.loads(pickle.dumps(pv)) == 0.25
+    pv2 = PendingValue(src)
+    src.hooks[:] = [lambda: pv2.deliver(0.5)]
+    log.log_kv("alpha", 1.25); log.log_kv("VF_error_after", pv2)
+    log.save_log(str(tmp_path))                                          # settles the one still pending
+    assert log.log["VF_error_after"] == [pv, 0.5] or log.log["VF_error_after"] == [0.25, 0.5]
+    rows = open(tmp_path / "log.csv").read().strip().splitlines()
+    assert len(rows) == 3 and "fitting" not in "".join(rows) and rows[2].split(",")[-1] in ("0.5", "1.25")
+    again = DataLog(); again.read_log(str(tmp_path / "log.csv"))
+    assert [float(x) for x in again.log["VF_error_after"]] == [0.25, 0.5]
+    src.is_done = True
+    pv3 = PendingValue(src); src.hooks[:] = [lambda: pv3.deliver(2.0)]
+    assert str(pv3) == "2.0"                                             # finished meanwhile: printing takes it over without waiting
+
+
+def test_dropin_binds_the_reference_module_names(tmp_path):
+    """mjrl_amd.dropin.install(): `from mjrl.algos.npg_cg import NPG` (examples/policy_opt_job_script.py:8-15) then yields this package's
+    classes while mjrl.utils / mjrl.samplers stay the reference's -- in a process of its own (the aliases are process-wide)"""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from oracle import ref_loader\n"
+        "if ref_loader.install() is None: print('SKIP'); raise SystemExit\n"
+        "from mjrl_amd import dropin; n = len(dropin.install())\n"
+        "from mjrl.algos.npg_cg import NPG; from mjrl.policies.gaussian_mlp import MLP; from mjrl.baselines.mlp_baseline import MLPBaseline\n"
+        "import mjrl.algos.trpo as t; from mjrl.utils.train_agent import train_agent; from mjrl.samplers.core import sample_paths\n"
+        "print(n, NPG.__module__, MLP.__module__, MLPBaseline.__module__, t.TRPO.__module__, train_agent.__module__, sample_paths.__module__)\n"
+    ) % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    if "SKIP" in r.stdout:
+        pytest.skip("reference not available")
+    assert r.stdout.split() == ["13", "mjrl_amd.algos.npg_cg", "mjrl_amd.policies.gaussian_mlp", "mjrl_amd.baselines.mlp_baseline",
+                                "mjrl_amd.algos.trpo", "mjrl.utils.train_agent", "mjrl.samplers.core"], r.stdout
