@@ -79,7 +79,39 @@ static PyObject* pw_identity(PyObject* self, PyObject* args) {
   return PyLong_FromLong(1);
 }
 
+/* hand_out(paths, key, host, offsets) -> list of views: paths[i][key] = host[offsets[i]:offsets[i + 1]] for every path -- the per-path
+ * views of a block that was computed on the device and read back once (returns, baseline values, advantages:
+ * utils/process_samples.py).  1 000 slices + dict stores per block and three blocks per iteration: 0.45 ms each as a Python loop,
+ * 0.1 ms here. */
+static PyObject* pw_hand_out(PyObject* self, PyObject* args) {
+  PyObject *paths, *key, *host;
+  Py_buffer ob;
+  if (!PyArg_ParseTuple(args, "O!UOy*", &PyList_Type, &paths, &key, &host, &ob)) return NULL;
+  const Py_ssize_t n = PyList_GET_SIZE(paths);
+  if (ob.len < (Py_ssize_t)((n + 1) * sizeof(int64_t))) {
+    PyBuffer_Release(&ob);
+    PyErr_SetString(PyExc_ValueError, "hand_out: offsets shorter than the path list + 1");
+    return NULL;
+  }
+  const int64_t* off = (const int64_t*)ob.buf;
+  PyObject* views = PyList_New(n);
+  if (!views) { PyBuffer_Release(&ob); return NULL; }
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject* path = PyList_GET_ITEM(paths, i);
+    PyObject* v = PyDict_Check(path) ? PySequence_GetSlice(host, (Py_ssize_t)off[i], (Py_ssize_t)off[i + 1]) : NULL;
+    if (!v || PyDict_SetItem(path, key, v) != 0) {
+      if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "hand_out: paths must be a list of dicts");
+      Py_XDECREF(v); Py_DECREF(views); PyBuffer_Release(&ob);
+      return NULL;
+    }
+    PyList_SET_ITEM(views, i, v);                               /* steals the reference */
+  }
+  PyBuffer_Release(&ob);
+  return views;
+}
+
 static PyMethodDef methods[] = {
+    {"hand_out", pw_hand_out, METH_VARARGS, "hand_out(paths, key, host, offsets) -> [host[offsets[i]:offsets[i+1]]], stored as paths[i][key]"},
     {"collect", pw_collect, METH_VARARGS, "collect(paths, key, ptrs, lens) -> width * 16 + itemsize, or -1"},
     {"identity", pw_identity, METH_VARARGS, "identity(paths, key, arrays) -> 1 if paths[i][key] is arrays[i] for all i"},
     {NULL, NULL, 0, NULL}};

@@ -60,6 +60,9 @@ def _hand_out(h, paths, key, block, off):
     """one read-back of a device block; the paths get per-path views of the host copy -> the list of views"""
     host = ingest.download_owned(h, block)   # (page-locked memory that lives as long as the paths' views of it)
     host.setflags(write=False)          # the device block stays registered for this batch: an in-place edit of a view must not go unnoticed (utils/ingest.py)
+    pw = ingest._pathwalk
+    if pw is not None and hasattr(pw, "hand_out") and type(paths) is list and isinstance(off, np.ndarray) and off.dtype == np.int64 and off.flags.c_contiguous:
+        return pw.hand_out(paths, key, host, off)               # the same slices and dict stores in one C loop (csrc/pathwalk.c)
     views = [host[off[i]:off[i + 1]] for i in range(len(paths))]
     for p, v in zip(paths, views):
         p[key] = v

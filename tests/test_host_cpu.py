@@ -517,3 +517,32 @@ def test_dropin_binds_the_reference_module_names(tmp_path):
         pytest.skip("reference not available")
     assert r.stdout.split() == ["13", "mjrl_amd.algos.npg_cg", "mjrl_amd.policies.gaussian_mlp", "mjrl_amd.baselines.mlp_baseline",
                                 "mjrl_amd.algos.trpo", "mjrl.utils.train_agent", "mjrl.samplers.core"], r.stdout
+
+
+def test_path_walk_hand_out_equals_the_python_loop():
+    """_pathwalk.hand_out: paths[i][key] = host[off[i]:off[i + 1]] in one C loop -- the same read-only views of the same block, the
+    buffer's reference count following the views like it does for Python-made slices (ingest.download_owned recycles a page-locked
+    block when its last view has died)"""
+    import sys
+    from mjrl_amd.utils import ingest
+    if ingest._pathwalk is None or not hasattr(ingest._pathwalk, "hand_out"):
+        pytest.skip("_pathwalk not built")
+    rng = np.random.RandomState(0)
+    lens = rng.randint(0, 50, 40)
+    off = np.zeros(41, np.int64); np.cumsum(lens, out=off[1:])
+    root = np.arange(int(off[-1]) + 8, dtype=np.float64)
+    host = root[:int(off[-1])]
+    host.setflags(write=False)
+    paths = [dict(rewards=np.zeros(l)) for l in lens]
+    before = sys.getrefcount(root)
+    views = ingest._pathwalk.hand_out(paths, "returns", host, off)
+    assert len(views) == 40 and all(paths[i]["returns"] is views[i] for i in range(40))
+    for i in range(40):
+        assert np.array_equal(views[i], host[off[i]:off[i + 1]]) and not views[i].flags.writeable and views[i].base is root
+    assert sys.getrefcount(root) == before + 40
+    del views
+    for p in paths:
+        p.pop("returns")
+    assert sys.getrefcount(root) == before
+    with pytest.raises((TypeError, ValueError)):
+        ingest._pathwalk.hand_out([1, 2], "returns", host, off)
