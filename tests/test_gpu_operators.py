@@ -621,7 +621,7 @@ def test_background_prefetch_hands_out_complete_blocks():
     ingest.drop_shared()
 
 
-@pytest.mark.parametrize("d_in", [9, 21, 23, 27, 35, 43, 50, 55, 64, 115, 380])
+@pytest.mark.parametrize("d_in", [9, 21, 23, 27, 35, 43, 50, 55, 56, 64, 96, 97, 115, 380, 768, 769])
 def test_persistent_mlp_trainer_equals_per_step_launches(monkeypatch, d_in):
     """The persistent single-workgroup trainer of the MLP baseline (csrc/mlp_fit.h; two 32-feature blocks of the input
     layer beyond 31 inputs, as far as 160 KB of LDS reach: 55; the Adroit observations + 4 time features are 43..50)
