@@ -912,6 +912,10 @@ struct LayerwiseWS {
   std::vector<float*> P, RD;         // general-HVP extras: pre-activation cotangents / R-deltas (lazy)
   float* rd3 = nullptr; int64_t gen_cap = 0;
   float* part = nullptr; int64_t part_cap = 0;          // split-K partials
+  // MJX_LW_OVERLAP=1 (experiment, r05): the weight gradient of layer l on a side stream beside the delta product towards layer
+  // l - 1 (both only read delta_l): its own column-sum workspace, one event fork / join per layer
+  float* cpart2 = nullptr; int64_t cpart2_cap = 0;
+  hipStream_t side = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;
   double* hpart = nullptr;           // head partials
   bool fwd_valid = false;
   int nL() const { return (int)sizes.size() - 1; }   // number of affine layers
@@ -933,6 +937,10 @@ struct LayerwiseWS {
     for (auto& p : H) { hipFree(p); p = nullptr; }
     for (auto& p : T) { hipFree(p); p = nullptr; }
     hipFree(mu); hipFree(mu2); hipFree(d3); hipFree(part); hipFree(hpart); hipFree(rd3); rd3 = nullptr; gen_cap = 0;
+    hipFree(cpart2); cpart2 = nullptr; cpart2_cap = 0;
+    if (side) { (void)hipStreamDestroy(side); side = nullptr; }
+    if (ev_a) { (void)hipEventDestroy(ev_a); ev_a = nullptr; }
+    if (ev_b) { (void)hipEventDestroy(ev_b); ev_b = nullptr; }
     for (auto& p : P) { hipFree(p); p = nullptr; }
     for (auto& p : RD) { hipFree(p); p = nullptr; }
     mu = mu2 = d3 = part = nullptr; hpart = nullptr; cap = 0; part_cap = 0;
@@ -1203,7 +1211,16 @@ struct LayerwiseWS {
   int backward(const float* theta, int64_t N, float* grad, hipStream_t st, int l_start = -1, const float* delta0 = nullptr) {
     const float* delta = delta0 ? delta0 : d3;
     bool bias_done = delta0 != nullptr;
+    static const bool overlap_on = [] { const char* e = getenv("MJX_LW_OVERLAP"); return e && e[0] == '1'; }();
+    const bool overlap = overlap_on && N >= 65536;
+    if (overlap && !side) {
+      if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_a, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ev_b, hipEventDisableTiming) != hipSuccess) return 2;
+    }
+    hipStream_t main_st = st;
+    if (overlap) { (void)hipEventRecord(ev_a, main_st); (void)hipStreamWaitEvent(side, ev_a, 0); }     // delta of the top layer is ready on the caller's stream
     for (int l = (l_start >= 0 ? l_start : nL() - 1); l >= 0; --l) {
+      if (overlap) st = side;                        // this layer's weight gradient (and its reductions) go to the side stream
       const int ho = sizes[l + 1], hi_ = sizes[l];
       const float* in = (l == 0) ? Xn : H[l - 1];
       // weight gradient: gW[ho x hi] = delta^T (ho x N) * in (N x hi), split over samples
@@ -1246,6 +1263,13 @@ struct LayerwiseWS {
       if (padw) hipLaunchKernelGGL(k_unpad_rows, dim3(ew_grid((int64_t)ho * hi_)), dim3(256), 0, st, G1p, ho, hi_, wN, grad + oW[l]);
       float* bpart = part + (int64_t)splits * ho * wN;
       float* cpart = bpart + (int64_t)csplits * ho;
+      if (overlap) {
+        // the delta product below runs on the caller's stream beside this layer's weight gradient: its column-sum partials get a
+        // block of their own (the next layer's gradient slabs on the side stream may grow over `cpart`)
+        const int64_t need = (int64_t)rowblocks * hi_ + (int64_t)rsplits * hi_;
+        if (need > cpart2_cap) { hipFree(cpart2); cpart2 = nullptr; cpart2_cap = 0; if (hipMalloc(&cpart2, (size_t)need * 4) != hipSuccess) return 2; cpart2_cap = need; }
+        cpart = cpart2;
+      }
       if (!bias_done) {
         const int cs = (N <= 4096) ? 1 : csplits;
         float* dst = (cs == 1) ? grad + ob[l] : bpart;
@@ -1255,6 +1279,7 @@ struct LayerwiseWS {
           hipLaunchKernelGGL(k_reduce_partials, dim3((ho + 15) / 16), dim3(256), 0, st, bpart, cs, ho, grad + ob[l],
                              (const float*)nullptr, (const float*)nullptr, 0, 0.f);
       }
+      if (overlap) st = main_st;                     // ... the delta product towards the layer below stays on the caller's stream
       if (l > 0) {
         // delta_{l} = (delta_{l+1} W_l) (1 - H_{l-1}^2)   -> T[l-1]   (+ its column sums = grad b_{l-1})
         GemmArgs b{};
@@ -1279,8 +1304,10 @@ struct LayerwiseWS {
                              (const float*)nullptr, (const float*)nullptr, 0, 0.f);
         bias_done = true;
         delta = T[l - 1];
+        if (overlap) { (void)hipEventRecord(ev_a, main_st); (void)hipStreamWaitEvent(side, ev_a, 0); }   // the next layer's gradient needs this delta
       }
     }
+    if (overlap) { (void)hipEventRecord(ev_b, side); (void)hipStreamWaitEvent(main_st, ev_b, 0); }      // join: the gradients are complete on the caller's stream
     return hipGetLastError() == hipSuccess ? 0 : 1;
   }
 
