@@ -107,6 +107,12 @@ class BatchREINFORCE:
             paths = []
         elif sample_mode == 'trajectories':
             paths = trajectory_sampler.sample_paths(num_traj=n_mine, **common)
+            if d is not None and len(paths) != n_mine:
+                # (a sampler that rounds each worker's share up -- core.py:124 with num_cpu not dividing the share -- hands back more
+                #  episodes than asked for: the ranks' lists are then no longer the one-process batch)
+                import warnings
+                warnings.warn("mjrl_amd: rank %d asked its sampler for %d trajectories and got %d (num_cpu = %r does not divide the "
+                              "share?): the ranks' batches no longer add up to the one-process batch" % (d.get_rank(), n_mine, len(paths), num_cpu))
         else:
             paths = trajectory_sampler.sample_data_batch(num_samples=n_mine, **common)
         if self.save_logs:
