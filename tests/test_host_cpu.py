@@ -546,3 +546,15 @@ def test_path_walk_hand_out_equals_the_python_loop():
     assert sys.getrefcount(root) == before
     with pytest.raises((TypeError, ValueError)):
         ingest._pathwalk.hand_out([1, 2], "returns", host, off)
+
+
+def test_allocator_tuning_is_applied_once_and_can_be_switched_off():
+    """utils/ingest._tune_malloc: glibc's mmap / trim thresholds raised in the training process (what made releasing a rollout batch
+    cost 0.5 or 13 ms); MJX_MALLOC_TUNE=0 leaves the allocator alone"""
+    import subprocess
+    import sys
+    from mjrl_amd.utils import ingest
+    assert ingest.MALLOC_TUNED is True
+    code = "import sys; sys.path.insert(0, %r); from mjrl_amd.utils import ingest; print(ingest.MALLOC_TUNED)" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MJX_MALLOC_TUNE="0"), timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "False", (r.stdout, r.stderr[-500:])
