@@ -386,7 +386,9 @@ int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, con
  * release fences), so a timed run samples with a stride that is coprime to the CG iteration count
  * instead of bracketing every launch.  mjx_profile_read synchronises and returns out[0] = total
  * milliseconds, out[1] = number of launches measured since the last mjx_profile_enable(ctx, k);
- * on = 0 switches the events off. */
+ * on = 0 switches the events off.  on = -k (r06): every k-th ITERATION of mjx_cg_solve's loop as a whole instead -- product,
+ * reduction (+ peer exchange) and vector update between one pair of events (the last iteration, which also forms the step, is
+ * left out); what bench.py's 8-rank rehearsal reports next to the product's own time. */
 int mjx_profile_enable(mjx_ctx* ctx, int on);
 int mjx_profile_read(mjx_ctx* ctx, double* out_host);
 /* every bracketed launch's HIP-event time on its own (milliseconds, launch order; at most `cap` of them are written,

@@ -86,6 +86,8 @@ class BatchREINFORCE:
             env = self.env.env_id if hasattr(self.env, "env_id") else self.env
         if sample_mode not in ('trajectories', 'samples'):
             raise ValueError("sample_mode must be either 'trajectories' or 'samples'")
+        from ..utils import ingest as _ingest
+        _ingest.tune_malloc()                   # this is a training process: host allocator policy for rollout batches (once; utils/ingest.py)
         t0 = timer.time()
         # One process per GPU (torch.distributed initialised): N is the size of the WHOLE batch and every rank samples its
         # contiguous share of it.  In sample_mode 'trajectories' the share is a range of EPISODES seeded as a single process
@@ -106,7 +108,13 @@ class BatchREINFORCE:
         if n_mine <= 0:
             paths = []
         elif sample_mode == 'trajectories':
-            paths = trajectory_sampler.sample_paths(num_traj=n_mine, **common)
+            # ingestion under sampling: this package's sampler hands every finished chunk of episodes to the stager
+            # while the later ones are still being simulated -- rewards, observations and actions are resident when sampling ends
+            # (utils/ingest.StreamedBatch; MJX_STREAM_INGEST=0: stage after sampling).  An env ID goes to the reference's own
+            # sampler, whose workers return their whole share at once (samplers/core.py:196-205): today's path.
+            sink = None if isinstance(env, str) else _ingest.StreamedBatch.for_current_device()
+            paths = trajectory_sampler.sample_paths(num_traj=n_mine, **common, **({} if sink is None else {"sink": sink}))
+            self.last_ingest = None if sink is None else dict(streamed=bool(sink.finish(paths)), chunks=sink.chunks, why_not=sink.why)
             if d is not None and len(paths) != n_mine:
                 # (a sampler that rounds each worker's share up -- core.py:124 with num_cpu not dividing the share -- hands back more
                 #  episodes than asked for: the ranks' lists are then no longer the one-process batch)
@@ -155,6 +163,11 @@ class BatchREINFORCE:
                 fit_async(paths, **({"predrawn": pre} if pre is not None else {}))
             else:
                 self.baseline.fit(paths)
+            if self.save_logs and hasattr(self.baseline, "predraw"):
+                # how often the speculative permutation draws were (not) the fit's own draws, cumulative (MLPBaseline._take_predrawn)
+                taken, discarded = getattr(self.baseline, "predraw_stats", (0, 0)) if "predraw_stats" in vars(self.baseline) else (0, 0)
+                self.logger.log_kv('VF_predraw_taken', taken)
+                self.logger.log_kv('VF_predraw_discarded', discarded)
         drop_shared_batch()                     # the iteration's one upload served predict, update and fit; nothing may outlive it
         return eval_statistics
 

@@ -107,6 +107,8 @@ class MLPBaseline:
         state.pop("_pending", None)
         state.pop("_pins", None)
         state.pop("predraw_stats", None)
+        state.pop("_predraw_misses", None)
+        state.pop("_predraw_warned", None)
         return state
 
     def _settle(self):
@@ -119,13 +121,23 @@ class MLPBaseline:
         pend.end_ev.synchronize()
         h = pend.host
         n = d["params"].size
+        if self.epochs > 0 and np.isnan(h["losses"][:self.epochs]).any() and pend.num_samples > 0:
+            # the several-workgroup trainer (csrc/mlp_fit.h, MULTI + k_mlp_fit_verdict) turns every loss into NaN when a workgroup
+            # waited ~2 s for another.  The baseline keeps what it had BEFORE this fit (parameters, moments, step count, losses);
+            # whoever waits on the pending entries (logger.PendingValue, PendingFit.result) is served -- with NaN -- before the
+            # error is raised, so a later save_log() / pickle does not trip over a half-settled fit
+            from .._lib import MjxError
+            d["adam_steps"] = pend.steps_before
+            pend.device_ms = float(pend.start_ev.elapsed_time(pend.end_ev))
+            pend.value = (float("nan"), float("nan")) if pend.returns is not None else None
+            pend.done, pend.keep = True, []
+            hooks, pend.hooks = pend.hooks, []
+            for hook in hooks:
+                hook(pend.value, pend.device_ms)
+            raise MjxError("MLPBaseline.fit: non-finite epoch losses (a workgroup of the persistent trainer gave up waiting for "
+                           "the others, or the fit diverged); the baseline keeps the parameters it had before this fit")
         d["params"], d["adam_m"], d["adam_v"] = (h["pmv"][i * pend.seg:i * pend.seg + n].copy() for i in range(3))
         d["epoch_losses"] = list(h["losses"][:self.epochs].astype(np.float64) / max(pend.steps, 1))
-        if self.epochs > 0 and np.isnan(h["losses"][:self.epochs]).any() and pend.num_samples > 0:
-            # the several-workgroup trainer (csrc/mlp_fit.h, MULTI) poisons the losses when a workgroup waited ~2 s for another
-            from .._lib import MjxError
-            raise MjxError("MLPBaseline.fit: non-finite epoch losses (a workgroup of the persistent trainer gave up waiting for "
-                           "the others, or the fit diverged); parameters of this fit are not to be trusted")
         pend.device_ms = float(pend.start_ev.elapsed_time(pend.end_ev))
         if pend.returns is not None:
             r = pend.returns[:pend.num_samples]
@@ -203,6 +215,16 @@ class MLPBaseline:
             np.random.set_state(('MT19937', h["key"], int(h["pos"].value), st[3], st[4]))
         d = self.__dict__
         d["predraw_stats"] = (d.get("predraw_stats", (0, 0))[0] + int(same), d.get("predraw_stats", (0, 0))[1] + int(not same))    # (taken, discarded)
+        # somebody else draws from np.random between compute_returns and the fit in EVERY iteration (a callback, an env wrapper): the
+        # speculative draws are thrown away each time and ~11 ms per 1M rows x 2 epochs are back on the critical path.  Say so once.
+        d["_predraw_misses"] = 0 if same else d.get("_predraw_misses", 0) + 1
+        if d["_predraw_misses"] == 2 and not d.get("_predraw_warned"):
+            d["_predraw_warned"] = True
+            import warnings
+            warnings.warn("mjrl_amd.MLPBaseline: the speculative epoch permutations were discarded twice in a row -- something draws from "
+                          "NumPy's global generator between the returns and the baseline fit of an iteration, so the draws run on the "
+                          "critical path again (correct results, ~11 ms per 1M timesteps x 2 epochs slower); predraw_stats = "
+                          "(taken %d, discarded %d)" % d["predraw_stats"])
         return same
 
     def fit(self, paths, return_errors=False):
@@ -263,7 +285,7 @@ class MLPBaseline:
         losses = torch.zeros(max(self.epochs, 1), dtype=torch.float64, device=blk.dev)
         steps = max(int(num_samples / self.batch_size) - 1, 0)
         pend = PendingFit(self)
-        pend.steps, pend.num_samples, pend.seg = steps, num_samples, seg
+        pend.steps, pend.num_samples, pend.seg, pend.steps_before = steps, num_samples, seg, int(self.adam_steps)
         main, side = torch.cuda.current_stream(blk.dev), _fit_stream(torch, blk.dev)
         side.wait_stream(main)                                  # everything above is queued on the caller's stream
         host = dict(pmv=self._pinned(torch, "pmv", 3 * seg, torch.float32), losses=self._pinned(torch, "losses", max(self.epochs, 1), torch.float64))

@@ -108,6 +108,7 @@ struct mjx_ctx {
   std::vector<hipEvent_t> prof_ev;   // pairs
   size_t prof_used = 0;
   int prof_stride = 1;               // bracket every prof_stride-th launch
+  bool prof_iter = false;            // bracket whole CG iterations (mjx_profile_enable(ctx, -k)) instead of product launches
   size_t prof_seen = 0;
   void* comm = nullptr; int comm_world = 0, comm_rank = 0;   // RCCL communicator (one process per GPU)
   mjx_reduce_fn reduce_cb = nullptr; void* reduce_user = nullptr;   // transport hook in its place (tests)
@@ -473,7 +474,21 @@ int mjx_mlp_predict(const float* feat, int64_t N, int d_in, const int* hidden, i
   MlpRegressor net; net.init(d_in, hidden, n_hidden);
   const int64_t CH = 1 << 17;
   size_t per_row = 0; for (int i = 0; i < n_hidden; ++i) per_row += hidden[i];
-  static thread_local Scratch sc;
+  // the activation scratch is kept PER STREAM: MLPBaseline.fit_async runs its before / after forwards on a side stream while the
+  // caller's stream may be predicting with another baseline -- one shared block would be written by both at once
+  static thread_local std::vector<std::pair<void*, Scratch>> by_stream;
+  Scratch* scp = nullptr;
+  for (auto& e : by_stream) if (e.first == stream) scp = &e.second;
+  if (!scp) {
+    if (by_stream.size() >= 8) {                 // (streams come and go: forget the oldest block once nothing can still be using it)
+      HIPCHK(hipDeviceSynchronize());
+      if (by_stream.front().second.p) (void)hipFree(by_stream.front().second.p);
+      by_stream.erase(by_stream.begin());
+    }
+    by_stream.push_back({stream, Scratch{}});
+    scp = &by_stream.back().second;
+  }
+  Scratch& sc = *scp;
   if (int rc = get_scratch(sc, (size_t)CH * (per_row ? per_row : 1) * sizeof(float))) return rc;
   std::vector<float*> acts(n_hidden);
   { float* q = (float*)sc.p; for (int i = 0; i < n_hidden; ++i) { acts[i] = q; q += (size_t)CH * hidden[i]; } }
@@ -564,6 +579,7 @@ int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, con
       HIPCHK(hipMemsetAsync(xch + xbytes, 0, 256, st));                       // the counter (the exchange block needs no clearing)
       MlpFitArgs a{feat, y, perm, N, d_in, epochs, steps_, params, m, v, (float*)mvws.p, step0, lr, wd, epoch_loss_out};
       a.xch = (float*)xch; a.bar = (unsigned*)(xch + xbytes); a.G = G; a.FS = FS;
+      { const char* f = getenv("MJX_FIT_FAULT"); a.fault = (f && !strcmp(f, "straggler")) ? 1 : 0; }      // (tests/test_gpu_lifecycle.py)
       static thread_local bool configured = false;
       if (!configured) {
         HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fit<128, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
@@ -573,6 +589,9 @@ int mjx_mlp_fit_adam(const float* feat, const float* y, int64_t N, int d_in, con
       const char* rm = getenv("MJX_FIT_REGMOM");
       if (!(rm && rm[0] == '0')) hipLaunchKernelGGL((k_mlp_fit<128, 2, true, true>), dim3(G), dim3(256), Lw.bytes(), st, a);
       else hipLaunchKernelGGL((k_mlp_fit<128, 2, false, true>), dim3(G), dim3(256), Lw.bytes(), st, a);
+      // a barrier wait that timed out (a workgroup without a CU) is recorded in a word of its own; this turns it into NaN epoch
+      // losses AFTER every workgroup has left -- the last writer of epoch_loss no longer decides
+      hipLaunchKernelGGL(k_mlp_fit_verdict, dim3(1), dim3(64), 0, st, (const unsigned*)a.bar + 1, epoch_loss_out, epochs);
       HIPCHK(hipGetLastError());
       return MJX_OK;
     }
@@ -641,7 +660,8 @@ int mjx_profile_enable(mjx_ctx* c, int on) {
     for (auto& e : c->prof_ev) HIPCHK(hipEventCreate(&e));
   }
   c->prof_on = on != 0;
-  if (on) { c->prof_used = 0; c->prof_seen = 0; c->prof_stride = on; }
+  c->prof_iter = on < 0;                       // on = -k: every k-th CG ITERATION (product, reduction / exchange, vector update) instead of the product alone
+  if (on) { c->prof_used = 0; c->prof_seen = 0; c->prof_stride = on < 0 ? -on : on; }
   return MJX_OK;
 }
 
@@ -691,7 +711,9 @@ int mjx_set_clock_buffer(mjx_ctx* c, int64_t* clk) {
   return MJX_OK;
 }
 
-int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
+// pp (peer exchange): the gradient's reduction kernel writes this rank's slot (grad_out IS that slot) into every peer's buffer,
+// K1's 4 sums travel with it at byte scal_off of the slot (scal_out: that place in the own slot), one arrival flag for both
+static int surr_vpg_impl(mjx_ctx* c, float* grad_out, double* scal_out, void* stream, const PeerPush* pp, int scal_off) {
   if (int rc = check_bound(c, true)) return rc;
   if (!grad_out || !scal_out) return fail(MJX_ERR_ARG, "null output");
   hipStream_t st = (hipStream_t)stream;
@@ -737,16 +759,21 @@ int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) {
     }
   }
   if (int rc = dispatch_fused(c, MODE_VPG, a, st)) return rc;
-  if ((c->d & 3) == 0)
-    hipLaunchKernelGGL(k_reduce_partials4, dim3((c->d + 31) / 32), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
-                       grad_out, (const float*)nullptr, (const float*)nullptr, c->oS, 0.f);
-  else
+  if ((c->d & 3) == 0) {
+    // the 4 sums are reduced by one extra workgroup of the vector reduction (r06: no launch of their own)
+    hipLaunchKernelGGL(k_reduce_partials4, dim3((c->d + 31) / 32 + 1), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
+                       grad_out, (const float*)nullptr, (const float*)nullptr, c->oS, 0.f, pp ? *pp : PeerPush{},
+                       ScalTail{c->spartials, c->grid, scal_out, pp ? scal_off : -1});
+  } else {
     hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
                        grad_out, (const float*)nullptr, (const float*)nullptr, c->oS, 0.f);
-  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, c->grid, scal_out);
+    hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, c->grid, scal_out, PeerPush{});
+  }
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }
+
+int mjx_surr_vpg(mjx_ctx* c, float* grad_out, double* scal_out, void* stream) { return surr_vpg_impl(c, grad_out, scal_out, stream, nullptr, -1); }
 
 // pp: peer exchange folded into the reduction kernel (fused kernels with d % 4 == 0 only; `out` is then this rank's slot)
 static int fvp_impl(mjx_ctx* c, const float* v, float* out, void* stream, const PeerPush* pp) {
@@ -764,7 +791,7 @@ static int fvp_impl(mjx_ctx* c, const float* v, float* out, void* stream, const 
     return rc ? fail(MJX_ERR_STATE, "general Hessian-vector product failed (%d)", rc) : MJX_OK;
   }
   const float frac = (float)((double)c->N_local / (double)c->N_global);
-  const bool prof = c->prof_on && (c->prof_seen++ % (size_t)c->prof_stride == 0) && c->prof_used + 2 <= c->prof_ev.size();
+  const bool prof = c->prof_on && !c->prof_iter && (c->prof_seen++ % (size_t)c->prof_stride == 0) && c->prof_used + 2 <= c->prof_ev.size();
   if (prof) HIPCHK(hipEventRecord(c->prof_ev[c->prof_used], st));
   if (!c->fused) {
     int rc = c->lw.fvp(c->obs, c->N_local, c->N_global, c->theta_new, c->tr_new ? c->tr_new : c->ident_tr, v, out, st);
@@ -792,7 +819,9 @@ static int fvp_impl(mjx_ctx* c, const float* v, float* out, void* stream, const 
 
 int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) { return fvp_impl(c, v, out, stream, nullptr); }
 
-int mjx_eval_surr_kl(mjx_ctx* c, double* scal_out, void* stream) {
+// pp (peer exchange): the reduction of K3's sums writes them into slot `rank` of every buffer (scal_out IS the own slot) and raises
+// the flags; the caller launches the consumer (k_peer_sum<double>)
+static int eval_impl(mjx_ctx* c, double* scal_out, void* stream, const PeerPush* pp) {
   if (int rc = check_bound(c, true)) return rc;
   if (!scal_out) return fail(MJX_ERR_ARG, "null output");
   hipStream_t st = (hipStream_t)stream;
@@ -809,10 +838,12 @@ int mjx_eval_surr_kl(mjx_ctx* c, double* scal_out, void* stream) {
   static const bool ximg_on = [] { const char* e = getenv("MJX_K3_XIMG"); return !(e && e[0] == '0'); }();
   if (ximg_on && a.ocache && c->ximg_ok && c->hcache && c->N_local <= c->ximg_rows && c->obs == c->hcache_obs) a.hcache = c->hcache;
   if (int rc = dispatch_fused(c, MODE_EVAL, a, st)) return rc;
-  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, 2 * c->grid, scal_out);
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, 2 * c->grid, scal_out, pp ? *pp : PeerPush{});
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }
+
+int mjx_eval_surr_kl(mjx_ctx* c, double* scal_out, void* stream) { return eval_impl(c, scal_out, stream, nullptr); }
 
 // ---------------------------------------------------------------------------- peer exchange (HIP IPC + stream memory operations)
 namespace {
@@ -892,14 +923,41 @@ int mjx_cg_finish(mjx_ctx* c, const float* b, float* x_out, double* bdotx_out, v
   return MJX_OK;
 }
 
-int mjx_cg_solve(mjx_ctx* c, const float* b, int iters, float damping, double tol, float* x_out, double* bdotx_out,
-                 mjx_allreduce_fn allreduce, void* user, void* stream) {
-  if (!c || !b || iters < 0) return fail(MJX_ERR_ARG, "bad arguments");
-  if (int rc = mjx_cg_init(c, b, stream)) return rc;
+}  // extern "C"  (internal helpers with C++ types follow)
+namespace {
+// d-float vectors the peer exchange folds into the loop's own kernels (k_reduce_partials4 / k_cg_step_reg<8, W>)
+bool peer_folded(const mjx_ctx* c) { return c->peer.on && c->fused && (c->d & 3) == 0 && c->d <= 8 * 1024; }
+// where the 4 doubles that travel with a gradient sit in a slot (mjx_peer_export sizes the slots for it)
+int peer_scal_off(const mjx_ctx* c) { return (int)(((size_t)c->d * sizeof(float) + 15) & ~(size_t)15); }
+
+// The solve, with (r06) what precedes and follows it folded into its own launches when the shapes allow:
+//  * b_slots: the right-hand side arrives as one slot per rank (the gradient's peer exchange, with K1's 4 sums riding along):
+//    k_cg_init_w waits, sums, leaves the summed gradient in `b` and the sums in s4_out;
+//  * fin: after the LAST vector update the same kernel forms b.x, x_out and (mode 2 / 3) the stepped parameters -- k_cg_finish and
+//    k_apply_*_step are not launched (d <= 8192 and at least one iteration; otherwise they are, as before).
+int cg_solve_impl(mjx_ctx* c, float* b, int iters, float damping, double tol, float* x_out, double* bdotx_out, mjx_allreduce_fn allreduce,
+                  void* user, void* stream, const PeerSlots* b_slots, double* s4_out, CgFin fin) {
+  hipStream_t st = (hipStream_t)stream;
+  if (b_slots) {
+    c->fvp_seq = 0;
+    const int off = peer_scal_off(c);
+#define MJX_INIT_W(W) hipLaunchKernelGGL((k_cg_init_w<W>), dim3(1), dim3(1024), 0, st, *b_slots, off, b, s4_out, c->cg_x, c->cg_r, c->cg_p, c->cg_scal, (int)c->d)
+    if (c->peer.world <= 2) MJX_INIT_W(2); else if (c->peer.world <= 4) MJX_INIT_W(4); else if (c->peer.world <= 8) MJX_INIT_W(8); else MJX_INIT_W(16);
+#undef MJX_INIT_W
+    HIPCHK(hipGetLastError());
+  } else if (int rc = mjx_cg_init(c, b, stream)) return rc;
+  const bool reg = c->d <= 8 * 1024;
+  bool fin_done = false;
+  fin.b = b; fin.x_out = x_out; fin.bdotx = bdotx_out; fin.oS = c->oS;
   for (int i = 0; i < iters; ++i) {
-    if (!allreduce && c->peer.on && c->fused && c->old_is_new && c->N_local > 0 && (c->d & 3) == 0 && c->d <= 8 * 1024) {
+    const CgFin f = (reg && i == iters - 1) ? fin : CgFin{};
+    // (mjx_profile_enable(ctx, -k): every k-th iteration as a whole -- product, reduction / exchange, vector update -- between two events)
+    const bool piter = c->prof_on && c->prof_iter && i + 1 < iters && (c->prof_seen++ % (size_t)c->prof_stride == 0) && c->prof_used + 2 <= c->prof_ev.size();
+    if (piter) HIPCHK(hipEventRecord(c->prof_ev[c->prof_used], st));
+    struct IterEnd { mjx_ctx* c; hipStream_t st; bool on; ~IterEnd() { if (on) { (void)hipEventRecord(c->prof_ev[c->prof_used + 1], st); c->prof_used += 2; } } } iter_end{c, st, piter};
+    if (!allreduce && peer_folded(c) && c->old_is_new && c->N_local > 0) {
       // peer exchange, folded into the loop's own kernels: the product's reduction kernel writes this rank's vector into slot `rank` of
-      // EVERY rank's buffer and bumps the peers' arrival counters, the vector-update kernel waits on the own counter and sums its local
+      // EVERY rank's buffer and raises its arrival flags, the vector-update kernel waits on the own flags and sums its local
       // slots (rank order): per iteration FVP -> reduction -> step -- exactly the launches of the one-rank loop, no host round trip.
       // (A rank on another route -- empty shard -- runs the same exchange through mjx_comm_allreduce.)
       const uint32_t seq = ++c->peer.seq;
@@ -907,19 +965,103 @@ int mjx_cg_solve(mjx_ctx* c, const float* b, int iters, float damping, double to
       const PeerPush pp = peer_push(c, par, seq);
       if (int rc = fvp_impl(c, c->cg_p, (float*)peer_slot(c, c->peer.rank, par, c->peer.rank), stream, &pp)) return rc;
       const PeerSlots ps = peer_slots(c, par, seq);
-#define MJX_STEP_W(W) hipLaunchKernelGGL((k_cg_step_reg<8, W>), dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)nullptr, damping, tol, \
-                                         c->cg_x, c->cg_r, c->cg_p, c->cg_scal, (int)c->d, ps)
+#define MJX_STEP_W(W) hipLaunchKernelGGL((k_cg_step_reg<8, W>), dim3(1), dim3(1024), 0, st, (const float*)nullptr, damping, tol, \
+                                         c->cg_x, c->cg_r, c->cg_p, c->cg_scal, (int)c->d, ps, f)
       if (c->peer.world <= 2) MJX_STEP_W(2); else if (c->peer.world <= 4) MJX_STEP_W(4); else if (c->peer.world <= 8) MJX_STEP_W(8); else MJX_STEP_W(16);
 #undef MJX_STEP_W
       HIPCHK(hipGetLastError());
+      fin_done = f.mode != 0;
       continue;
     }
     if (int rc = mjx_fvp(c, c->cg_p, c->cg_Ap, stream)) return rc;
     if (allreduce) { if (int rc = allreduce(user, c->cg_Ap, c->d, stream)) return fail(rc, "allreduce callback failed (%d)", rc); }
     else if (has_ranks(c)) { if (int rc = mjx_comm_allreduce(c, c->cg_Ap, c->d, 0, stream)) return rc; }
-    if (int rc = mjx_cg_step(c, c->cg_Ap, damping, tol, stream)) return rc;
+    if (reg) {
+      hipLaunchKernelGGL(k_cg_step_reg<8>, dim3(1), dim3(1024), 0, st, (const float*)c->cg_Ap, damping, tol, c->cg_x, c->cg_r, c->cg_p,
+                         c->cg_scal, (int)c->d, PeerSlots{}, f);
+      HIPCHK(hipGetLastError());
+      fin_done = f.mode != 0;
+    } else if (int rc = mjx_cg_step(c, c->cg_Ap, damping, tol, stream)) return rc;
   }
-  return mjx_cg_finish(c, b, x_out, bdotx_out, stream);
+  if (fin_done) return MJX_OK;
+  if (int rc = mjx_cg_finish(c, b, x_out, bdotx_out, stream)) return rc;
+  if (fin.mode == 2) return mjx_apply_npg_step(c, fin.theta, x_out, bdotx_out, fin.step_size, fin.min_log_std, fin.theta_out, fin.alpha_out, stream);
+  if (fin.mode == 3) return mjx_apply_step(c, fin.theta, x_out, fin.const_alpha, fin.min_log_std, fin.theta_out, stream);
+  return MJX_OK;
+}
+
+CgFin fin_step(const float* theta, float* theta_out, double* alpha_out, double step_size, double const_alpha, float min_log_std) {
+  CgFin f;
+  f.mode = std::isnan(const_alpha) ? 2 : 3;
+  f.theta = theta; f.theta_out = theta_out; f.alpha_out = alpha_out; f.step_size = step_size;
+  f.const_alpha = std::isnan(const_alpha) ? 0.f : (float)const_alpha; f.min_log_std = min_log_std;
+  return f;
+}
+CgFin fin_only() { CgFin f; f.mode = 1; return f; }
+
+// K1 and the rank sums of its outputs, up to the point where the solve starts.  -> *slots_out set when the gradient's sum is
+// left to the solve's first kernel (peer exchange, folded: ONE exchange carries the gradient and K1's sums -- every rank of the
+// job takes this route or none does: the condition depends on the architecture and the transport only)
+int vpg_and_rank_sums(mjx_ctx* c, float* grad_out, double* s4, bool need_s4_sum, void* stream, PeerSlots* slots_out, bool* folded) {
+  *folded = false;
+  hipStream_t st = (hipStream_t)stream;
+  if (peer_folded(c) && need_s4_sum) {
+    const uint32_t seq = ++c->peer.seq;
+    const int par = (int)(seq & 1u);
+    const PeerPush pp = peer_push(c, par, seq);
+    const int off = peer_scal_off(c);
+    char* own = peer_slot(c, c->peer.rank, par, c->peer.rank);
+    if (c->N_local > 0) {
+      if (int rc = surr_vpg_impl(c, (float*)own, (double*)(own + off), stream, &pp, off)) return rc;
+    } else {                                     // a rank without samples: zeros, through the same exchange
+      HIPCHK(hipMemsetAsync(grad_out, 0, c->d * sizeof(float), st));
+      HIPCHK(hipMemsetAsync(s4, 0, 4 * sizeof(double), st));
+      hipLaunchKernelGGL(k_peer_push_vs, dim3((unsigned)((c->d + 255) / 256)), dim3(256), 0, st, (const float*)grad_out, (const double*)s4, pp, (int)c->d, off);
+      HIPCHK(hipGetLastError());
+    }
+    *slots_out = peer_slots(c, par, seq);
+    *folded = true;
+    return MJX_OK;
+  }
+  if (int rc = mjx_surr_vpg(c, grad_out, s4, stream)) return rc;
+  if (c->comm && need_s4_sum) {
+    RcclApi& r = rccl();
+    (void)r.GroupStart();                       // one launch for the gradient and its scalars
+    int rc = mjx_comm_allreduce(c, grad_out, c->d, 0, stream);
+    if (!rc) rc = mjx_comm_allreduce(c, s4, 4, 1, stream);
+    const int ge = r.GroupEnd();
+    if (rc) return rc;
+    if (ge) return fail(1000 + ge, "ncclGroupEnd: %s", r.GetErrorString(ge));
+  } else if (has_ranks(c)) {
+    if (int rc = mjx_comm_allreduce(c, grad_out, c->d, 0, stream)) return rc;
+    if (need_s4_sum) if (int rc = mjx_comm_allreduce(c, s4, 4, 1, stream)) return rc;
+  }
+  return MJX_OK;
+}
+
+// K3 and the rank sum of its 4 doubles (peer exchange: the push rides on the reduction kernel)
+int eval_and_rank_sum(mjx_ctx* c, double* res4, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (c->peer.on && c->fused && c->N_local > 0) {
+    const uint32_t seq = ++c->peer.seq;
+    const int par = (int)(seq & 1u);
+    const PeerPush pp = peer_push(c, par, seq);
+    if (int rc = eval_impl(c, (double*)peer_slot(c, c->peer.rank, par, c->peer.rank), stream, &pp)) return rc;
+    hipLaunchKernelGGL(k_peer_sum<double>, dim3(1), dim3(256), 0, st, peer_slots(c, par, seq), res4, (int64_t)4);
+    HIPCHK(hipGetLastError());
+    return MJX_OK;
+  }
+  if (int rc = mjx_eval_surr_kl(c, res4, stream)) return rc;
+  if (has_ranks(c)) if (int rc = mjx_comm_allreduce(c, res4, 4, 1, stream)) return rc;
+  return MJX_OK;
+}
+}  // namespace
+extern "C" {
+
+int mjx_cg_solve(mjx_ctx* c, const float* b, int iters, float damping, double tol, float* x_out, double* bdotx_out,
+                 mjx_allreduce_fn allreduce, void* user, void* stream) {
+  if (!c || !b || iters < 0) return fail(MJX_ERR_ARG, "bad arguments");
+  return cg_solve_impl(c, const_cast<float*>(b), iters, damping, tol, x_out, bdotx_out, allreduce, user, stream, nullptr, nullptr, fin_only());
 }
 
 // ---------------------------------------------------------------------------- multi-rank (RCCL, bound at run time)
@@ -973,7 +1115,7 @@ int mjx_peer_export(mjx_ctx* c, int rank, int world, char* handle_out) {
   if (!c || !handle_out || world < 2 || world > 16 || rank < 0 || rank >= world) return fail(MJX_ERR_ARG, "bad arguments (2 <= world <= 16)");
   if (c->comm || c->reduce_cb || c->peer.buf) return fail(MJX_ERR_STATE, "a transport is already attached");
   HIPCHK(hipSetDevice(c->device));
-  size_t slot = (size_t)c->d * sizeof(float);
+  size_t slot = (((size_t)c->d * sizeof(float) + 15) & ~(size_t)15) + 4 * sizeof(double);   // a d-float vector + the 4 doubles that may travel with it (peer_scal_off)
   if (slot < 64 * sizeof(double)) slot = 64 * sizeof(double);
   slot = (slot + 255) & ~(size_t)255;
   void* p = nullptr;
@@ -1055,27 +1197,15 @@ int mjx_npg_update(mjx_ctx* c, int iters, float damping, double tol, double step
   if (!grad_out || !x_out || !theta_out || !results || iters < 0) return fail(MJX_ERR_ARG, "bad arguments");
   if (!c->old_is_new) return fail(MJX_ERR_STATE, "mjx_npg_update starts from theta_new == theta_old (mjx_bind_policy with old_is_new)");
   if (theta_out == c->theta_old) return fail(MJX_ERR_ARG, "theta_out must not alias theta_old");
-  if (int rc = mjx_surr_vpg(c, grad_out, results + 4, stream)) return rc;
-  if (c->comm) {
-    RcclApi& r = rccl();
-    (void)r.GroupStart();                       // one launch for the gradient and its scalars
-    int rc = mjx_comm_allreduce(c, grad_out, c->d, 0, stream);
-    if (!rc) rc = mjx_comm_allreduce(c, results + 4, 4, 1, stream);
-    const int ge = r.GroupEnd();
-    if (rc) return rc;
-    if (ge) return fail(1000 + ge, "ncclGroupEnd: %s", r.GetErrorString(ge));
-  } else if (c->reduce_cb || c->peer.on) {
-    if (int rc = mjx_comm_allreduce(c, grad_out, c->d, 0, stream)) return rc;
-    if (int rc = mjx_comm_allreduce(c, results + 4, 4, 1, stream)) return rc;
-  }
-  if (int rc = mjx_cg_solve(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream)) return rc;
+  PeerSlots gs{};
+  bool folded = false;
+  if (int rc = vpg_and_rank_sums(c, grad_out, results + 4, true, stream, &gs, &folded)) return rc;
   const float* base = c->theta_old;               // == theta_new in value; theta_out may be the theta_new buffer itself
-  if (!std::isnan(const_alpha)) { if (int rc = mjx_apply_step(c, base, x_out, (float)const_alpha, min_log_std, theta_out, stream)) return rc; }
-  else if (int rc = mjx_apply_npg_step(c, base, x_out, results + 8, step_size, min_log_std, theta_out, results + 9, stream)) return rc;
+  // (theta_out == theta_new: the stepped parameters are written by the solve's LAST kernel, after every product has read theta)
+  if (int rc = cg_solve_impl(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream, folded ? &gs : nullptr, results + 4,
+                             fin_step(base, theta_out, results + 9, step_size, const_alpha, min_log_std))) return rc;
   if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc;
-  if (int rc = mjx_eval_surr_kl(c, results, stream)) return rc;
-  if (has_ranks(c)) if (int rc = mjx_comm_allreduce(c, results, 4, 1, stream)) return rc;
-  return MJX_OK;
+  return eval_and_rank_sum(c, results, stream);
 }
 
 int mjx_trpo_update(mjx_ctx* c, int iters, float damping, double tol, double step_size, double kl_dist, int n_trials, int first,
@@ -1086,20 +1216,18 @@ int mjx_trpo_update(mjx_ctx* c, int iters, float damping, double tol, double ste
   hipStream_t st = (hipStream_t)stream;
   if (first) {
     if (!c->old_is_new) return fail(MJX_ERR_STATE, "mjx_trpo_update starts from theta_new == theta_old (mjx_bind_policy with old_is_new)");
-    if (int rc = mjx_surr_vpg(c, grad_out, results + 4, stream)) return rc;
-    if (has_ranks(c)) {
-      if (int rc = mjx_comm_allreduce(c, grad_out, c->d, 0, stream)) return rc;
-      if (int rc = mjx_comm_allreduce(c, results + 4, 4, 1, stream)) return rc;
-    }
-    if (int rc = mjx_cg_solve(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream)) return rc;
+    PeerSlots gs{};
+    bool folded = false;
+    if (int rc = vpg_and_rank_sums(c, grad_out, results + 4, true, stream, &gs, &folded)) return rc;
+    if (int rc = cg_solve_impl(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream, folded ? &gs : nullptr, results + 4,
+                               fin_only())) return rc;
   }
   for (int t = 0; t < n_trials; ++t) {
     hipLaunchKernelGGL(k_trpo_try, dim3((c->d + 255) / 256), dim3(256), 0, st, c->theta_old, x_out, results, step_size,
                        (first && t == 0) ? 1 : 0, min_log_std, theta_out, (int)c->d, c->oS);
     HIPCHK(hipGetLastError());
     if (first && t == 0) { if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc; }
-    if (int rc = mjx_eval_surr_kl(c, results, stream)) return rc;
-    if (has_ranks(c)) if (int rc = mjx_comm_allreduce(c, results, 4, 1, stream)) return rc;
+    if (int rc = eval_and_rank_sum(c, results, stream)) return rc;
     hipLaunchKernelGGL(k_trpo_check, dim3(1), dim3(64), 0, st, results, kl_dist, (double)c->N_global);
     HIPCHK(hipGetLastError());
   }
@@ -1124,14 +1252,11 @@ int mjx_dapg_update(mjx_ctx* c, int iters, float damping, double tol, double ste
   HIPCHK(hipGetLastError());
   // Fisher metric, surrogate and KL: the on-policy prefix with its own advantages, means over the on-policy count (:92, :103)
   if (int rc = mjx_bind_rows(c, rows_on, N_on_global, adv_on)) return rc;
-  if (int rc = mjx_eval_surr_kl(c, results + 4, stream)) return rc;                    // surr_before (theta_new == theta_old)
-  if (ranks) if (int rc = mjx_comm_allreduce(c, results + 4, 4, 1, stream)) return rc;
-  if (int rc = mjx_cg_solve(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream)) return rc;
-  if (int rc = mjx_apply_npg_step(c, c->theta_old, x_out, results + 8, step_size, min_log_std, theta_out, results + 9, stream)) return rc;
+  if (int rc = eval_and_rank_sum(c, results + 4, stream)) return rc;                   // surr_before (theta_new == theta_old)
+  if (int rc = cg_solve_impl(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream, nullptr, nullptr,
+                             fin_step(c->theta_old, theta_out, results + 9, step_size, std::nan(""), min_log_std))) return rc;
   if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc;
-  if (int rc = mjx_eval_surr_kl(c, results, stream)) return rc;
-  if (ranks) if (int rc = mjx_comm_allreduce(c, results, 4, 1, stream)) return rc;
-  return MJX_OK;
+  return eval_and_rank_sum(c, results, stream);
 }
 
 int mjx_apply_step(mjx_ctx* c, const float* theta, const float* x, float alpha, float min_log_std, float* theta_out, void* stream) {

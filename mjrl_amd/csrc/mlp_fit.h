@@ -83,8 +83,9 @@ struct MlpFitArgs {
   double* epoch_loss;      // [epochs] sum over steps of the minibatch MSE
   // ---- several workgroups (k_mlp_fit<.., MULTI = true>: inputs wider than one workgroup's LDS holds; see the kernel)
   float* xch = nullptr;    // UNCACHED exchange block [2 parities][G][H][32]: every workgroup's partial first-layer pre-activations
-  unsigned* bar = nullptr; // UNCACHED arrival counter (zero at launch)
+  unsigned* bar = nullptr; // UNCACHED arrival counter (zero at launch); bar[1]: "a workgroup gave up on a barrier" (k_mlp_fit_verdict)
   int G = 1, FS = 0;       // workgroups; features per workgroup (the last one takes what is left + the bias column)
+  int fault = 0;           // tests (MJX_FIT_FAULT=straggler): workgroup 0 starts 2.6 s late -- the others give up on the first barrier
 };
 
 template <int H>
@@ -127,6 +128,14 @@ struct MlpFitLayout {
 // One barrier per 32-sample half; the exchange block is double-buffered by barrier parity (a workgroup is at most one phase
 // ahead of another).  The last workgroup carries the bias column b1.  A wait that exceeds ~2 s poisons the epoch losses with NaN
 // and leaves (no hung GPU if a workgroup never gets a CU).
+// MULTI's verdict (one wave, launched on the same stream behind the trainer): a workgroup that gave up on a grid barrier left a
+// mark in the word behind the arrival counter -> every epoch loss becomes NaN, whatever the workgroups wrote there and in whatever
+// order (the host rejects a fit with non-finite losses and keeps the previous parameters, baselines/mlp_baseline.py _settle)
+__global__ void k_mlp_fit_verdict(const unsigned* __restrict__ gave_up, double* __restrict__ epoch_loss, int epochs) {
+  if (__hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+  for (int e = threadIdx.x; e < (epochs > 0 ? epochs : 1); e += blockDim.x) epoch_loss[e] = (double)__builtin_nanf("");
+}
+
 template <int H, int NF1 = 1, bool REGMOM = false, bool MULTI = false>
 __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   static_assert(H == 128, "wave w owns unit tile w: 4 waves x 32 units");
@@ -143,6 +152,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
   const int K1 = L.K1, S1 = L.S1;
   unsigned phase = 0;                                                 // grid barriers passed (MULTI)
   bool timed_out = false;
+  if constexpr (MULTI) {
+    if (A.fault == 1 && g_id == 0) {                                  // fault injection: the straggler of ADVICE r05 (it then passes every abandoned barrier at once)
+      if (tid == 0) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < 260000000ull) __builtin_amdgcn_s_sleep(8); }
+      __syncthreads();
+    }
+  }
   float* sW1 = lds + L.oW1; float* sW2 = lds + L.oW2; float* sW3 = lds + L.oW3; float* sB2 = lds + L.oB2;
   float* sB3 = sB2 + H;
   float* xs = lds + L.oXS; float* xT = lds + L.oXT; float* h1T = lds + L.oH1; float* h2T = lds + L.oH2; float* d2T = lds + L.oD2;
@@ -316,7 +331,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fit(MlpFitArgs A) {
             const unsigned long long t0 = wall_clock64();             // 100 MHz
             while ((int)(__hip_atomic_load(A.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
               __builtin_amdgcn_s_sleep(1);
-              if (timed_out || wall_clock64() - t0 > 200000000ull) { timed_out = true; break; }      // ~2 s: give up (once), poison the losses
+              if (timed_out || wall_clock64() - t0 > 200000000ull) {                                  // ~2 s: give up (once), poison the losses
+                // ... through a word of its own next to the counter (uncached, OR-ed: no other writer can undo it).  The epoch
+                // losses alone are not a safe place: workgroup 0 -- if IT was the straggler -- passes every abandoned barrier at
+                // once later and overwrites the NaNs with finite sums of stale partials.  k_mlp_fit_verdict, launched
+                // behind this kernel, turns the word into NaN losses once every workgroup has left.
+                if (!timed_out) __hip_atomic_fetch_or(A.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                timed_out = true; break;
+              }
             }
           }
           __syncthreads();

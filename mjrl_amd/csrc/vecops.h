@@ -167,13 +167,34 @@ __global__ void k_peer_sum(PeerSlots ps, T* __restrict__ out, int64_t count) {  
   out[i] = ok ? a : (T)__builtin_nanf("");
 }
 
+// the 4 fp64 sums a fused kernel leaves per workgroup (surrogate / KL / ...), reduced by ONE EXTRA workgroup of the vector
+// reduction below instead of a launch of their own (k_reduce_scalars: ~4.5 us as a dependent launch, r06); same arithmetic, same
+// order.  peer_off >= 0: the sums also travel with the vector, as 4 doubles at byte `peer_off` of this rank's slot.
+struct ScalTail { const double* sp; int G; double* out; int peer_off; };
+
 // the same for d % 4 == 0 with 16-byte loads: 32 columns (8 float4) x 32 row groups per block, i.e. 128-byte row
 // segments instead of 64-byte ones and a quarter of the load instructions (7 -> ~4.5 us for 256 x 5.7 k partials)
 __global__ __launch_bounds__(256) void k_reduce_partials4(const float* __restrict__ partials, int G, int d,
                                                            float* __restrict__ out, const float* theta,
-                                                           const float* v, int oS, float frac, PeerPush pp = PeerPush{}) {
+                                                           const float* v, int oS, float frac, PeerPush pp = PeerPush{},
+                                                           ScalTail stl = ScalTail{nullptr, 0, nullptr, -1}) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ double sh[32][33];
+  if (stl.sp != nullptr && blockIdx.x == gridDim.x - 1) {            // the extra workgroup: k_reduce_scalars' sums (launched with grid + 1)
+    for (int k = 0; k < 4; ++k) {
+      double a = 0.0;
+      for (int g = threadIdx.x; g < stl.G; g += blockDim.x) a += stl.sp[(size_t)g * 4 + k];
+      a = block_sum(a, &sh[0][0]);
+      if (threadIdx.x == 0) {
+        stl.out[k] = a;
+        if (stl.peer_off >= 0)
+          for (int q = 0; q < pp.world; ++q)
+            if (q != pp.rank) ((double*)((char*)pp.dst[q] + stl.peer_off))[k] = a;
+      }
+    }
+    if (pp.world) peer_signal_tail(pp);
+    return;
+  }
   const int cq = threadIdx.x & 7, rg = threadIdx.x >> 3;
   const int c0 = (blockIdx.x * 8 + cq) * 4;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -203,14 +224,37 @@ __global__ __launch_bounds__(256) void k_reduce_partials4(const float* __restric
   if (pp.world) peer_signal_tail(pp);
 }
 
-__global__ void k_reduce_scalars(const double* __restrict__ sp, int G, double* __restrict__ out) {
+// a vector of d floats and 4 doubles in ONE exchange (the gradient and K1's sums of a rank that holds no samples: it has no
+// reduction kernel to fold the push into, but must take part in the same exchanges as the others)
+__global__ void k_peer_push_vs(const float* __restrict__ v, const double* __restrict__ s4, PeerPush pp, int d, int scal_off) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d) {
+    const float x = v[i];
+    for (int q = 0; q < pp.world; ++q) ((float*)pp.dst[q])[i] = x;
+  }
+  if (i < 4) {
+    const double x = s4[i];
+    for (int q = 0; q < pp.world; ++q) ((double*)((char*)pp.dst[q] + scal_off))[i] = x;
+  }
+  peer_signal_tail(pp);
+}
+
+// pp.world > 0: `out` is this rank's slot (4 doubles at its start) in its own buffer, the sums go to the same place in every
+// peer's buffer and the arrival flags are raised -- the push of a 4-double exchange folded into the reduction (k_peer_sum<double>
+// is the consumer)
+__global__ void k_reduce_scalars(const double* __restrict__ sp, int G, double* __restrict__ out, PeerPush pp = PeerPush{}) {
   __shared__ double sh[17];
   for (int k = 0; k < 4; ++k) {
     double a = 0.0;
     for (int g = threadIdx.x; g < G; g += blockDim.x) a += sp[(size_t)g * 4 + k];
     a = block_sum(a, sh);
-    if (threadIdx.x == 0) out[k] = a;
+    if (threadIdx.x == 0) {
+      out[k] = a;
+      for (int q = 0; q < pp.world; ++q)
+        if (q != pp.rank) ((double*)pp.dst[q])[k] = a;
+    }
   }
+  if (pp.world) peer_signal_tail(pp);
 }
 
 // ---- conjugate gradient (mjrl/utils/cg_solve.py:3-22); vectors fp32, dots fp64 ----
@@ -223,6 +267,39 @@ __global__ __launch_bounds__(1024) void k_cg_init(const float* __restrict__ b, f
     float bi = b[i];
     x[i] = 0.f; r[i] = bi; p[i] = bi;
     a += (double)bi * (double)bi;
+  }
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) { scal[0] = a; scal[1] = 0.0; scal[2] = 0.0; scal[3] = 0.0; }
+}
+// the same with b arriving as one slot per rank (the gradient's exchange folded in, r06): waits for the arrivals, sums the W
+// slots in rank order -- vector AND the 4 doubles that travel with it at byte `scal_off` of every slot (K1's sums -> s4_out) --,
+// leaves the summed gradient in b_out for everything that reads it later, and starts the solve.  One launch instead of
+// k_peer_sum<float> + k_peer_sum<double> + k_cg_init.
+template <int W>
+__global__ __launch_bounds__(1024) void k_cg_init_w(PeerSlots ps, int scal_off, float* __restrict__ b_out, double* __restrict__ s4_out,
+                                                     float* x, float* r, float* p, double* scal, int d) {
+  __shared__ double sh[17];
+  const bool ok = peer_arrived(ps);
+  double a = 0.0;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    float t[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) t[q] = ((const float*)ps.slot[q])[i];
+    float bi = t[0];
+#pragma unroll
+    for (int q = 1; q < W; ++q) bi += t[q];
+    if (!ok) bi = __builtin_nanf("");
+    b_out[i] = bi; x[i] = 0.f; r[i] = bi; p[i] = bi;
+    a += (double)bi * (double)bi;
+  }
+  if (threadIdx.x < 4) {
+    double t[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) t[q] = q < ps.world ? ((const double*)((const char*)ps.slot[q] + scal_off))[threadIdx.x] : 0.0;   // (the zero slot is shorter than scal_off)
+    double sres = t[0];
+#pragma unroll
+    for (int q = 1; q < W; ++q) sres += t[q];
+    s4_out[threadIdx.x] = ok ? sres : (double)__builtin_nanf("");
   }
   a = block_sum(a, sh);
   if (threadIdx.x == 0) { scal[0] = a; scal[1] = 0.0; scal[2] = 0.0; scal[3] = 0.0; }
@@ -262,9 +339,20 @@ __global__ __launch_bounds__(1024) void k_cg_step(const float* __restrict__ Ap, 
 // W > 0: the Fisher-vector product arrives as one slot per rank (peer exchange, W = slots read: world rounded up to a power
 // of two, the surplus entries point at zeros); the body waits for the arrivals and sums the slots in rank order.
 // Called by all 1024 threads of one workgroup.
+// what follows the LAST vector update of a solve, folded into its kernel (r06: k_cg_finish + k_apply_npg_step were two dependent
+// ~4.7 us launches of a 3.8 ms -- or, on an eighth of the batch, 0.8 ms -- update): mode 1: x_out = x, bdotx = b.x (k_cg_finish);
+// mode 2: ... and theta_out = theta + sqrt(|step_size / (b.x + 1e-20)|) x with the log_std clamp, the step length to alpha_out
+// (k_apply_npg_step); mode 3: the same with the caller's constant step length.  Same arithmetic, same order, same bits.
+struct CgFin {
+  int mode = 0;
+  const float* b = nullptr; float* x_out = nullptr; double* bdotx = nullptr;
+  const float* theta = nullptr; float* theta_out = nullptr; double* alpha_out = nullptr;
+  double step_size = 0.0; float const_alpha = 0.f, min_log_std = 0.f; int oS = 0;
+};
+
 template <int EPT, int W>
 __device__ __forceinline__ void cg_step_body(const float* Ap, float damping, double tol, float* x, float* r, float* p,
-                                             double* scal, int d, const PeerSlots& ps, double* sh /* 17 doubles */) {
+                                             double* scal, int d, const PeerSlots& ps, double* sh /* 17 doubles */, const CgFin& fin) {
   bool ok = true;
   if (W) ok = peer_arrived(ps);
   const double done = scal[1], rr = scal[0];
@@ -286,40 +374,69 @@ __device__ __forceinline__ void cg_step_body(const float* Ap, float damping, dou
     }
     pv[e] = p[ic]; xv[e] = x[ic]; rv[e] = r[ic];
   }
-  if (done != 0.0) return;                          // converged earlier: cg_solve.py:19-20 `break`
-  double pz = 0.0;
+  if (done == 0.0) {                                  // (converged earlier: cg_solve.py:19-20 `break` -- nothing moves any more)
+    double pz = 0.0;
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const float zi = ap[e] + damping * pv[e];       // npg_cg.py:81  hvp_flat + regu_coef*vector
-    ap[e] = zi;
-    if (threadIdx.x + e * 1024 < d) pz += (double)pv[e] * (double)zi;
-  }
-  pz = block_sum(pz, sh);
-  const float alpha = (float)(rr / pz);
-  double nrr = 0.0;
+    for (int e = 0; e < EPT; ++e) {
+      const float zi = ap[e] + damping * pv[e];       // npg_cg.py:81  hvp_flat + regu_coef*vector
+      ap[e] = zi;
+      if (threadIdx.x + e * 1024 < d) pz += (double)pv[e] * (double)zi;
+    }
+    pz = block_sum(pz, sh);
+    const float alpha = (float)(rr / pz);
+    double nrr = 0.0;
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    xv[e] = fmaf(alpha, pv[e], xv[e]);
-    rv[e] = fmaf(-alpha, ap[e], rv[e]);
-    if (threadIdx.x + e * 1024 < d) nrr += (double)rv[e] * (double)rv[e];
+    for (int e = 0; e < EPT; ++e) {
+      xv[e] = fmaf(alpha, pv[e], xv[e]);
+      rv[e] = fmaf(-alpha, ap[e], rv[e]);
+      if (threadIdx.x + e * 1024 < d) nrr += (double)rv[e] * (double)rv[e];
+    }
+    nrr = block_sum(nrr, sh);
+    const float mu = (float)(nrr / rr);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = threadIdx.x + e * 1024;
+      if (i < d) { x[i] = xv[e]; r[i] = rv[e]; p[i] = fmaf(mu, pv[e], rv[e]); }
+    }
+    if (threadIdx.x == 0) {
+      scal[0] = nrr; scal[2] = pz; scal[3] += 1.0;
+      if (nrr < tol) scal[1] = 1.0;
+    }
   }
-  nrr = block_sum(nrr, sh);
-  const float mu = (float)(nrr / rr);
+  if (fin.mode == 0) return;
+  // ---- k_cg_finish: x_out, b.x (each thread adds its elements in increasing index order, like the strided loop there)
+  double bx = 0.0;
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int i = threadIdx.x + e * 1024;
-    if (i < d) { x[i] = xv[e]; r[i] = rv[e]; p[i] = fmaf(mu, pv[e], rv[e]); }
+    if (i < d) {
+      if (fin.x_out) fin.x_out[i] = xv[e];
+      bx += (double)fin.b[i] * (double)xv[e];
+    }
   }
-  if (threadIdx.x == 0) {
-    scal[0] = nrr; scal[2] = pz; scal[3] += 1.0;
-    if (nrr < tol) scal[1] = 1.0;
+  bx = block_sum(bx, sh);
+  if (threadIdx.x == 0 && fin.bdotx) fin.bdotx[0] = bx;
+  if (fin.mode == 1) return;
+  // ---- k_apply_npg_step / k_apply_step
+  const double a64 = fin.mode == 2 ? sqrt(fabs(fin.step_size / (bx + 1e-20))) : (double)fin.const_alpha;
+  if (threadIdx.x == 0 && fin.alpha_out && fin.mode == 2) fin.alpha_out[0] = a64;
+  const float alpha = fin.mode == 2 ? (float)a64 : fin.const_alpha;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = threadIdx.x + e * 1024;
+    if (i < d) {
+      float v = __fadd_rn(fin.theta[i], __fmul_rn(alpha, xv[e]));   // numpy: separate multiply and add
+      if (i >= fin.oS) v = fmaxf(v, fin.min_log_std);
+      fin.theta_out[i] = v;
+    }
   }
 }
 template <int EPT, int W = 0>
 __global__ __launch_bounds__(1024) void k_cg_step_reg(const float* __restrict__ Ap, float damping, double tol,
-                                                       float* x, float* r, float* p, double* scal, int d, PeerSlots ps = PeerSlots{}) {
+                                                       float* x, float* r, float* p, double* scal, int d, PeerSlots ps = PeerSlots{},
+                                                       CgFin fin = CgFin{}) {
   __shared__ double sh[17];
-  cg_step_body<EPT, W>(Ap, damping, tol, x, r, p, scal, d, ps, sh);
+  cg_step_body<EPT, W>(Ap, damping, tol, x, r, p, scal, d, ps, sh, fin);
 }
 
 __global__ __launch_bounds__(1024) void k_cg_finish(const float* __restrict__ b, const float* __restrict__ x,

@@ -51,6 +51,8 @@ def install(verbose=False):
             except Exception:                           # pragma: no cover
                 pass
         bound.append(ref_name)
+    from .utils import ingest
+    ingest.tune_malloc()                                # a training process from here on (utils/ingest.py; MJX_MALLOC_TUNE=0 opts out)
     if verbose:
         print("[mjrl_amd.dropin] %d mjrl modules bound to the MI355X path" % len(bound), file=sys.stderr)
     return bound

@@ -12,6 +12,19 @@ from the training process: no HIP context, no page-locked blocks, no half-held l
 costs -- an interpreter start per worker -- is paid once per job instead of once per iteration).  ``MJX_SAMPLER_START``
 = ``spawn`` (default) | ``forkserver`` | ``fork`` picks the start method.  ``max_process_time`` / ``max_timeouts`` act like
 the reference's: a worker set that does not answer in time is torn down and the whole request is retried.
+
+What spawn asks of the caller (r06): a spawned worker imports the training script again as ``__mp_main__`` and finds
+env factories / policy classes BY NAME.  (i) A script without an ``if __name__ == "__main__":`` guard would re-run itself in
+every worker: such a main module is detected and the request is served in this process (one warning; guard the script or set
+``MJX_SAMPLER_START=fork``).  (ii) An env factory or policy class the workers cannot import (defined in ``__main__`` of a script
+run through ``runpy``, a lambda, a local class) fails INSIDE the worker's job -- the payload travels as bytes and is unpickled
+there -- and comes back as an error at once instead of a lost task and a 300 s timeout: same fall-back, same warning.
+(iii) ``num_cpu='max'`` means ``min(cpu_count, MJX_SAMPLER_MAX_WORKERS = 32)`` interpreters, not 256 on a 256-thread host.
+
+Streaming: with a ``sink`` (utils/ingest.StreamedBatch -- train_step passes one) the request is cut into
+more jobs than workers, the results are taken in EPISODE ORDER as they arrive and every chunk's rewards / observations /
+actions are gathered into the page-locked staging blocks and sent to the GPU while the later episodes are still being
+simulated: when sampling ends the batch is resident.  Same episodes, same seeds (base_seed + episode index), same path list.
 """
 import atexit
 import multiprocessing as mp
@@ -38,7 +51,8 @@ def _stack_dict_list(dicts):
 def _make_env(env, env_kwargs):
     if isinstance(env, str):
         raise RuntimeError("string env ids need mjrl + gym on the host (mjrl/utils/gym_env.py:23-24); pass an env object or a factory")
-    if callable(env) and not hasattr(env, "step"):
+    if isinstance(env, type) or (callable(env) and not hasattr(env, "step")):
+        # a factory -- or an env CLASS (core.py:36-39 instantiates any callable; a class has `step` too, as a plain function)
         return env(**(env_kwargs or {}))
     if hasattr(env, "step") and hasattr(env, "reset"):
         return env
@@ -46,9 +60,10 @@ def _make_env(env, env_kwargs):
     raise AttributeError
 
 
-def native_do_rollout(num_traj, env, policy, eval_mode=False, horizon=1e6, base_seed=None, env_kwargs=None):
-    """mjrl/samplers/core.py:13-97 -- one process, `num_traj` episodes, episode `ep` seeded with base_seed + ep"""
-    env = _make_env(env, env_kwargs)
+def native_do_rollout(num_traj, env, policy, eval_mode=False, horizon=1e6, base_seed=None, env_kwargs=None, _env_obj=None):
+    """mjrl/samplers/core.py:13-97 -- one process, `num_traj` episodes, episode `ep` seeded with base_seed + ep
+    (_env_obj: an env built from `env` earlier -- the streaming jobs of one worker share it like the episodes of one job do)"""
+    env = _env_obj if _env_obj is not None else _make_env(env, env_kwargs)
     seed_env = getattr(env, "set_seed", None)
     if base_seed is not None:
         if seed_env is not None:
@@ -84,6 +99,7 @@ def native_do_rollout(num_traj, env, policy, eval_mode=False, horizon=1e6, base_
 
 # ---------------------------------------------------------------------------------------------------------------- worker pool
 _POOLS = {}
+_SERIAL_ONLY = {}            # why this process serves num_cpu > 1 requests itself (set once, with the warning): reason string
 
 
 def _start_method():
@@ -91,6 +107,47 @@ def _start_method():
     if m not in ("spawn", "forkserver", "fork"):
         raise ValueError("MJX_SAMPLER_START must be spawn, forkserver or fork, not %r" % m)
     return m
+
+
+def _resolve_num_cpu(num_cpu):
+    """core.py:113-115; 'max' is capped (MJX_SAMPLER_MAX_WORKERS, default 32): every worker is a spawned interpreter"""
+    num_cpu = 1 if num_cpu is None else num_cpu
+    if num_cpu == 'max':
+        num_cpu = max(1, min(mp.cpu_count(), int(os.environ.get("MJX_SAMPLER_MAX_WORKERS", "32"))))
+    assert type(num_cpu) == int                                                   # noqa: E721 (core.py:115)
+    return num_cpu
+
+
+def _main_would_rerun():
+    """would a spawned worker, importing this process's main module again, re-run a training script?  (a main module that is a
+    file without an `if __name__ == "__main__":` guard; `python -c`, interactive sessions and guarded scripts: no)"""
+    import re
+    import sys
+    main = sys.modules.get("__main__")
+    spec = getattr(main, "__spec__", None)
+    path = getattr(spec, "origin", None) if getattr(spec, "name", None) else getattr(main, "__file__", None)
+    if not path or not os.path.isfile(path) or not str(path).endswith(".py"):
+        return False
+    try:
+        with open(path, errors="replace") as f:
+            src = f.read()
+    except OSError:                                      # pragma: no cover
+        return False
+    return re.search(r"^[ \t]*if[ \t]+__name__[ \t]*==[ \t]*['\"]__main__['\"]", src, re.M) is None
+
+
+def _serve_here(reason):
+    """remember (and say once) that this process runs its rollouts itself"""
+    if "why" not in _SERIAL_ONLY:
+        _SERIAL_ONLY["why"] = reason
+        import warnings
+        warnings.warn("mjrl_amd.samplers: num_cpu > 1 is served in the training process itself -- %s.  Guard the script with "
+                      "`if __name__ == \"__main__\":` and define env factories / policy classes in an importable module, or set "
+                      "MJX_SAMPLER_START=fork (forked workers inherit everything; libmjx refuses device work in them and they ask for none)." % reason)
+
+
+class _PayloadError(Exception):
+    """a worker could not rebuild the job's env / policy from the bytes it was sent"""
 
 
 def _pool(num_cpu):
@@ -118,18 +175,49 @@ def close_pools():
 
 atexit.register(close_pools)
 
+_WORKER = {}                 # worker-side: the last env / policy payloads and what they unpickled to
 
-def _try_multiprocess(func, input_dict_list, num_cpu, max_process_time, max_timeouts):
-    """core.py:189-210 on the persistent pool: all jobs or nothing; a timeout tears the workers down and retries"""
-    for _ in range(int(max_timeouts)):
+
+def _rollout_job(env_blob, policy_blob, num_traj, base_seed, eval_mode, horizon):
+    """runs in a worker: (env, env_kwargs) and the policy arrive as BYTES and are rebuilt here, so that a payload the worker cannot
+    import fails as an ordinary exception of this job (-> _PayloadError) instead of killing the worker while it reads its task
+    queue.  The env built from `env_blob` is kept between jobs (like the episodes of one reference job share theirs: every episode
+    is re-seeded, core.py:57-60); the policy is rebuilt whenever its bytes change (once per iteration).  -> (paths, T)"""
+    import pickle
+    try:
+        if _WORKER.get("env_blob") != env_blob:
+            env, env_kwargs = pickle.loads(env_blob)
+            _WORKER.update(env_blob=env_blob, env=_make_env(env, env_kwargs))
+        if _WORKER.get("policy_blob") != policy_blob:
+            _WORKER.update(policy_blob=policy_blob, policy=pickle.loads(policy_blob))
+    except Exception as e:
+        _WORKER.clear()
+        raise _PayloadError("%s: %s" % (type(e).__name__, e))
+    env = _WORKER["env"]
+    paths = native_do_rollout(num_traj, None, _WORKER["policy"], eval_mode, horizon, base_seed, None, _env_obj=env)
+    return paths, min(horizon, getattr(env, "horizon", horizon))
+
+
+def _try_multiprocess(jobs, num_cpu, max_process_time, max_timeouts, sink=None):
+    """core.py:189-210 on the persistent pool: all jobs or nothing; a timeout tears the workers down and retries.  The results are
+    taken in job (= episode) order; with a sink every chunk is handed on the moment it is there, while later jobs still run."""
+    for attempt in range(int(max_timeouts)):
         pool = _pool(num_cpu)
-        runs = [pool.apply_async(func, kwds=d) for d in input_dict_list]
+        runs = [pool.apply_async(_rollout_job, args=j) for j in jobs]
+        out = []
         try:
-            return [r.get(timeout=max_process_time) for r in runs]
+            for r in runs:
+                paths, T = r.get(timeout=max_process_time)
+                out.append(paths)
+                if sink is not None:
+                    sink.add(paths, T)
+            return out
         except mp.TimeoutError as e:
             print(str(e))
             print("Timeout Error raised... Trying again")
             _drop_pool(num_cpu)
+            if sink is not None:
+                sink.abort("a sampler timeout: the request was retried")      # (what was streamed belongs to a discarded attempt)
         except Exception:
             _drop_pool(num_cpu)
             raise
@@ -137,23 +225,59 @@ def _try_multiprocess(func, input_dict_list, num_cpu, max_process_time, max_time
 
 
 def native_sample_paths(num_traj, env, policy, eval_mode=False, horizon=1e6, base_seed=None, num_cpu=1,
-                        max_process_time=300, max_timeouts=4, suppress_print=False, env_kwargs=None):
+                        max_process_time=300, max_timeouts=4, suppress_print=False, env_kwargs=None, sink=None):
     """mjrl/samplers/core.py:99-148: num_cpu == 1 in this process; otherwise ceil(num_traj / num_cpu) episodes per worker,
     worker i seeded base_seed + i * paths_per_cpu -- the episodes (and, when num_cpu divides num_traj, their order) of the
-    one-process call."""
-    num_cpu = 1 if num_cpu is None else num_cpu
-    num_cpu = mp.cpu_count() if num_cpu == 'max' else num_cpu
-    assert type(num_cpu) == int                                                   # noqa: E721 (core.py:115)
+    one-process call.  sink (utils/ingest.StreamedBatch): see the module docstring -- every worker's share is cut into
+    MJX_SAMPLER_PIECES (4) jobs, each seeded base_seed + its first episode's index, so the episodes are the same ones."""
+    import pickle
+    num_cpu = _resolve_num_cpu(num_cpu)
     common = dict(env=env, policy=policy, eval_mode=eval_mode, horizon=horizon, env_kwargs=env_kwargs)
-    if num_cpu == 1:
-        return native_do_rollout(num_traj=num_traj, base_seed=base_seed, **common)
+    pieces = max(1, int(os.environ.get("MJX_SAMPLER_PIECES", "4"))) if sink is not None else 1
+    if num_cpu > 1 and "why" not in _SERIAL_ONLY and _start_method() != "fork" and _main_would_rerun():
+        _serve_here("the main module of this process is a script without a __main__ guard, which every spawned worker would run again")
+    blobs = None
+    if num_cpu > 1 and "why" not in _SERIAL_ONLY:
+        try:
+            blobs = (pickle.dumps((env, env_kwargs)), pickle.dumps(policy))
+        except Exception as e:                            # a lambda, a local class, an env holding an open handle ...
+            _serve_here("the env / policy cannot be pickled for the workers (%s: %s)" % (type(e).__name__, e))
+    if blobs is None:
+        # this process: the reference's one-process call (episodes base_seed + ep); with a sink in pieces, each handed on when done
+        total = num_traj if num_cpu == 1 else num_cpu * int(np.ceil(num_traj / num_cpu))       # (core.py:124 rounds every worker's share up)
+        if sink is None:
+            return native_do_rollout(num_traj=total, base_seed=base_seed, **common)
+        env_obj = _make_env(env, env_kwargs)
+        T = min(horizon, getattr(env_obj, "horizon", horizon))
+        sink.begin(total)
+        step = max(1, int(np.ceil(total / (4 * pieces))))
+        paths = []
+        for lo in range(0, total, step):
+            chunk = native_do_rollout(min(step, total - lo), None, policy, eval_mode, horizon,
+                                      None if base_seed is None else base_seed + lo, None, _env_obj=env_obj)
+            paths += chunk
+            sink.add(chunk, T)
+        return paths
     paths_per_cpu = int(np.ceil(num_traj / num_cpu))
-    jobs = [dict(num_traj=paths_per_cpu, base_seed=None if base_seed is None else base_seed + i * paths_per_cpu, **common)
-            for i in range(num_cpu)]
+    piece = max(1, int(np.ceil(paths_per_cpu / pieces)))
+    jobs = []
+    for i in range(num_cpu):
+        for lo in range(0, paths_per_cpu, piece):
+            ep = i * paths_per_cpu + lo
+            jobs.append(blobs + (min(piece, paths_per_cpu - lo), None if base_seed is None else base_seed + ep, eval_mode, horizon))
     if suppress_print is False:
         start_time = timer.time()
         print("####### Gathering Samples #######")
-    results = _try_multiprocess(native_do_rollout, jobs, num_cpu, max_process_time, max_timeouts)
+    if sink is not None:
+        sink.begin(num_cpu * paths_per_cpu)
+    try:
+        results = _try_multiprocess(jobs, num_cpu, max_process_time, max_timeouts, sink)
+    except _PayloadError as e:
+        _serve_here("the workers cannot rebuild the env / policy they were sent (%s)" % e)
+        if sink is not None:
+            sink.abort("the worker pool was given up")
+        return native_sample_paths(num_traj, env, policy, eval_mode, horizon, base_seed, num_cpu, max_process_time, max_timeouts,
+                                   True, env_kwargs, None)
     if results is None:
         raise RuntimeError("sample_paths: %d worker timeouts of %s s each -- no rollouts (mjrl/samplers/core.py:192-193 returns None here, "
                            "which its caller then fails on)" % (max_timeouts, max_process_time))
@@ -166,9 +290,7 @@ def native_sample_paths(num_traj, env, policy, eval_mode=False, horizon=1e6, bas
 def native_sample_data_batch(num_samples, env, policy, eval_mode=False, horizon=1e6, base_seed=None, num_cpu=1,
                              paths_per_call=1, env_kwargs=None):
     """mjrl/samplers/core.py:151-186: rounds of paths_per_call * num_cpu episodes until num_samples timesteps are in"""
-    num_cpu = 1 if num_cpu is None else num_cpu
-    num_cpu = mp.cpu_count() if num_cpu == 'max' else num_cpu
-    assert type(num_cpu) == int                                                   # noqa: E721
+    num_cpu = _resolve_num_cpu(num_cpu)
     start_time = timer.time()
     print("####### Gathering Samples #######")
     sampled_so_far, paths = 0, []
@@ -205,15 +327,15 @@ def do_rollout(num_traj, env, policy, eval_mode=False, horizon=1e6, base_seed=No
 
 
 def sample_paths(num_traj, env, policy, eval_mode=False, horizon=1e6, base_seed=None, num_cpu=1, max_process_time=300,
-                 max_timeouts=4, suppress_print=False, env_kwargs=None):
+                 max_timeouts=4, suppress_print=False, env_kwargs=None, sink=None):
     """An env ID (what train_step passes when agent.env is mjrl's GymEnv, batch_reinforce.py:71) can only be resolved by mjrl's own
-    GymEnv / gym.make: such calls go to the UNMODIFIED mjrl.samplers.core.sample_paths, fork pool and all.  Env objects and
-    factories are served here."""
+    GymEnv / gym.make: such calls go to the UNMODIFIED mjrl.samplers.core.sample_paths, fork pool and all (a `sink` is not
+    used: the reference's workers hand back their whole share at once, core.py:196-205).  Env objects and factories are served here."""
     if _is_env_id(env):
         return _mjrl_core().sample_paths(num_traj, env, policy, eval_mode, horizon, base_seed, num_cpu, max_process_time,
                                          max_timeouts, suppress_print, env_kwargs)
     return native_sample_paths(num_traj, env, policy, eval_mode, horizon, base_seed, num_cpu, max_process_time, max_timeouts,
-                               suppress_print, env_kwargs)
+                               suppress_print, env_kwargs, sink)
 
 
 def sample_data_batch(num_samples, env, policy, eval_mode=False, horizon=1e6, base_seed=None, num_cpu=1, paths_per_call=1,

@@ -27,16 +27,29 @@ except Exception:                           # pragma: no cover
     _pathwalk = None
 
 
-def _tune_malloc():
-    """Host allocator settings for a training process that turns over hundreds of MB of rollout arrays per iteration (once, at the
-    first import of this module -- the training process only; sampler workers never import it).  With glibc's defaults a rollout
-    array of 136 KB (1 000 steps x 17 observations in fp64) sits right at the mmap threshold: batches end up either as 2 000
-    separate mappings (every free an munmap) or at the top of the heap (every free a trim, an sbrk with its page-table work):
-    releasing ONE batch then costs 6-13 ms instead of 0.5 (tools/e2e_timeline.py with TL_ALTERNATE=1: the whole difference
-    between an 8 ms and a 20 ms NPG.train_from_paths), wherever in the iteration the last reference dies.  M_MMAP_THRESHOLD at its
-    maximum (32 MB: rollout arrays come from the heap) and M_TRIM_THRESHOLD at 2 GB (the heap keeps what a batch needs) make
-    that release a list insertion.  MJX_MALLOC_TUNE=0 leaves the allocator alone."""
+MALLOC_TUNED = None          # None: not asked for yet (importing this package changes nothing in the process); True / False: tune_malloc()'s outcome
+
+
+def tune_malloc():
+    """Host allocator settings for a TRAINING process that turns over hundreds of MB of rollout arrays per iteration.  Called by
+    the training entry points -- BatchREINFORCE.train_step, mjrl_amd.dropin.install, bench.py -- never by importing the package
+    (r06: a process-global allocator policy is not an import side effect of a drop-in library; a process that only unpickles a
+    policy or calls get_action keeps glibc's defaults).  Idempotent; MJX_MALLOC_TUNE=0 leaves the allocator alone.
+
+    Why: with glibc's defaults a rollout array of 136 KB (1 000 steps x 17 observations in fp64) sits right at the mmap threshold:
+    batches end up either as 2 000 separate mappings (every free an munmap) or at the top of the heap (every free a trim, an sbrk
+    with its page-table work): releasing ONE batch then costs 6-13 ms instead of 0.5 (tools/e2e_timeline.py with TL_ALTERNATE=1:
+    the whole difference between an 8 ms and a 20 ms NPG.train_from_paths), wherever in the iteration the last reference dies.
+    M_MMAP_THRESHOLD at its maximum (32 MB: rollout arrays come from the heap) and M_TRIM_THRESHOLD at 2 GB (the heap keeps what
+    a batch needs) make that release a list insertion.
+    Consequence for the resident set: freed heap pages are no longer handed back to the kernel, so the process keeps the high-water
+    mark of its rollout batches (~190 MB per 1M fp64 HalfCheetah timesteps held at once; tools/soak.py: RSS flat after the first
+    iterations of 300, profiles/r05_bench/soak.log) instead of oscillating by that amount every iteration."""
+    global MALLOC_TUNED
+    if MALLOC_TUNED is not None:
+        return MALLOC_TUNED
     if os.environ.get("MJX_MALLOC_TUNE", "1") == "0" or not sys.platform.startswith("linux"):
+        MALLOC_TUNED = False
         return False
     try:
         import ctypes
@@ -44,12 +57,10 @@ def _tune_malloc():
         M_TRIM_THRESHOLD, M_MMAP_THRESHOLD = -1, -3
         ok = libc.mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024) == 1
         ok = (libc.mallopt(M_TRIM_THRESHOLD, 2 ** 31 - 1) == 1) and ok
-        return ok
+        MALLOC_TUNED = bool(ok)
     except Exception:                       # pragma: no cover  (another libc: nothing to tune)
-        return False
-
-
-MALLOC_TUNED = _tune_malloc()
+        MALLOC_TUNED = False
+    return MALLOC_TUNED
 
 
 def minibatch_indices(lib, num_samples, steps, mb_size):
@@ -622,7 +633,7 @@ def _release_other_batches(dev, paths, keys):
     """a NEW batch is about to be staged under `keys`: let go of the entries it replaces -- in one go and before the new batch's
     staging jobs start, instead of key by key in the middle of them.  (What a release costs is the host
     allocator's business -- 0.5 or 13 ms for the 2 000 arrays of a 1M-timestep batch with glibc's defaults, tools/e2e_timeline.py
-    with TL_ALTERNATE=1; see _tune_malloc above.)"""
+    with TL_ALTERNATE=1; see tune_malloc above.)"""
     stale = []
     with _SHARED_LOCK:
         reg = _SHARED.get((dev.type, dev.index), {})
@@ -706,6 +717,146 @@ def stage_shared(backend, paths, keys, raw=None, defer=False):
                 _order_after(backend, ent)
             out[k] = dict(f32=ent["f32"], raw=ent["raw"])
     return out
+
+
+class StreamedBatch:
+    """Rollout ingestion UNDER sampling (second half): the sampler hands over chunks of finished trajectories in
+    episode order (mjrl_amd/samplers.py; any producer may: ``begin(total_episodes)``, ``add(chunk, T)`` ..., then
+    ``finish(paths)`` with the complete list), every chunk's rewards / observations / actions are gathered into the page-locked
+    staging blocks by libmjx's host threads and their transfers are queued at once -- when the last episode ends, the batch is
+    resident.  ``finish`` REGISTERS the blocks exactly as ``stage_shared`` would have for that list (same stagers, same modes:
+    raw fp64 where some consumer reads the rollouts in their own precision, fp32 converted by the gather otherwise), so everything
+    downstream -- compute_returns, the baselines, train_from_paths -- finds its block by the identity of the list and its arrays
+    and uploads nothing.  Rows are placed in episode order: the blocks are bit for bit the ones a stage-after-sampling builds
+    (tests/test_gpu_operators.py::test_streamed_ingestion_equals_staging_after_sampling).
+
+    Nothing here is load-bearing for correctness: whatever does not fit the scheme (ragged dtypes, a chunk beyond the capacity
+    bound total_episodes x T, a retried request, a consumer that rebuilds the list) aborts the stream and the batch is staged
+    after sampling as before."""
+    KEYS = ("rewards", "observations", "actions")
+
+    def __init__(self, backend, keys=None):
+        self.backend, self.dev = backend, backend.device
+        self.keys = tuple(keys) if keys is not None else self.KEYS
+        self.ok = backend.device.type == "cuda" and getattr(backend, "lib", None) is not None
+        self.why = None if self.ok else "no GPU / libmjx"
+        self.total, self.st, self.mode, self.seen, self.rows, self.cap = None, None, {}, [], 0, 0
+        self.chunks = 0
+
+    @classmethod
+    def for_current_device(cls, keys=None):
+        """-> a StreamedBatch on torch's current CUDA device, or None (no GPU, MJX_STREAM_INGEST=0)"""
+        if os.environ.get("MJX_STREAM_INGEST", "1") == "0":
+            return None
+        try:
+            import torch
+            from .. import _lib
+            if not torch.cuda.is_available():
+                return None
+            return cls(DeviceHandle(torch, torch.device("cuda", torch.cuda.current_device()), _lib.load()), keys)
+        except Exception:                         # pragma: no cover
+            return None
+
+    def begin(self, total_episodes):
+        self.total = int(total_episodes)
+
+    def abort(self, why):
+        if self.ok:
+            self.ok, self.why = False, str(why)
+        if self.st:
+            for st in self.st.values():          # (a staging job must not outlive this attempt; the blocks are reused by the next begin())
+                try:
+                    st.join()
+                except Exception:                 # pragma: no cover
+                    pass
+        self.st, self.seen = None, []
+
+    def _open(self, chunk, T):
+        """first chunk: which keys stream (uniform float arrays), in which mode, with what capacity"""
+        first = chunk[0]
+        keys = []
+        for k in self.keys:
+            a = first.get(k)
+            if not isinstance(a, np.ndarray) or a.ndim not in (1, 2) or a.dtype not in (np.float64, np.float32):
+                continue
+            if k == "rewards" and not (a.ndim == 1 and a.dtype == np.float64):     # (what process_samples._rewards_block stages; else its own route)
+                continue
+            keys.append(k)
+        if not keys or self.total is None:
+            return self.abort("nothing to stream")
+        self.cap = int(self.total) * int(max(1, min(int(T), 10 ** 7)))
+        if self.cap > (1 << 31):
+            return self.abort("capacity bound beyond 2^31 rows")
+        dev = self.dev
+        sentinel = object()
+        _release_other_batches(dev, sentinel, keys)                # whatever batch is still registered under these keys is replaced
+        self.st = {}
+        with _SHARED_LOCK:
+            reg = _SHARED.setdefault((dev.type, dev.index), {})
+            for k in keys:
+                as_raw = (k == "rewards") or ((dev.type, dev.index, k) in _RAW_STICKY)
+                if k == "rewards":
+                    _RAW_STICKY.add((dev.type, dev.index, k))
+                ent = reg.get(k)
+                skey = "stager" if as_raw else "stager32"
+                st = ent.get(skey) if ent is not None else None
+                self.st[k] = st if st is not None else PathStager(self.backend)
+                self.mode[k] = skey
+        for k in keys:
+            a = first[k]
+            self.st[k].begin((k,), [a.shape[1] if a.ndim == 2 else 1], [np.float64 if a.dtype == np.float64 else np.float32], self.cap,
+                             hostcast=() if self.mode[k] == "stager" else True)
+
+    def add(self, chunk, T=None):
+        """the next episodes of the batch (in order); T: an upper bound of a trajectory's length (the env's horizon)"""
+        if not self.ok or not chunk:
+            return
+        try:
+            if self.st is None:
+                self._open(chunk, T if T is not None else max(len(p["rewards"]) for p in chunk))
+                if not self.ok:
+                    return
+            rows = sum(len(p["rewards"]) for p in chunk)
+            if self.rows + rows > self.cap:
+                return self.abort("a chunk beyond the capacity bound (trajectories longer than the horizon the sampler named)")
+            for k, st in self.st.items():
+                st.add_paths(chunk)                                 # native gather into the page-locked block + queued copies
+            self.rows += rows
+            self.seen.extend(chunk)
+            self.chunks += 1
+        except Exception as e:                                      # anything irregular: stage after sampling, as before
+            self.abort("%s: %s" % (type(e).__name__, e))
+
+    def finish(self, paths):
+        """`paths`: the complete list the sampler returned.  Registers the resident blocks for it -> True; False when the stream
+        was aborted or `paths` is not what was streamed (then nothing is registered and the batch is staged on first use)."""
+        if not self.ok or self.st is None:
+            return False
+        if type(paths) is not list or len(paths) != len(self.seen) or any(p is not q for p, q in zip(paths, self.seen)):
+            self.abort("the sampler's list is not the streamed episodes")
+            return False
+        dev, torch = self.dev, self.backend.torch
+        try:
+            for k, st in self.st.items():
+                st._drain(block=True)
+                st.join()
+                if st._rows != self.rows:
+                    raise ValueError("row count of %r" % k)
+                arrays = [p[k] for p in paths]
+                ready = torch.cuda.Event()
+                ready.record(st.side)
+                with _SHARED_LOCK:
+                    reg = _SHARED.setdefault((dev.type, dev.index), {})
+                    old = reg.get(k)
+                    new = dict(stager=old.get("stager") if old else None, stager32=old.get("stager32") if old else None,
+                               f32=st._slots[k]["dev_f32"][:self.rows], raw=st.raw(k), paths=paths, arrays=arrays, probes=_probes(arrays), ready=ready)
+                    new[self.mode[k]] = new["active"] = st
+                    reg[k] = new
+        except Exception as e:
+            self.abort("%s: %s" % (type(e).__name__, e))
+            return False
+        self.seen = []
+        return True
 
 
 _PREFETCH_POOL = None

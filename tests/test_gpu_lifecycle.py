@@ -196,6 +196,7 @@ def test_background_fit_equals_the_blocking_fit_and_fills_the_log(tmp_path, monk
         assert all(0.0 < v < 10.0 for v in log["VF_error_after"]) and all(v > 0 for v in log["time_VF"])
         if mode == "1":                                                  # the epoch permutations were drawn under the update and taken over
             assert agent.baseline.__dict__.get("predraw_stats") == (3, 0), agent.baseline.__dict__.get("predraw_stats")
+            assert log["VF_predraw_taken"] == [1, 2, 3] and log["VF_predraw_discarded"] == [0, 0, 0]      # ... and the log says so (r06)
         runs[mode] = dict(theta=agent.policy.get_param_values().copy(), bl=agent.baseline.params.copy(), m=agent.baseline.adam_m.copy(),
                           steps=agent.baseline.adam_steps, err=[float(v) for v in log["VF_error_after"]], pending=pending_seen,
                           pickled=pickle.loads(pickle.dumps(agent.baseline)).params.copy())
@@ -236,3 +237,48 @@ def test_speculative_permutation_draws_are_discarded_when_the_stream_moved():
     np.random.seed(21)
     ref.fit(paths)
     assert np.array_equal(out["taken"][0], ref.params) and np.array_equal(out["taken"][2], np.random.randn(3))
+    # a consumer of np.random that draws in EVERY iteration forfeits the speculative draws every time: one warning, at the second miss
+    import warnings
+    bl = MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=1, learn_rate=1e-3)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for _ in range(3):
+            h = bl.predraw(30 * 40)
+            np.random.randn(1)
+            bl.fit_async(paths, predrawn=h).result()
+    assert bl.__dict__["predraw_stats"] == (0, 3)
+    assert len([w for w in caught if "discarded twice in a row" in str(w.message)]) == 1
+
+
+def test_a_straggling_workgroup_cannot_launder_a_timed_out_fit(monkeypatch):
+    """in the several-workgroup trainer (csrc/mlp_fit.h MULTI) a workgroup that waited ~2 s on a grid barrier gives up.
+    If workgroup 0 was the straggler it later passes every abandoned barrier at once and writes finite losses and parameters LAST.
+    The give-up is recorded in a word of its own and k_mlp_fit_verdict turns it into NaN losses after the kernel; the baseline then
+    keeps the state it had before the fit, serves the pending log entries (NaN) and raises.  MJX_FIT_FAULT=straggler delays
+    workgroup 0 by 2.6 s."""
+    import torch
+    from mjrl_amd._lib import MjxError
+    from mjrl_amd.baselines.mlp_baseline import MLPBaseline
+    from mjrl_amd.utils import process_samples
+    spec = type("Spec", (), dict(observation_dim=60, action_dim=2, horizon=40))       # 64 inputs: two workgroups
+    rng = np.random.RandomState(2)
+    paths = [dict(observations=rng.randn(40, 60), rewards=rng.randn(40), terminated=False) for _ in range(20)]
+    process_samples.compute_returns(paths, 0.99)
+    torch.manual_seed(5); np.random.seed(5)
+    bl = MLPBaseline(spec, reg_coef=1e-3, batch_size=64, epochs=2, learn_rate=1e-3)
+    bl.fit(paths)
+    before = (bl.params.copy(), bl.adam_m.copy(), bl.adam_v.copy(), bl.adam_steps, list(bl.epoch_losses))
+    assert before[3] == 2 * (800 // 64 - 1) and np.all(np.isfinite(before[4]))
+    monkeypatch.setenv("MJX_FIT_FAULT", "straggler")
+    pend = bl.fit_async(paths, return_errors=True)
+    delivered = []
+    pend.hooks.append(lambda errors, ms: delivered.append((errors, ms)))
+    with pytest.raises(MjxError, match="keeps the parameters it had before"):
+        pend.result()
+    assert pend.done and len(delivered) == 1 and np.isnan(delivered[0][0][0]) and np.isnan(delivered[0][0][1]) and delivered[0][1] > 2000.0
+    assert pend.result() == pend.value                     # a second look no longer raises (nor returns None into a float())
+    assert np.array_equal(bl.params, before[0]) and np.array_equal(bl.adam_m, before[1]) and np.array_equal(bl.adam_v, before[2])
+    assert bl.adam_steps == before[3] and list(bl.epoch_losses) == before[4]
+    monkeypatch.delenv("MJX_FIT_FAULT")
+    e0, e1 = bl.fit(paths, return_errors=True)             # the baseline is still usable
+    assert np.isfinite(e0) and np.isfinite(e1) and bl.adam_steps == 2 * before[3] and not np.array_equal(bl.params, before[0])

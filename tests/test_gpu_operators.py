@@ -621,6 +621,110 @@ def test_background_prefetch_hands_out_complete_blocks():
     ingest.drop_shared()
 
 
+def test_streamed_ingestion_equals_staging_after_sampling():
+    """SURVEY 8f N2, second half (r06): chunks of finished trajectories handed to utils/ingest.StreamedBatch WHILE the rest is still
+    being "sampled" end up in exactly the device blocks a stage-after-sampling builds -- rewards / observations raw fp64, actions
+    fp32 by the converting gather, rows in episode order, bit for bit -- registered for the final list, so that compute_returns,
+    the baseline, the update and the fit upload nothing; the whole iteration gives the same bits as without streaming.  Irregular
+    producers (a list that is not the streamed episodes, a chunk beyond the capacity bound) fall back to staging after."""
+    import torch
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    from mjrl_amd.utils import ingest, process_samples
+    n, m, T = 17, 6, 300
+    spec = type("Spec", (), dict(observation_dim=n, action_dim=m, horizon=T))
+
+    def iteration(streamed, warm):
+        ingest.drop_shared()
+        h = process_samples._handle()
+        if warm:                  # a consumer has asked for the raw observations before (the quadratic baseline does, every iteration)
+            wp = synth.make_paths(3, 20, n, m, seed=99)
+            ingest.stage_shared(h, wp, ("observations",)); ingest.drop_shared_batch()
+        paths = synth.make_paths(64, T, n, m, seed=5, ragged=True)
+        info = None
+        if streamed:
+            sb = ingest.StreamedBatch(h)
+            sb.begin(len(paths))
+            for lo in range(0, len(paths), 10):                   # 7 chunks, the last one short
+                sb.add(paths[lo:lo + 10], T)
+            assert sb.finish(paths), sb.why
+            info = dict(chunks=sb.chunks, rows=sb.rows)
+            reg = ingest._SHARED[(h.device.type, h.device.index)]
+            assert all(reg[k]["paths"] is paths for k in ("rewards", "observations", "actions"))
+        blocks = ingest.stage_shared(h, paths, ("rewards", "observations", "actions"), raw=("rewards",) + (("observations",) if warm else ()))
+        if streamed:              # ... served from the stream: no second staging pass
+            assert blocks["rewards"]["raw"].data_ptr() == reg["rewards"]["raw"].data_ptr()
+            assert blocks["actions"]["f32"].data_ptr() == reg["actions"]["f32"].data_ptr()
+        snap = {k: (None if v["raw"] is None else v["raw"].clone(), v["f32"].clone()) for k, v in blocks.items()}
+        pol = MLP(spec, hidden_sizes=(64, 64), seed=1, init_log_std=-0.5)
+        bl = QuadraticBaseline(spec)
+        agent = NPG(None, pol, bl, normalized_step_size=0.05)
+        with ingest.trusted_iteration():
+            process_samples.compute_returns(paths, 0.99)
+            bl.fit(paths)
+            process_samples.compute_advantages(paths, bl, 0.99, 0.95)
+            stats = agent.train_from_paths(paths)
+            errs = bl.fit(paths, return_errors=True)
+        out = dict(snap=snap, theta=pol.get_param_values().copy(), coeffs=bl._coeffs.copy(), stats=np.array(stats), errs=np.array(errs),
+                   adv=np.concatenate([p["advantages"] for p in paths]), ret=np.concatenate([p["returns"] for p in paths]), info=info, paths=paths)
+        agent.engine.close()
+        return out
+    for warm in (True, False):
+        a, b = iteration(True, warm), iteration(False, warm)
+        assert a["info"]["chunks"] == 7 and a["info"]["rows"] == sum(len(p["rewards"]) for p in a["paths"])
+        for k in ("rewards", "observations", "actions"):
+            (ra, fa), (rb, fb) = a["snap"][k], b["snap"][k]
+            assert (ra is None) == (rb is None) and (ra is None or torch.equal(ra, rb)) and torch.equal(fa, fb), k
+        obs = np.concatenate([p["observations"] for p in a["paths"]])
+        assert torch.equal(a["snap"]["observations"][1].cpu(), torch.from_numpy(obs.astype(np.float32)))
+        assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["coeffs"], b["coeffs"]) and np.array_equal(a["adv"], b["adv"])
+        assert np.array_equal(a["ret"], b["ret"]) and np.array_equal(a["stats"], b["stats"]) and np.array_equal(a["errs"], b["errs"])
+    # fall-backs: nothing registered, the ordinary staging serves the batch
+    h = process_samples._handle()
+    ingest.drop_shared()
+    paths = synth.make_paths(8, 50, n, m, seed=6)
+    sb = ingest.StreamedBatch(h); sb.begin(8); sb.add(paths[:4], 50); sb.add(paths[4:], 50)
+    assert not sb.finish(list(reversed(paths))) and "not the streamed episodes" in sb.why
+    sb = ingest.StreamedBatch(h); sb.begin(8); sb.add(paths[:4], 10)                          # a horizon that was a lie
+    assert not sb.ok and "capacity" in sb.why and not sb.finish(paths)
+    got = ingest.stage_shared(h, paths, ("observations",))["observations"]["f32"]
+    assert torch.equal(got.cpu(), torch.from_numpy(np.concatenate([p["observations"] for p in paths]).astype(np.float32)))
+    ingest.drop_shared()
+
+
+def test_train_step_streams_its_rollouts_and_changes_nothing(monkeypatch):
+    """BatchREINFORCE.train_step hands its own sampler a StreamedBatch (pool and in-process): three iterations end on the bits of the
+    runs that stage after sampling (MJX_STREAM_INGEST=0), and the log of the stream says every batch was resident when sampling ended"""
+    from mjrl_amd import samplers
+    from mjrl_amd.algos.npg_cg import NPG
+    from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
+    from mjrl_amd.policies.gaussian_mlp import MLP
+    from mjrl_amd.utils import ingest
+    from tests import _driver_env as DE
+    spec = type("Spec", (), dict(observation_dim=6, action_dim=2, horizon=25))
+    finals = {}
+    for mode, num_cpu in (("1", 2), ("1", 1), ("0", 2)):
+        monkeypatch.setenv("MJX_STREAM_INGEST", mode)
+        ingest.drop_shared()
+        pol = MLP(spec, hidden_sizes=(32, 32), seed=4, init_log_std=-0.5)
+        agent = NPG(DE.make_point_mass, pol, QuadraticBaseline(spec), normalized_step_size=0.05, seed=11, save_logs=True)
+        seen = []
+        for _ in range(3):
+            agent.train_step(N=32, sample_mode='trajectories', gamma=0.95, gae_lambda=0.97, num_cpu=num_cpu)
+            seen.append(agent.last_ingest)
+        if mode == "1":
+            assert all(s is not None and s["streamed"] and s["chunks"] >= 4 for s in seen), seen
+        else:
+            assert all(s is None for s in seen)
+        finals[(mode, num_cpu)] = (pol.get_param_values().copy(), agent.baseline._coeffs.copy())
+        agent.engine.close()
+    for k in (("1", 1), ("0", 2)):
+        assert np.array_equal(finals[("1", 2)][0], finals[k][0]) and np.array_equal(finals[("1", 2)][1], finals[k][1]), k
+    samplers.close_pools()
+    ingest.drop_shared()
+
+
 @pytest.mark.parametrize("d_in", [9, 21, 23, 27, 35, 43, 50, 55, 56, 64, 96, 97, 115, 380, 768, 769])
 def test_persistent_mlp_trainer_equals_per_step_launches(monkeypatch, d_in):
     """The persistent single-workgroup trainer of the MLP baseline (csrc/mlp_fit.h; two 32-feature blocks of the input

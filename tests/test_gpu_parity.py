@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL_VPG = 3e-6
 TOL_FVP = 3e-6
 TOL_STEP = 1e-5          # the north-star bar
+TOL_KL = 1e-5            # mean KL of an update against the reference (r06: was 1e-4)
 
 
 def rel(a, b):
@@ -88,7 +89,7 @@ def test_npg_agent_update_vs_reference(name):
     assert rel(step, ref) < TOL_STEP, rel(step, ref)
     lg = agent.logger.get_current_log()
     assert abs(lg["alpha"] - float(c.g["alpha"])) < 1e-5 * float(c.g["alpha"])
-    assert abs(lg["kl_dist"] - float(c.g["kl"])) < 1e-4 * float(c.g["kl"])
+    assert abs(lg["kl_dist"] - float(c.g["kl"])) < TOL_KL * float(c.g["kl"]), ("kl", lg["kl_dist"], float(c.g["kl"]))
     assert abs(lg["surr_improvement"] - float(c.g["surr_improvement"])) < 2e-5
     np.testing.assert_allclose(stats, c.g["base_stats"], rtol=1e-12)
     assert pol.old_equals_new()
@@ -105,7 +106,7 @@ def test_trpo_line_search_vs_reference():
     agent.train_from_paths(c.paths)
     assert agent.last_update["trials"] == 2                  # the fixture backtracks exactly once
     assert abs(agent.last_update["alpha"] - float(c.g["alpha"])) < 1e-5 * float(c.g["alpha"])
-    assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < 1e-4 * float(c.g["kl"])
+    assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < TOL_KL * float(c.g["kl"]), ("kl", agent.last_update["kl_dist"], float(c.g["kl"]))
     step, ref = pol.get_param_values().astype(np.float64) - c.theta0, c.g["new_params"].astype(np.float64) - c.theta0
     assert rel(step, ref) < TOL_STEP
 
@@ -167,7 +168,7 @@ def test_cfg4_wide_kernels_and_npg_update_vs_reference():
     step = pol.get_param_values().astype(np.float64) - c.theta0
     print("cfg4 wide update step:", c.check_step("update_step", step, TOL_STEP))
     assert abs(agent.last_update["alpha"] - float(c.g["alpha"])) < 1e-5 * float(c.g["alpha"])
-    assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < 1e-4 * float(c.g["kl"])
+    assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < TOL_KL * float(c.g["kl"]), ("kl", agent.last_update["kl_dist"], float(c.g["kl"]))
     np.testing.assert_allclose(stats, c.g["base_stats"], rtol=1e-12)
     agent.engine.close()
 
@@ -189,7 +190,7 @@ def test_dapg_cfg5_wide_vs_reference():
     step = pol.get_param_values().astype(np.float64) - c.theta0
     print("dapg wide update step:", c.check_step("update_step", step, TOL_STEP))
     assert abs(agent.last_update["alpha"] - float(c.g["alpha"])) < 1e-5 * float(c.g["alpha"])
-    assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < 1e-4 * float(c.g["kl"])
+    assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < TOL_KL * float(c.g["kl"]), ("kl", agent.last_update["kl_dist"], float(c.g["kl"]))
     assert abs((agent.last_update["surr_after"] - agent.last_update["surr_before"]) - float(c.g["surr_improvement"])) < 2e-5
     np.testing.assert_allclose(stats, c.g["base_stats"], rtol=1e-12)
     agent.engine.close()
@@ -239,7 +240,7 @@ def test_shard_size_update_vs_reference(key):
              abs(lu["alpha"] - float(g["alpha"])) / float(g["alpha"]), abs(lu["kl_dist"] - float(g["kl"])) / float(g["kl"])))
     assert err < TOL_STEP, err
     assert abs(lu["alpha"] - float(g["alpha"])) < 1e-5 * float(g["alpha"])
-    assert abs(lu["kl_dist"] - float(g["kl"])) < 1e-4 * float(g["kl"])
+    assert abs(lu["kl_dist"] - float(g["kl"])) < TOL_KL * float(g["kl"]), ("kl", lu["kl_dist"], float(g["kl"]))
     assert abs((lu["surr_after"] - lu["surr_before"]) - float(g["surr_improvement"])) < 1e-4 * abs(float(g["surr_improvement"])) + 2e-6
     agent.engine.close()
 
@@ -320,7 +321,7 @@ def test_shard_sum_parity():
     eng.close()
 
 
-@pytest.mark.parametrize("transport,cut", [("peer", 23456), ("hook", 23456), ("peer", 0), ("peer3", 20000)])
+@pytest.mark.parametrize("transport,cut", [("peer", 23456), ("hook", 23456), ("peer", 0), ("peer3", 20000), ("peer8", 7000)])
 def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport, cut):
     """The multi-rank control flow on real kernels: two processes (torch.distributed.run) share the GPU, each binds a ragged
     trajectory shard and runs the engine's update sequence (K1 + rank sum, the per-iteration FVP / rank sum / CG-step loop,
@@ -332,26 +333,29 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport, cut):
     kernels.  Result == the one-process update on the whole batch (NPG call by call and as one call, TRPO with the device-side
     line search, DAPG as one call); all ranks hold bit-identical vectors.
     "peer3" (r04): THREE processes on the GPU -- the peer exchange with one arrival flag per source rank beyond two ranks (a 4-slot
-    sum with one slot of zeros; ADVICE r03 asked for >= 3 ranks: this covers the protocol, not the ordering of real xGMI links)."""
+    sum with one slot of zeros; ADVICE r03 asked for >= 3 ranks: this covers the protocol, not the ordering of real xGMI links).
+    "peer8" (r06): EIGHT processes on the GPU, the world size of the north-star's node -- 8 per-source flags, the 8-slot sums of
+    k_cg_init_w / k_cg_step_reg<8, 8>, both slot parities, one rank (3) without any trajectory (the generic exchange next to the
+    folded ones); the gradient and K1's sums travel in ONE exchange, the step is formed by the solve's last kernel."""
     import subprocess
     import sys
     import torch
     from mjrl_amd.engine import UpdateEngine
     out = str(tmp_path / "two_rank.npz")
     port = 29600 + (os.getpid() % 300)
-    world = 3 if transport == "peer3" else 2
-    cuts3 = [20000, 41000]
+    world = 3 if transport == "peer3" else 8 if transport == "peer8" else 2
+    cuts3 = [20000, 41000] if world != 8 else [7000, 15000, 22000, 22000, 38000, 45000, 52500]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MJX_PEER_COMM="1" if transport.startswith("peer") else "0",
                MJX_TEST_CUT=str(cut), MJX_TEST_CUTS=",".join(str(c) for c in cuts3))
-    port += (7 if transport == "peer" else 0) + (13 if cut == 0 else 0) + (29 if world == 3 else 0)
+    port += (7 if transport == "peer" else 0) + (13 if cut == 0 else 0) + (29 if world == 3 else 0) + (41 if world == 8 else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "_two_rank_gpu_worker.py"), out]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280 if world < 8 else 900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     two = np.load(out)
     assert bool(two["ranks_identical"][0])
     assert two["native_comm"].all(), "the rank sums must run inside libmjx's C loops (mjx_cg_solve / mjx_npg_update)"
-    assert str(two["comm_kind"][0]) == ("peer" if world == 3 else transport)
+    assert str(two["comm_kind"][0]) == ("peer" if world > 2 else transport)
     assert bool(two["one_call_equal"][0]), "mjx_npg_update != the call-by-call sequence on two ranks"
     n, m, hid, N = 17, 6, (64, 64), 60000
     rng = np.random.RandomState(5)
@@ -898,7 +902,7 @@ def test_npg_input_normalization_vs_reference():
     print("input_normalization step: vs reference %.2e, vs fp64 %.2e (reference vs fp64 %.2e)" % (e_ref, e_f64, ref_f64))
     assert e_ref < TOL_STEP, (e_ref, e_f64, ref_f64)
     assert abs(agent.last_update["alpha"] - float(c.g["alpha"])) < 1e-5 * float(c.g["alpha"])
-    assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < 1e-4 * float(c.g["kl"])
+    assert abs(agent.last_update["kl_dist"] - float(c.g["kl"])) < TOL_KL * float(c.g["kl"]), ("kl", agent.last_update["kl_dist"], float(c.g["kl"]))
 
 
 def test_hvp_sample_frac_rng_parity():

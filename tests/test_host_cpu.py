@@ -548,13 +548,21 @@ def test_path_walk_hand_out_equals_the_python_loop():
         ingest._pathwalk.hand_out([1, 2], "returns", host, off)
 
 
-def test_allocator_tuning_is_applied_once_and_can_be_switched_off():
-    """utils/ingest._tune_malloc: glibc's mmap / trim thresholds raised in the training process (what made releasing a rollout batch
-    cost 0.5 or 13 ms); MJX_MALLOC_TUNE=0 leaves the allocator alone"""
+def test_allocator_tuning_is_opt_in_by_the_training_entry_points():
+    """utils/ingest.tune_malloc: glibc's mmap / trim thresholds raised in the TRAINING process (what made releasing a rollout batch
+    cost 0.5 or 13 ms) -- by BatchREINFORCE.train_step / dropin.install / bench.py, NOT by importing the package (VERDICT r05 item 7);
+    idempotent; MJX_MALLOC_TUNE=0 leaves the allocator alone"""
     import subprocess
     import sys
-    from mjrl_amd.utils import ingest
-    assert ingest.MALLOC_TUNED is True
-    code = "import sys; sys.path.insert(0, %r); from mjrl_amd.utils import ingest; print(ingest.MALLOC_TUNED)" % ROOT
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MJX_MALLOC_TUNE="0"), timeout=120)
-    assert r.returncode == 0 and r.stdout.strip() == "False", (r.stdout, r.stderr[-500:])
+    code = ("import sys; sys.path.insert(0, %r); import mjrl_amd; from mjrl_amd.utils import ingest; import mjrl_amd.algos.npg_cg, mjrl_amd.policies.gaussian_mlp;"
+            "a = ingest.MALLOC_TUNED; b = ingest.tune_malloc(); c = ingest.tune_malloc(); print(a, b, c, ingest.MALLOC_TUNED)" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "MJX_MALLOC_TUNE"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "None True True True", (r.stdout, r.stderr[-500:])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, MJX_MALLOC_TUNE="0"), timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "None False False False", (r.stdout, r.stderr[-500:])
+    import inspect
+    from mjrl_amd import dropin
+    from mjrl_amd.algos import batch_reinforce
+    assert "tune_malloc()" in inspect.getsource(batch_reinforce.BatchREINFORCE.train_step)
+    assert "tune_malloc()" in inspect.getsource(dropin.install)

@@ -76,6 +76,94 @@ def test_native_sampler_pool_matches_the_serial_sampler():
     samplers.close_pools()
 
 
+class _RecordingSink:
+    """what mjrl_amd.samplers asks of a sink (utils/ingest.StreamedBatch): begin(total), add(chunk, T) in episode order, abort(why)"""
+    def __init__(self):
+        self.total, self.chunks, self.T, self.aborted = None, [], [], None
+
+    def begin(self, total):
+        self.total = total
+
+    def add(self, chunk, T=None):
+        self.chunks.append(chunk); self.T.append(T)
+
+    def abort(self, why):
+        self.aborted = why
+
+
+def test_native_sampler_streams_chunks_in_episode_order():
+    """r06: with a sink the request is cut into more jobs than workers and every chunk is handed on, in EPISODE
+    order, the moment it arrives -- the same episodes, the same path list as without one (pool and in-process)"""
+    from mjrl_amd import samplers
+    pol = _policy()
+    plain = samplers.sample_paths(12, DE.make_point_mass, pol, base_seed=40, num_cpu=1)
+    for num_cpu in (2, 1):
+        sink = _RecordingSink()
+        got = samplers.sample_paths(12, DE.make_point_mass, pol, base_seed=40, num_cpu=num_cpu, suppress_print=True, sink=sink)
+        _same_paths(plain, got)
+        assert sink.total == 12 and sink.aborted is None and len(sink.chunks) > num_cpu and set(sink.T) == {25}
+        flat = [p for c in sink.chunks for p in c]
+        assert len(flat) == len(got) and all(a is b for a, b in zip(flat, got))       # the very dicts of the returned list, in its order
+    # ceil split (core.py:124): 5 episodes on 2 workers are 6, streamed or not
+    sink = _RecordingSink()
+    assert len(samplers.sample_paths(5, DE.make_point_mass, pol, base_seed=3, num_cpu=2, suppress_print=True, sink=sink)) == 6 and sink.total == 6
+    samplers.close_pools()
+
+
+class EnvClassWithKwargs(DE.PointMassGym):
+    def __init__(self, shift=0.0):
+        super().__init__()
+        self.shift = shift
+
+
+def test_native_sampler_accepts_env_classes_and_survives_unpicklable_payloads(monkeypatch):
+    """(i) an env CLASS is a factory (core.py:36-39 instantiates any callable; a class also has `step`); (ii) a payload the
+    workers cannot be sent -- here a lambda -- is served in this process with one warning instead of a lost task and a timeout;
+    (iii) num_cpu='max' is capped"""
+    import warnings
+    from mjrl_amd import samplers
+    pol = _policy()
+    a = samplers.sample_paths(3, EnvClassWithKwargs, pol, base_seed=7, num_cpu=1, env_kwargs=dict(shift=1.0))
+    b = samplers.sample_paths(3, DE.make_point_mass, pol, base_seed=7, num_cpu=1)
+    _same_paths(a, b)
+    monkeypatch.setattr(samplers, "_SERIAL_ONLY", {})
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        c = samplers.sample_paths(4, lambda: DE.PointMassGym(), pol, base_seed=7, num_cpu=2, suppress_print=True)
+        d = samplers.sample_paths(4, lambda: DE.PointMassGym(), pol, base_seed=7, num_cpu=2, suppress_print=True)
+    _same_paths(c, samplers.sample_paths(4, DE.make_point_mass, pol, base_seed=7, num_cpu=1))
+    _same_paths(c, d)
+    assert len([w for w in caught if "served in the training process itself" in str(w.message)]) == 1
+    assert DE.worker_evidence(c)["pids"] == [os.getpid()]
+    monkeypatch.setenv("MJX_SAMPLER_MAX_WORKERS", "3")
+    assert samplers._resolve_num_cpu('max') == min(3, os.cpu_count()) and samplers._resolve_num_cpu(None) == 1
+    samplers.close_pools()
+
+
+def test_a_main_script_without_a_guard_is_not_handed_to_spawned_workers(tmp_path):
+    """a spawned worker imports the main module again: an unguarded training script would re-run itself in every worker.  Such a
+    main module is detected, the request is served in-process (one warning), the script's results are the serial ones."""
+    import subprocess
+    import sys
+    script = tmp_path / "unguarded_job.py"
+    script.write_text(
+        "import sys, warnings\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import _driver_env as DE\n"
+        "from mjrl_amd import samplers\n"
+        "from mjrl_amd.policies.gaussian_mlp import MLP\n"
+        "spec = type('Spec', (), dict(observation_dim=6, action_dim=2, horizon=25))\n"
+        "pol = MLP(spec, hidden_sizes=(32, 32), seed=1, init_log_std=-0.5)\n"
+        "with warnings.catch_warnings(record=True) as w:\n"
+        "    warnings.simplefilter('always')\n"
+        "    paths = samplers.sample_paths(4, DE.make_point_mass, pol, base_seed=1, num_cpu=2, suppress_print=True)\n"
+        "print('RESULT', len(paths), len(DE.worker_evidence(paths)['pids']), sum('without a __main__ guard' in str(x.message) for x in w))\n"
+        % (ROOT, os.path.join(ROOT, "tests")))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")] == ["RESULT 4 1 1"], r.stdout      # ran once, in one process
+
+
 class _SlowEnv(DE.PointMassGym):
     def step(self, a):
         import time

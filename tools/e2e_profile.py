@@ -3,6 +3,7 @@ import os, sys, time, json, cProfile, pstats, io
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from mjrl_amd.algos.npg_cg import NPG
+from mjrl_amd.utils import ingest as _ingest; _ingest.tune_malloc()   # a training process (what train_step / dropin.install do)
 from mjrl_amd.policies.gaussian_mlp import MLP
 spec = type("Spec", (), dict(observation_dim=17, action_dim=6, horizon=1000))
 rng = np.random.RandomState(0)

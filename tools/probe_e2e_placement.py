@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import bench
 from mjrl_amd.algos.npg_cg import NPG
+from mjrl_amd.utils import ingest as _ingest; _ingest.tune_malloc()   # a training process (what train_step / dropin.install do)
 from mjrl_amd.policies.gaussian_mlp import MLP
 
 libc = ctypes.CDLL(None, use_errno=True)

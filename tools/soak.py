@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from mjrl_amd.algos.npg_cg import NPG
+from mjrl_amd.utils import ingest as _ingest; _ingest.tune_malloc()   # a training process (what train_step / dropin.install do)
 from mjrl_amd.algos.trpo import TRPO
 from mjrl_amd.algos.ppo_clip import PPO
 from mjrl_amd.baselines.quadratic_baseline import QuadraticBaseline
