@@ -150,9 +150,8 @@ def cpu_baseline(theta0, sample_traj):
     default_threads = torch.get_num_threads()
     one_update(paths_of(10))                                      # warm-up
     cal, cal_paths = {}, paths_of(200)
-    for k in sorted({8, 16, 32, 64, default_threads}):
-        if k > default_threads:
-            continue
+    for k in sorted({k for k in (8, 16, 32, 64) if k <= default_threads} or {default_threads}):
+        # (torch's default -- one thread per core: 128 on the GPU boxes -- took 27 s on this slice against 4.2 s at 16: not a candidate)
         torch.set_num_threads(k)
         cal[k] = one_update(cal_paths)[0]
     best = min(cal, key=cal.get)
@@ -226,7 +225,7 @@ def cpu_baseline_port(theta0, sample_traj):
                 seconds=dt, nproc=os.cpu_count())
 
 
-def secondary_measurements(eng, theta0, theta0_dev, ref=None):
+def secondary_measurements(eng, theta0, theta0_dev, ref=None, full_size=True):
     """Measured AFTER the primary timed region, on the same GPU (N = 1):
     * BASELINE configs[2]: one TRPO update (KL line search, mjrl/algos/trpo.py:100-126) on the same 1M batch -- K1, CG,
       then backtracking evaluations of K3 until KL < kl_dist (kl_dist = 0.025: the first two step lengths are rejected), the
@@ -297,6 +296,7 @@ def secondary_measurements(eng, theta0, theta0_dev, ref=None):
         P = sum(sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1))
         flop = 2 * (4 * P - 2 * n * hid[0]) * N
         ms = prof[0] / prof[1]
+        ab = lw_switch_ab(e, grad, flop)
         # one whole NPG update of this shard (K1, the config's CG iterations, step, K3) through the one-call entry point
         cg_iters = cfg["cg_iters"]
         sa, kl = e.npg_update(cg_iters, 1e-4, 0.05, -3.0)
@@ -312,7 +312,8 @@ def secondary_measurements(eng, theta0, theta0_dev, ref=None):
         lw[name] = {"rows": N, "fvp_ms": ms, "TFLOPs": flop / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
                     "flop_per_fvp": flop, "kernels": "k_gemm_p (persistent tangent / delta products, csrc/lw_gemm_p.h) + k_gemm<128,256> / <128,128> weight gradients + k_lw_head (one-pass output layer, csrc/lw_head.h)",
                     "timed": "4 products, HIP events around the whole chain of one product",
-                    "npg_update_ms": upd_ms, "cg_iters": cg_iters, "inputs": "seeded host rows (bench.lw_shard_inputs, PCG64 seed %d)" % cfg["seed"]}
+                    "npg_update_ms": upd_ms, "cg_iters": cg_iters, "inputs": "seeded host rows (bench.lw_shard_inputs, PCG64 seed %d)" % cfg["seed"],
+                    "switch_ab_same_process": ab}
         if cfg["algo"] == "dapg":
             # ... and the algorithm configs[4] names: one DAPG update (mjrl/algos/dapg.py:92-121) of the same shard with 25 x 200
             # demonstration steps appended, through the one-call entry point mjx_dapg_update (K1 over [on-policy ; demos],
@@ -363,7 +364,214 @@ def secondary_measurements(eng, theta0, theta0_dev, ref=None):
         del e, inp
         torch.cuda.empty_cache()
     out["roofline_lw"] = lw
+    if full_size:
+        # BASELINE configs[3] / [4] at their stated size on this one GPU (4M x 376-256^2-17, 25 CG; 8M x 39-512^2-28 + demos, DAPG)
+        out["full_size"] = {"configs3": full_size_case("configs3_humanoid_256x256"), "configs4": full_size_case("configs4_adroit_512x512")}
     out.update(user_level_measurements())
+    return out
+
+
+def lw_switch_ab(e, v, flop, switches=("MJX_LW_HEAD8", "MJX_LW_HEAD_KTRIM", "MJX_LW_PERSIST"), rounds=3, per=3):
+    """Same-process, same-box A/B of the layer-wise chain's switches (the boxes' spread, 0.649-0.692 at
+    configs[3], is wider than the effects to adjudicate): for every switch, `rounds` alternations of [default ; switch = 0], `per`
+    Fisher-vector products each between HIP events (libmjx re-reads its MJX_LW_* switches at every launch since r06).
+    -> {switch: {on_ms, off_ms, off_over_on}} + the default chain's median over all its passes."""
+    import torch
+    from mjrl_amd._lib import check
+
+    def timed():
+        torch.cuda.synchronize()
+        check(e.lib.mjx_profile_enable(e.ctx, 1))
+        for _ in range(per):
+            e.fvp(v)
+        prof = (ctypes.c_double * 2)()
+        check(e.lib.mjx_profile_read(e.ctx, prof))
+        check(e.lib.mjx_profile_enable(e.ctx, 0))
+        return prof[0] / prof[1]
+    out, base_all = {}, []
+    for sw in switches:
+        on, off = [], []
+        prev = os.environ.get(sw)
+        try:
+            for _ in range(rounds):
+                os.environ.pop(sw, None)
+                if prev is not None:
+                    os.environ[sw] = prev
+                e.fvp(v); on.append(timed())
+                os.environ[sw] = "0"
+                e.fvp(v); off.append(timed())
+        finally:
+            os.environ.pop(sw, None)
+            if prev is not None:
+                os.environ[sw] = prev
+        base_all += on
+        mon, moff = sorted(on)[len(on) // 2], sorted(off)[len(off) // 2]
+        out[sw] = {"on_ms": mon, "off_ms": moff, "off_over_on": moff / mon, "on_ms_each": on, "off_ms_each": off,
+                   "on_frac_of_fp32_mfma_peak": flop / (mon * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF}
+    e.fvp(v)
+    torch.cuda.synchronize()
+    base_all.sort()
+    out["default_chain_ms_median_of_all_passes"] = base_all[len(base_all) // 2]
+    out["default_chain_frac_median"] = flop / (base_all[len(base_all) // 2] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF
+    out["what"] = "alternating passes in ONE process on ONE box: [switch at its default ; switch = 0] x %d, %d products per pass, HIP events around the chain" % (rounds, per)
+    return out
+
+
+def full_size_case(name, rows=None, shards=8, seed_shift=0, time_it=True):
+    """BASELINE configs[3] / configs[4] at their STATED size on ONE MI355X: `shards` x the per-GPU shard of
+    LW_SHARDS[name] (4M x 376-256^2-17 with 25 CG iterations; 8M x 39-512^2-28 + 8 x 5 000 demonstration rows, DAPG), resident
+    in HBM, rows generated on the device (torch.Generator; what matters here is that the full batch and its shards see the same
+    rows) -- the N = 1 anchor of those configs' 1 -> 8 curve.  One engine holds the whole batch: K1, Fisher-vector products (HIP
+    events around the chain), one whole update.  Then the SAME rows as `shards` engines of N / shards rows each with the global
+    sample count (what the ranks of an 8-GPU job hold): gradient and product must be the sum of the shards' (<= 1e-6), and the
+    update composed from the shards' sums -- CG on the summed products with the library's own vector kernels, step length,
+    K3 sums -- must give the full batch's alpha / KL / step.  Nothing in this function knows a 32-bit row or element index:
+    tests/test_gpu_parity.py::test_layerwise_block_beyond_2_31_elements runs it at 4.3M x 512 (2.2e9 elements per activation block).
+    rows: total on-policy rows (default: shards x the LW_SHARDS entry)."""
+    import torch
+    from mjrl_amd._lib import check, ptr
+    from mjrl_amd.engine import UpdateEngine
+    cfg = LW_SHARDS[name]
+    n, m, hid = cfg["n"], cfg["m"], cfg["hidden"]
+    S = (cfg["n_traj"] * cfg["T"]) if rows is None else int(rows) // shards
+    N = S * shards
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + cfg["seed"] + seed_shift)
+    th = lw_initial_params(n, m, hid)
+    ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    obs = torch.randn((N, n), generator=gen, device=dev, dtype=torch.float32)
+    act = torch.randn((N, m), generator=gen, device=dev, dtype=torch.float32)
+    adv64 = torch.randn(N, generator=gen, device=dev, dtype=torch.float64)
+    adv_w64 = (adv64 - adv64.mean()) / (adv64.std(unbiased=False) + 1e-6)                       # batch_reinforce.py:185
+    dapg = cfg["algo"] == "dapg"
+    Nd_s = cfg.get("demo_rows", 0) if dapg else 0                                            # demonstration rows per shard
+    cg_iters, damping = cfg["cg_iters"], 1e-4
+    step_size = 2.0 * cfg["kl_dist"] if dapg else 0.05
+    if dapg:
+        dobs = torch.randn((Nd_s * shards, n), generator=gen, device=dev, dtype=torch.float32)
+        dact = torch.randn((Nd_s * shards, m), generator=gen, device=dev, dtype=torch.float32)
+        adv_on = adv_w64.to(torch.float32)
+        adv_all_on = (1e-2 * adv_w64 / (adv_w64.std(unbiased=False) + 1e-8)).to(torch.float32)  # dapg.py:65-70, iteration 0
+        adv_demo = torch.full((Nd_s * shards,), 1e-2 * cfg["lam_0"], device=dev, dtype=torch.float32)
+    else:
+        adv_on = adv_w64.to(torch.float32)
+    del adv64, adv_w64
+    N_all = N + Nd_s * shards
+    sizes = (n,) + tuple(hid) + (m,)
+    P = sum(sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1))
+    flop = 2 * (4 * P - 2 * n * hid[0]) * N
+
+    def bind(e, lo, hi, dlo, dhi):
+        """engine `e` <- on-policy rows [lo, hi) (+ demonstration rows [dlo, dhi)), global counts; K1 run -> gradient (a clone)"""
+        e.set_policy(th, th, ident, ident)
+        if dapg:
+            e.set_batch(torch.cat([obs[lo:hi], dobs[dlo:dhi]]), torch.cat([act[lo:hi], dact[dlo:dhi]]),
+                        torch.cat([adv_all_on[lo:hi], adv_demo[dlo:dhi]]), N_global=N_all)
+        else:
+            e.set_batch(obs[lo:hi], act[lo:hi], adv_on[lo:hi], N_global=N)
+        g = e.surr_vpg(sync=False)[0].clone()
+        if dapg:
+            g *= np.float32(N_all / float(N))                                  # dapg.py:97-98 (fp32 product per element, like k_scale_f32)
+            e.bind_rows(hi - lo, adv=adv_on[lo:hi], N_global=N)                   # Fisher / surrogate / KL: the on-policy prefix (:92, :103)
+        return g
+
+    def rel(a, b):
+        a, b = a.double(), b.double()
+        return float((a - b).norm() / b.norm())
+
+    out = {"rows": N, "demo_rows": Nd_s * shards, "d": int(th.size), "cg_iters": cg_iters, "algo": cfg["algo"],
+           "hbm_GB_inputs": (obs.numel() + act.numel() + adv_on.numel()) * 4 / 1e9}
+    # ---- the whole batch on one engine
+    e = UpdateEngine(n, m, hid)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    g_full = bind(e, 0, N, 0, Nd_s * shards)
+    torch.cuda.synchronize(); out["bind_plus_K1_ms"] = 1e3 * (time.perf_counter() - t0)
+    v = g_full.clone()
+    hv_full = e.fvp(v).clone()
+    if time_it:
+        torch.cuda.synchronize()
+        check(e.lib.mjx_profile_enable(e.ctx, 1))
+        for _ in range(3):
+            e.fvp(v)
+        prof = (ctypes.c_double * 2)()
+        check(e.lib.mjx_profile_read(e.ctx, prof))
+        check(e.lib.mjx_profile_enable(e.ctx, 0))
+        ms = prof[0] / prof[1]
+        out.update(fvp_ms=ms, fvp_TFLOPs=flop / (ms * 1e-3) / 1e12, fvp_frac_of_fp32_mfma_peak=flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+                   flop_per_fvp=flop)
+        out["switch_ab_same_process"] = lw_switch_ab(e, v, flop, switches=("MJX_LW_HEAD8",), rounds=2, per=2)
+
+    def update(eng):
+        eng.set_policy(th, th, ident, ident)
+        if dapg:                                                                 # back to [on-policy ; demonstrations] with K1's advantages
+            eng.set_batch(eng.obs, eng.act, torch.cat([adv_all_on, adv_demo]), N_global=N_all)
+            res = eng.dapg_update(cg_iters, damping, step_size, -3.0, N, adv_on, N_on_global=N)
+        else:
+            res = eng.npg_update(cg_iters, damping, step_size, -3.0)
+        late = eng.deferred()
+        return dict(alpha=late["alpha"], kl=res[1], surr_improvement=res[0] - late["surr_before"], gdotx=late["gdotx"],
+                    step=(eng.theta_new - torch.from_numpy(th).to(dev)).clone())
+    full = update(e)
+    if time_it:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        update(e)
+        torch.cuda.synchronize(); out["update_ms"] = 1e3 * (time.perf_counter() - t0)
+        out["updates_per_s"] = 1e3 / out["update_ms"]
+    out["hbm_GB_in_use_full_batch"] = torch.cuda.mem_get_info(dev)[1] / 1e9 - torch.cuda.mem_get_info(dev)[0] / 1e9
+    e.close()
+    del e
+    torch.cuda.empty_cache()
+    # ---- the same rows as `shards` engines (what the ranks of the 8-GPU job hold), composed by hand
+    engs, g_sum = [], None
+    for k in range(shards):
+        ek = UpdateEngine(n, m, hid)
+        gk = bind(ek, k * S, (k + 1) * S, k * Nd_s, (k + 1) * Nd_s)
+        g_sum = gk if g_sum is None else g_sum + gk
+        engs.append(ek)
+    hv_sum = None
+    for ek in engs:
+        h = ek.fvp(v).clone()
+        hv_sum = h if hv_sum is None else hv_sum + h
+    out["shard_sum_vs_full"] = {"gradient_rel_l2": rel(g_sum, g_full), "fvp_rel_l2": rel(hv_sum, hv_full), "bar": 1e-6, "shards": shards}
+    # K3 at theta_old (DAPG's surr_before on the on-policy rows), CG on the summed products, step, K3
+    e0 = engs[0]
+    b = g_sum.contiguous()
+    e0.backend.cg_init(b)
+    Ap, tmp = torch.empty_like(b), torch.empty_like(b)
+    p_ptr = ctypes.c_void_p(e0.lib.mjx_cg_p(e0.ctx))
+    for _ in range(cg_iters):
+        Ap.zero_()
+        for ek in engs:
+            check(ek.lib.mjx_fvp(ek.ctx, p_ptr, ptr(tmp), ek.stream()))
+            Ap += tmp
+        e0.backend.cg_step(Ap, damping, 1e-10)
+    x, bdotx = torch.empty_like(b), torch.zeros(1, dtype=torch.float64, device=dev)
+    e0.backend.cg_finish(b, x, bdotx)
+    gdotx = float(bdotx.item())
+    alpha = float(np.sqrt(abs(step_size / (gdotx + 1e-20))))
+    th_new = (torch.from_numpy(th).to(dev) + np.float32(alpha) * x)
+    th_new[-m:] = torch.clamp(th_new[-m:], min=-3.0)
+    th_new_h = th_new.cpu().numpy()
+    sa = kl = 0.0
+    for ek in engs:
+        ek.set_policy(th_new_h, th, ident, ident)
+        s_, k_ = ek.eval_surr_kl()
+        sa += s_; kl += k_
+    comp = dict(alpha=alpha, kl=kl, step=th_new - torch.from_numpy(th).to(dev))
+    out["update_vs_shard_composition"] = {
+        "alpha_rel": abs(full["alpha"] - comp["alpha"]) / comp["alpha"], "kl_rel": abs(full["kl"] - comp["kl"]) / comp["kl"],
+        "step_rel_l2": rel(full["step"], comp["step"]), "alpha": full["alpha"], "kl": full["kl"],
+        "bars": {"alpha_rel": 1e-5, "kl_rel": 1e-4, "step_rel_l2": 1e-5},
+        "what": "the full batch's one-call update against the update composed from %d shards' sums (gradient, every CG iteration's product, "
+                "K3) with the library's own CG kernels: the arithmetic an 8-rank job performs, on one GPU" % shards}
+    out["failed"] = bool(out["shard_sum_vs_full"]["gradient_rel_l2"] > 1e-6 or out["shard_sum_vs_full"]["fvp_rel_l2"] > 1e-6
+                         or out["update_vs_shard_composition"]["alpha_rel"] > 1e-5 or out["update_vs_shard_composition"]["kl_rel"] > 1e-4
+                         or out["update_vs_shard_composition"]["step_rel_l2"] > 1e-5)
+    for ek in engs:
+        ek.close()
+    del engs, obs, act
+    torch.cuda.empty_cache()
     return out
 
 
@@ -463,26 +671,23 @@ def user_level_measurements():
                 pre = bl.predraw(N_TRAJ * T) if name == "mlp" else None       # (train_step: the epoch permutations drawn under advantages + update)
                 process_samples.compute_advantages(paths, bl, 0.995, 0.97); t2 = time.perf_counter()
                 agent.train_from_paths(paths); main.synchronize(); t3 = time.perf_counter()
-                if name == "mlp":
-                    pend = bl.fit_async(paths, predrawn=pre)   # what BatchREINFORCE.train_step does: started, not waited for
-                else:
-                    bl.fit(paths)
-                main.synchronize(); t4 = time.perf_counter()
+                # what BatchREINFORCE.train_step does: the fit is started, not waited for (the fitted baseline is first read by the
+                # NEXT iteration's compute_advantages, after sampling)
+                pend = bl.fit_async(paths, predrawn=pre) if name == "mlp" else bl.fit_async(paths)
+                t4 = time.perf_counter()
             ingest.drop_shared_batch()
             rows.append([1e3 * x for x in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)] + [stand_in_ms])
         if pend is not None:
             pend.result()
         rows = rows[1:]                                  # the first iteration allocates
         med = sorted(rows, key=lambda r: r[4])[len(rows) // 2]
-        if name == "mlp":
-            res = dict(zip(["returns_ms", "advantages_ms", "update_ms", "baseline_fit_enqueue_ms", "total_ms", "stand_in_sampling_ms"], med))
-            last = overl[-1] if overl else {}
-            res["baseline_fit_ms"] = last.get("baseline_fit_device_ms")
-            res["baseline_fit"] = ("overlapped: MLPBaseline.fit_async runs the Adam chain on a side stream under the next "
-                                   "iteration's sampling; total_ms is the critical path (fit enqueued, not waited for)")
-            res["overlap_each"] = overl
-        else:
-            res = dict(zip(["returns_ms", "advantages_ms", "update_ms", "baseline_fit_ms", "total_ms", "stand_in_sampling_ms"], med))
+        res = dict(zip(["returns_ms", "advantages_ms", "update_ms", "baseline_fit_enqueue_ms", "total_ms", "stand_in_sampling_ms"], med))
+        last = overl[-1] if overl else {}
+        res["baseline_fit_ms"] = last.get("baseline_fit_device_ms")
+        res["baseline_fit"] = ("overlapped: MLPBaseline.fit_async runs the Adam chain on a side stream under the next iteration's sampling" if name == "mlp" else
+                               "overlapped: the ridge baselines' fit_async enqueues the fp64 Gram kernel behind the update and a helper thread solves the "
+                               "F x F system under the next iteration's sampling") + "; total_ms is the critical path (fit enqueued, not waited for)"
+        res["overlap_each"] = overl
         res["total_ms_each"] = [r[4] for r in rows]
         res["iterations_timed"] = len(rows)
         res["ingestion"] = ("streamed under the stand-in sampler (utils/ingest.StreamedBatch: every chunk of 50 trajectories staged and sent as it "
@@ -606,6 +811,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (TRPO line-search update = BASELINE configs[2]; layer-wise FVP at the "
                          "per-GPU shard sizes of configs[3] / [4]); they run after the primary timed region, N = 1 only")
+    ap.add_argument("--no-full-size", action="store_true", help="skip secondary.full_size (configs[3] / [4] at their stated 4M / 8M rows on this GPU)")
     ap.add_argument("--no-rehearsal", action="store_true", help="skip secondary.rehearsal_world8 (two sub-runs of this script as rank 0 of 8)")
     ap.add_argument("--rehearse-world", type=int, default=0,
                     help="diagnostic, 1 GPU: run rank 0's share of an R-rank job (1/R of the batch, global N, "
@@ -831,7 +1037,7 @@ def main():
                         "cg_iteration_us around a whole iteration (every 7-th, in 8 extra updates); outside = ms_per_update - %d x iteration "
                         "(K1, K3, their reductions and rank sums, the read-back, the host's turn-around)" % (max(args.fvp_event_stride, 1), CG_ITERS)}
         if world == 1 and not args.no_secondary and args.rehearse_world <= 1:
-            out["secondary"] = secondary_measurements(eng, theta0, theta0_dev, ref)
+            out["secondary"] = secondary_measurements(eng, theta0, theta0_dev, ref, full_size=not args.no_full_size)
             if not args.no_rehearsal:
                 eng.close()                                       # (the rehearsals run in processes of their own, on the same GPU)
                 out["secondary"]["rehearsal_world8"] = rehearsal_world8(out["value"])
@@ -839,6 +1045,11 @@ def main():
                 print(json.dumps({"error": "TRPO update differs from the reference beyond 1e-5",
                                   "check": out["secondary"]["trpo_configs2"]["check_vs_reference"]}), file=sys.stderr, flush=True)
                 failed = True
+            for fs_name, fs_res in out["secondary"].get("full_size", {}).items():
+                if fs_res.get("failed"):
+                    print(json.dumps({"error": "%s at full size: the batch's gradient / product / update is not the sum over its shards" % fs_name,
+                                      "check": {k: fs_res[k] for k in ("shard_sum_vs_full", "update_vs_shard_composition")}}), file=sys.stderr, flush=True)
+                    failed = True
             for lw_name, lw_res in out["secondary"]["roofline_lw"].items():
                 if lw_res.get("check_vs_reference", {}).get("failed"):
                     print(json.dumps({"error": "%s: the shard's update differs from the reference beyond its bars" % lw_name,

@@ -108,12 +108,16 @@ class DeviceBlock:
             y = ingest.upload(self.handle, np.concatenate([np.asarray(p["returns"], np.float64) for p in self.paths]))
         return y
 
-    def gram(self, kind, y):
+    def gram_dev(self, kind, y):
+        """[A y]^T [A y] as an (F + 1) x (F + 1) fp64 device tensor (enqueued on the current stream, nothing waited for)"""
         F = self.lib.mjx_bl_num_features(kind, self.n)
         yt = y if hasattr(y, "data_ptr") else ingest.upload(self.handle, y, np.float64)
         G = self.torch.empty((F + 1, F + 1), dtype=self.torch.float64, device=self.dev)
         check(self.lib.mjx_bl_gram(kind, ptr(self.obs), ptr(self.tpos), ptr(yt), self.N, self.n, ptr(G), self.st()))
-        return ingest.download(self.handle, G)
+        return G
+
+    def gram(self, kind, y):
+        return ingest.download(self.handle, self.gram_dev(kind, y))
 
     def predict_linear_dev(self, kind, coef):
         ct = self.torch.from_numpy(np.ascontiguousarray(coef, dtype=np.float64)).to(self.dev)

@@ -25,6 +25,24 @@ def _few_blas_threads(limit=8):
         return contextlib.nullcontext()
 
 
+class PendingRidgeFit:
+    """One ridge fit in flight (_RidgeBaseline.fit_async): the normal equations are being accumulated on the GPU / the F x F system is
+    being solved on a helper thread.  ``result()`` waits (once), installs the coefficients and -> (error_before, error_after) when
+    errors were asked for, else None.  Same surface as baselines.mlp_baseline.PendingFit (train_step's pending log entries)."""
+
+    def __init__(self, baseline):
+        self.baseline, self.done, self.value, self.hooks, self.device_ms = baseline, False, None, [], None
+        self.future = self.error = self.coeffs = None
+
+    def finished(self):
+        return self.done or self.future is None or self.future.done()
+
+    def result(self):
+        if not self.done:
+            self.baseline._settle()
+        return self.value
+
+
 class _RidgeBaseline:
     _kind = None
 
@@ -33,6 +51,112 @@ class _RidgeBaseline:
         self.inp = inp
         self._reg_coeff = reg_coeff
         self._coeffs = None
+
+    # ---- whoever reads (or replaces) the coefficients -- predict, the next fit, pickle / deepcopy (train_agent.py:83,102,129-131) --
+    #      sees the finished fit
+    def __getattribute__(self, name):
+        if name == "_coeffs":
+            d = object.__getattribute__(self, "__dict__")
+            if d.get("_pending") is not None:
+                object.__getattribute__(self, "_settle")()
+        return object.__getattribute__(self, name)
+
+    def __setattr__(self, name, value):
+        if name == "_coeffs" and self.__dict__.get("_pending") is not None:
+            self._settle()
+        object.__setattr__(self, name, value)
+
+    def __getstate__(self):
+        self._settle()
+        state = dict(self.__dict__)
+        state.pop("_pending", None)
+        state.pop("_pins", None)
+        return state
+
+    def _settle(self):
+        pend = self.__dict__.get("_pending")
+        if pend is None:
+            return
+        self.__dict__["_pending"] = None
+        pend.future.result()                              # (work() catches its own exceptions: pend.error)
+        pend.done = True
+        hooks, pend.hooks = pend.hooks, []
+        if pend.error is not None:
+            if pend.value is None and pend.want_errors:
+                pend.value = (float("nan"), float("nan"))
+            for hook in hooks:
+                hook(pend.value, pend.device_ms or 0.0)
+            raise pend.error
+        self.__dict__["_coeffs"] = pend.coeffs
+        for hook in hooks:
+            hook(pend.value, pend.device_ms)
+
+    def fit_async(self, paths, return_errors=False, predrawn=None):
+        """quadratic_baseline.py:44-69 / linear_baseline.py:37-60 OFF the caller's critical path (r06): the fitted baseline is not
+        read before the NEXT iteration's compute_advantages, and sampling comes first (batch_reinforce.py:78-112).  The Gram
+        kernel (and, for the logged errors, the prediction with the old coefficients) is enqueued on the caller's stream, their
+        results land in page-locked memory, and a helper thread waits for them, solves the F x F system (LAPACK holds no
+        interpreter lock) and -- when errors were asked for -- evaluates the new coefficients on a side stream: the same calls, the
+        same bits as fit().  -> PendingRidgeFit.  With torch.distributed initialised (the normal equations are summed over the
+        ranks through the host) or MJX_ASYNC_FIT=0 the fit runs in place and the handle comes back settled."""
+        import os
+        self._settle()
+        pend = PendingRidgeFit(self)
+        pend.want_errors = bool(return_errors)
+        if not paths or ranks.group() is not None or os.environ.get("MJX_ASYNC_FIT", "1") == "0":
+            pend.value = self.fit(paths, return_errors)
+            pend.done, pend.coeffs, pend.device_ms = True, self.__dict__["_coeffs"], 0.0
+            return pend
+        blk = DeviceBlock(paths, self.inp)
+        torch, dev = blk.torch, blk.dev
+        main = torch.cuda.current_stream(dev)
+        coef_old = self.__dict__["_coeffs"]
+        y = blk.returns_dev()
+        F1 = num_features(self._kind, self.n) + 1
+        start_ev, end_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start_ev.record(main)
+        G = blk.gram_dev(self._kind, y)
+        Gpin = self._pinned(torch, "gram", F1 * F1).view(F1, F1)
+        Gpin.copy_(G, non_blocking=True)
+        pred_pin = None
+        if return_errors and coef_old is not None:
+            pred_old = blk.predict_linear_dev(self._kind, coef_old)
+            pred_pin = self._pinned(torch, "pred", blk.N)
+            pred_pin.copy_(pred_old, non_blocking=True)
+        end_ev.record(main)
+        side = _side_stream(torch, dev)
+
+        def work():
+            try:
+                end_ev.synchronize()
+                pend.device_ms = float(start_ev.elapsed_time(end_ev))
+                Gaug = Gpin.numpy()
+                F = F1 - 1
+                pend.coeffs = self._solve(Gaug[:F, :F].copy(), Gaug[:F, F].copy())
+                if return_errors:
+                    returns = np.concatenate([path["returns"] for path in paths])
+                    den = np.sum(returns ** 2)
+                    before = pred_pin.numpy() if pred_pin is not None else np.zeros(returns.shape)
+                    with torch.cuda.device(dev), torch.cuda.stream(side):
+                        after = blk.predict_linear(self._kind, pend.coeffs)          # (synchronises the side stream only)
+                    pend.value = (np.sum((returns - before) ** 2) / den, np.sum((returns - after) ** 2) / den)
+            except Exception as e:                     # delivered by _settle
+                pend.error = e
+            finally:
+                pend.keep = None
+        pend.keep = (blk, y, G, Gpin, pred_pin, paths)
+        pend.future = _fit_worker().submit(work)          # ONE long-lived helper thread: libmjx keeps per-thread feature tables
+        self.__dict__["_pending"] = pend
+        return pend
+
+    def _pinned(self, torch, name, count):
+        """page-locked fp64 result blocks, kept per baseline (allocating one costs more than the copy it receives); a fit in
+        flight is settled before the next one starts, so a block is never handed out twice at a time"""
+        pins = self.__dict__.setdefault("_pins", {})
+        ent = pins.get(name)
+        if ent is None or ent.numel() < count:
+            ent = pins[name] = torch.empty(max(int(count), 1), dtype=torch.float64, pin_memory=True)
+        return ent[:count]
 
     def _solve(self, G, b):
         """quadratic_baseline.py:54-63 / linear_baseline.py:45-54.  The F x F solve (F <= a few hundred) is a job for a
@@ -119,6 +243,24 @@ class _RidgeBaseline:
         if self._coeffs is None:
             return np.zeros(len(path["rewards"]))
         return self.predict_batch([path], shared=False)
+
+
+_SIDE = {}
+_WORKER = []
+
+
+def _fit_worker():
+    if not _WORKER:
+        from concurrent.futures import ThreadPoolExecutor
+        _WORKER.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix="mjx-ridge-fit"))
+    return _WORKER[0]
+
+
+def _side_stream(torch, dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
 class QuadraticBaseline(_RidgeBaseline):

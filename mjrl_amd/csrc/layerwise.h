@@ -979,7 +979,7 @@ struct LayerwiseWS {
   // MJX_LW_TILES (A/B measurements): 0 = the round-1 shapes only (128 x 128 in 512-thread workgroups / 128 x 32),
   // 1 = 128 x 256 tiles (one workgroup per CU), 2 = 128 x 128 tiles in 256-thread workgroups, two per CU
   static int tile_mode() {
-    static const int m = [] { const char* e = getenv("MJX_LW_TILES"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
+    const int m = [] { const char* e = getenv("MJX_LW_TILES"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
     return m;
   }
   static bool wide_tiles() { return tile_mode() == 1; }
@@ -999,7 +999,7 @@ struct LayerwiseWS {
     lw_set_dyn_lds((const void*)kern, (int)gemm_lds_bytes<BM, BN>());      // double-buffered operand tiles: dynamic LDS beyond the 64 KB default
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
     constexpr size_t lds = gemm_lds_bytes<BM, BN>();
-    static const bool fast_on = [] { const char* e = getenv("MJX_LW_FAST"); return !(e && e[0] == '0'); }();   // MJX_LW_FAST=0: A/B
+    const bool fast_on = [] { const char* e = getenv("MJX_LW_FAST"); return !(e && e[0] == '0'); }();   // MJX_LW_FAST=0: A/B
     if (g.fast != (fast_on ? 1 : 0)) { GemmArgs h = g; h.fast = fast_on ? 1 : 0; launch_tile<BM, BN, NTH>(h, splits, st); return; }
 #ifdef MJX_PHASE_CLOCK
     if (lw_clk_buf() && !g.clk && lw_clk_slot() < LW_CLK_SLOTS && (int64_t)grid.x * grid.y <= 16384) {
@@ -1011,7 +1011,7 @@ struct LayerwiseWS {
 #ifdef MJX_GEMM_EXPERIMENTS
     // timing experiment (results are WRONG): every row of a K-contiguous A operand reads the same 128-byte line, so the
     // k-loop's activation stream comes from cache -- separates memory stalls from issue / LDS limits
-    static const bool alias_a = [] { const char* e = getenv("MJX_LW_DEBUG_ALIAS_A"); return e && e[0] == '1'; }();
+    const bool alias_a = [] { const char* e = getenv("MJX_LW_DEBUG_ALIAS_A"); return e && e[0] == '1'; }();
     if (alias_a) {
       GemmArgs h = g;
       for (int p = 0; p < h.npairs; ++p) if (h.a_ks[p] == 1) h.a_rs[p] = 0;
@@ -1052,20 +1052,20 @@ struct LayerwiseWS {
   // 1 024 samples (up to 8 192 workgroups, 1 GB of partial slabs at that size): 7.2e-6, and the Fisher-vector product is 1 %
   // FASTER (19.27 -> 19.01 ms, tools/probe_chain_error.py: more, shorter workgroups fill the last round better).
   static int wgrad_chain() {
-    static const int v = [] { const char* e = getenv("MJX_LW_CHAIN"); const int x = e ? atoi(e) : 0; return x >= 256 ? x : 1024; }();
+    const int v = [] { const char* e = getenv("MJX_LW_CHAIN"); const int x = e ? atoi(e) : 0; return x >= 256 ? x : 1024; }();
     return v;
   }
   static int wgrad_wg_cap() {
-    static const int v = [] { const char* e = getenv("MJX_LW_WG_CAP"); const int x = e ? atoi(e) : 0; return x >= 64 ? x : 8192; }();
+    const int v = [] { const char* e = getenv("MJX_LW_WG_CAP"); const int x = e ? atoi(e) : 0; return x >= 64 ? x : 8192; }();
     return v;
   }
   static bool thin_wgrad(int ncols) {
-    static const bool on = [] { const char* e = getenv("MJX_LW_THIN"); return !(e && e[0] == '0'); }();
+    const bool on = [] { const char* e = getenv("MJX_LW_THIN"); return !(e && e[0] == '0'); }();
     return on && ncols > 32 && ncols <= 128 && tile_mode() == 1;
   }
   static int pick_splits(int64_t N, int row_tiles, int ncols, int cap) {
     const int ncu = lw_ncu();
-    static const bool on = [] { const char* e = getenv("MJX_LW_SPLITS"); return !(e && e[0] == '0'); }();
+    const bool on = [] { const char* e = getenv("MJX_LW_SPLITS"); return !(e && e[0] == '0'); }();
     if (cap < 4 || !on) return cap;
     int cb = 1;                                        // column blocks of the main launch (launch_gemm)
     if (ncols > 32) {
@@ -1086,7 +1086,7 @@ struct LayerwiseWS {
   // Sample-major products in their steady-state shape go to the persistent kernel (lw_gemm_p.h).
   // MJX_LW_PERSIST=0 keeps everything on the general kernel.
   static int persistent_lb(const GemmArgs& g, int splits) {        // -> 0 / 1: the B layout it can run with, -1: not eligible
-    static const bool on = [] { const char* e = getenv("MJX_LW_PERSIST"); return !(e && e[0] == '0'); }();
+    const bool on = [] { const char* e = getenv("MJX_LW_PERSIST"); return !(e && e[0] == '0'); }();
     if (on && lw_ticket_ring() == nullptr) return -1;               // no ticket counters on this device: the general kernel serves the product
     if (!on || splits != 1 || tile_mode() != 1 || g.M < 2 * GP_BM || g.N < GP_BN || (g.N % GP_BN) != 0) return -1;
     if ((g.M % GP_BM) != 0 && !g.rows_padded) return -1;
@@ -1150,7 +1150,7 @@ struct LayerwiseWS {
     if (splits > 1 && thin_wgrad(g.N)) {
       // (r04) up to 64 columns -- the 512 x 39 first-layer gradient of configs[4], stored 64 wide -- a 128 x 64 tile: the 128-column
       // tile spent half its matrix work and half its B-operand LDS traffic on padding (MJX_LW_THIN64=0: the r03 shape)
-      static const bool t64 = [] { const char* e = getenv("MJX_LW_THIN64"); return !(e && e[0] == '0'); }();
+      const bool t64 = [] { const char* e = getenv("MJX_LW_THIN64"); return !(e && e[0] == '0'); }();
       if (t64 && g.N <= 64) { launch_tile<128, 64, 256>(g, splits, st); return; }
       launch_tile<128, 128, 256>(g, splits, st);
       return;
@@ -1211,7 +1211,7 @@ struct LayerwiseWS {
   int backward(const float* theta, int64_t N, float* grad, hipStream_t st, int l_start = -1, const float* delta0 = nullptr) {
     const float* delta = delta0 ? delta0 : d3;
     bool bias_done = delta0 != nullptr;
-    static const bool overlap_on = [] { const char* e = getenv("MJX_LW_OVERLAP"); return e && e[0] == '1'; }();
+    const bool overlap_on = [] { const char* e = getenv("MJX_LW_OVERLAP"); return e && e[0] == '1'; }();
     const bool overlap = overlap_on && N >= 65536;
     if (overlap && !side) {
       if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_a, hipEventDisableTiming) != hipSuccess ||
@@ -1370,7 +1370,7 @@ struct LayerwiseWS {
   // (the pass reads theta / v with 16-byte loads: a direction that is a view at an odd offset of a larger tensor takes the
   //  generic chain instead of failing -- the fast path is an optimisation, not a precondition)
   bool head_fused(const float* theta, const float* v) const {
-    static const bool on = [] { const char* e = getenv("MJX_LW_HEAD"); return !(e && e[0] == '0'); }();
+    const bool on = [] { const char* e = getenv("MJX_LW_HEAD"); return !(e && e[0] == '0'); }();
     if (!on || nL() < 2 || m > 32) return false;
     if ((((uintptr_t)theta | (uintptr_t)v) & 15) != 0) return false;
     const int hl = sizes[nL() - 1];
@@ -1396,16 +1396,15 @@ struct LayerwiseWS {
     auto launch8 = [&](auto ch) {             // 256 / 512 units: the eight-wave build (two waves per SIMD)
       constexpr int CH = decltype(ch)::value;
       // the delta product's contraction over the actions in ceil(m / 2) steps: 9 (m <= 18: Humanoid's 17), 12 (<= 24), else all 16
-      static const bool trim = [] { const char* e = getenv("MJX_LW_HEAD_KTRIM"); return !(e && e[0] == '0'); }();
+      const bool trim = [] { const char* e = getenv("MJX_LW_HEAD_KTRIM"); return !(e && e[0] == '0'); }();
       void (*const kern)(HeadArgs) = !trim ? k_lw_head8<CH, 16> : m <= 18 ? k_lw_head8<CH, 9> : m <= 24 ? k_lw_head8<CH, 12> : k_lw_head8<CH, 16>;
       lw_set_dyn_lds((const void*)kern, (int)lw_head8_lds_bytes());
       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lw_head8_lds_bytes(), st, a);
     };
-    static const bool eight = [] { const char* e = getenv("MJX_LW_HEAD8"); return !(e && e[0] == '0'); }();
-    // (k_lw_head8 addresses H / T with 32-bit byte offsets from their base: the padded blocks must stay below 4 GB)
-    const bool off32 = ((uint64_t)((N + 127) / 128) * 128u * (uint64_t)hl * 4u) < (1ull << 32);
-    if (eight && off32 && hl == 256) launch8(std::integral_constant<int, 1>{});
-    else if (eight && off32 && hl == 512) launch8(std::integral_constant<int, 2>{});
+    const bool eight = [] { const char* e = getenv("MJX_LW_HEAD8"); return !(e && e[0] == '0'); }();
+    // (r06: k_lw_head8 re-bases its buffer resources per row tile -- no 4 GB limit on the blocks any more)
+    if (eight && hl == 256) launch8(std::integral_constant<int, 1>{});
+    else if (eight && hl == 512) launch8(std::integral_constant<int, 2>{});
     else switch (hl / 128) {
       case 1: launch(std::integral_constant<int, 1>{}); break;
       case 2: launch(std::integral_constant<int, 2>{}); break;

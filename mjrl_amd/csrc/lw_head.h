@@ -279,9 +279,13 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
   // are bounded at m rows, reads of the rows m..31 return zero by the hardware's range check (no clamp, no select).
   // (The first version formed a 64-bit address and two selects per load: 1 092 vector-ALU instructions per 144 MFMAs in the
   //  tile loop, tools/isa_mix.py -- vector-ALU time that fp32 MFMAs do not hide.)
+  // r06: the H / T resources are re-based at the row tile they serve (64-bit scalar arithmetic, four SGPRs each -- free next to
+  // the matrix pipe), so every offset below is relative to the tile and fits 32 bits whatever the block size: BASELINE configs[4]
+  // at its full 8M rows (16 GB per block) takes this kernel too (before: blocks >= 4 GB fell back to the four-wave k_lw_head).
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)a.H, 0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)a.T, 0, -1, 0x00020000);
+  auto rsrc_at = [&](const float* base, int64_t r0) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + r0 * (int64_t)h), 0, -1, 0x00020000);
+  };
   const int wbytes = m * h * 4;
   const __amdgpu_buffer_rsrc_t rV3 = __builtin_amdgcn_make_buffer_rsrc((void*)a.V3, 0, wbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rW3 = __builtin_amdgcn_make_buffer_rsrc((void*)a.W3, 0, wbytes, 0x00020000);
@@ -293,7 +297,8 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
   };
   // per k-tile: A 2 pairs x 64 rows x 8 float4 = 1024 -> two per thread; B 2 pairs x 32 rows x 8 = 512 -> one per thread
   auto gload = [&](f32x4 (&ra)[2], f32x4& rbq, int64_t r0, int kt) {
-    const uint32_t so = (uint32_t)(((uint64_t)r0 * (uint64_t)h + (uint64_t)(32 * kt)) * 4u);       // (N128 x h x 4 < 4 GB: checked on the host)
+    const __amdgpu_buffer_rsrc_t rH = rsrc_at(a.H, r0), rT = rsrc_at((const float*)a.T, r0);
+    const uint32_t so = (uint32_t)(32 * kt) * 4u;
     ra[0] = ld128(rH, voA, so);
     ra[1] = ld128(rT, voA, so);
     const uint32_t sw = (uint32_t)(32 * kt) * 4u;
@@ -365,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
     if (tile + gridDim.x < ntile) { gload(raA, rbA, (tile + gridDim.x) * LH_R, 0); gload(raB, rbB, (tile + gridDim.x) * LH_R, 1); }
     auto phase2 = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
+      const __amdgpu_buffer_rsrc_t rH = rsrc_at(a.H, row0), rT = rsrc_at((const float*)a.T, row0);
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         const int cb = 32 * (8 * i + wv);
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void k_lw_head8(HeadArgs a) {
         for (int rb = 0; rb < 2; ++rb) {
           __builtin_amdgcn_sched_barrier(0);
           float* __restrict__ Db = a.T + (row0 + 32 * rb) * (int64_t)h + cb;
-          const uint32_t sob = (uint32_t)((((uint64_t)row0 + (uint64_t)(32 * rb)) * (uint64_t)h + (uint64_t)cb) * 4u);
+          const uint32_t sob = (uint32_t)((32 * rb) * h + cb) * 4u;                     // (relative to the tile's resources)
           float y[16];
           if (FULL) {
 #pragma unroll

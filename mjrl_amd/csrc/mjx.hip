@@ -337,7 +337,12 @@ int mjx_bind_batch(mjx_ctx* c, const float* obs, const float* act, const float* 
   c->ocache_valid = false;
   c->ximg_ok = false;
   c->lw.invalidate();
-  if (!c->fused) { int rc = c->lw.reserve(N_local); if (rc) return fail(rc, "layer-wise workspace allocation failed"); }
+  if (!c->fused) {
+    // the layer-wise launches put one 128-row tile per grid row: gridDim.y <= 65 535 -> 8 388 480 rows per context (BASELINE
+    // configs[4] at its full 8M + demonstrations fits; beyond that, shard the batch -- element and byte offsets are 64-bit throughout)
+    if (N_local > (int64_t)65535 * 128) return fail(MJX_ERR_ARG, "layer-wise path: at most %lld rows per context (got %lld): bind the batch in shards", (long long)65535 * 128, (long long)N_local);
+    int rc = c->lw.reserve(N_local); if (rc) return fail(rc, "layer-wise workspace allocation failed");
+  }
   return MJX_OK;
 }
 
@@ -803,7 +808,7 @@ static int fvp_impl(mjx_ctx* c, const float* v, float* out, void* stream, const 
   // alternate sweep direction: K1 filled the cache front to back, so the first product of a solve starts at the back, the
   // next at the front, ... -- the lines the previous sweep touched last are the ones most likely still held by the
   // memory-side cache (the 592 MB image does not fit; a one-directional walk would evict every line before its reuse)
-  static const bool sweep_on = [] { const char* e = getenv("MJX_FVP_SWEEP"); return !(e && e[0] == '0'); }();
+  const bool sweep_on = [] { const char* e = getenv("MJX_FVP_SWEEP"); return !(e && e[0] == '0'); }();
   a.reverse = (a.hcache && sweep_on) ? (int)((c->fvp_seq++ & 1u) ^ 1u) : 0;
   if (int rc = dispatch_fused(c, MODE_FVP, a, st)) return rc;
   if (prof) { HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], st)); c->prof_used += 2; }
@@ -835,7 +840,7 @@ static int eval_impl(mjx_ctx* c, double* scal_out, void* stream, const PeerPush*
   if (c->ocache_valid && c->N_local <= c->ocache_rows) { a.ocache = c->ocache; a.snap = c->snap; }
   // K1's normalised-observation image of this batch (same rows, same observations; the kernel checks the input transform
   // against the snapshot before it trusts it) spares K3 the staging and normalisation of the raw observations
-  static const bool ximg_on = [] { const char* e = getenv("MJX_K3_XIMG"); return !(e && e[0] == '0'); }();
+  const bool ximg_on = [] { const char* e = getenv("MJX_K3_XIMG"); return !(e && e[0] == '0'); }();
   if (ximg_on && a.ocache && c->ximg_ok && c->hcache && c->N_local <= c->ximg_rows && c->obs == c->hcache_obs) a.hcache = c->hcache;
   if (int rc = dispatch_fused(c, MODE_EVAL, a, st)) return rc;
   hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, c->spartials, 2 * c->grid, scal_out, pp ? *pp : PeerPush{});

@@ -18,7 +18,16 @@ bl = QuadraticBaseline(spec) if kind == "quadratic" else MLPBaseline(spec, reg_c
 agent = NPG(None, pol, bl, normalized_step_size=0.05)
 
 def make():
-    return [dict(observations=rng.randn(1000, 17), actions=rng.randn(1000, 6), rewards=rng.randn(1000), terminated=False) for _ in range(1000)]
+    """STREAM=1 (r06): the batch is handed to utils/ingest.StreamedBatch in 20 chunks as it is produced, like mjrl_amd.samplers does"""
+    paths = [dict(observations=rng.randn(1000, 17), actions=rng.randn(1000, 6), rewards=rng.randn(1000), terminated=False) for _ in range(1000)]
+    if os.environ.get("STREAM") == "1":
+        _ingest.drop_shared_batch()
+        sb = _ingest.StreamedBatch.for_current_device()
+        sb.begin(len(paths))
+        for lo in range(0, len(paths), 50):
+            sb.add(paths[lo:lo + 50], 1000)
+        assert sb.finish(paths), sb.why
+    return paths
 
 def iteration(paths, ts):
     from mjrl_amd.utils import ingest
@@ -27,19 +36,19 @@ def iteration(paths, ts):
         process_samples.compute_returns(paths, 0.995); torch.cuda.synchronize(); t1 = time.perf_counter()
         process_samples.compute_advantages(paths, bl, 0.995, 0.97); torch.cuda.synchronize(); t2 = time.perf_counter()
         agent.train_from_paths(paths); torch.cuda.synchronize(); t3 = time.perf_counter()
-        bl.fit(paths); torch.cuda.synchronize(); t4 = time.perf_counter()
+        (bl.fit_async(paths) if os.environ.get('ASYNC_FIT', '1') == '1' and hasattr(bl, 'fit_async') else bl.fit(paths)); t4 = time.perf_counter()
     ingest.drop_shared_batch()
     ts.append([round(1e3 * x, 2) for x in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)])
 
 ts = []
 for _ in range(3):
     iteration(make(), ts)
-batches = [make() for _ in range(5)]
 pr = cProfile.Profile()
-pr.enable()
-for p in batches:
+for _ in range(5):
+    p = make()                     # (made right before its iteration: a streamed batch is the one registered batch)
+    pr.enable()
     iteration(p, ts)
-pr.disable()
+    pr.disable()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
 print(s.getvalue()[:9000])

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from mjrl_amd.engine import UpdateEngine
 import _synth as synth
-n, m, hid, N = 17, 6, (64, 64), 1000000
+n, m, hid, N = 17, 6, (64, 64), int(os.environ.get("N", "1000000"))
 rng = np.random.RandomState(0)
 th = synth.perturbed_params(synth.init_params(n, m, hid))
 ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
