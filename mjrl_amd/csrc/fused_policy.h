@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include <type_traits>
+#include <vector>
 
 namespace mjx {
 
@@ -55,6 +56,8 @@ struct FusedArgs {
   const float* snap;     // [d + 2n + 2m] parameters and transforms the ocache was computed with
   float* snap_out;       // MODE_VPG: the kernel writes that snapshot (thetaB | trB) while it fills the ocache
   int n, m;
+  int raw_dr;            // > 0: the gradient partial of a workgroup is written in ACCUMULATOR order (RawSlab<..>::DR floats per
+                         // workgroup, see RawSlab below); k_reduce_partials4 maps the columns to the flat order (perm)
 };
 
 #ifdef MJX_PHASE_CLOCK
@@ -283,6 +286,57 @@ struct FlatOff {
   int W1, b1, W2, b2, W3, b3, S, d;
   __host__ __device__ FlatOff(int n, int m, int h1, int h2) {
     W1 = 0; b1 = W1 + h1 * n; W2 = b1 + h1; b2 = W2 + h2 * h1; W3 = b2 + h2; b3 = W3 + m * h2; S = b3 + m; d = S + m;
+  }
+};
+
+// The gradient partial of a workgroup in ACCUMULATOR order (r06).  The kernels keep the weight gradients in MFMA accumulator
+// layout; writing a workgroup's partial in the flat parameter order cost every launch ~8 400 cycles (4 us: per-element index
+// arithmetic with the runtime observation width, scattered LDS writes) -- 4 % of a 1M-sample product, 8 % of a 125 k-sample one
+// (one rank of eight).  Now every wave drops register r of accumulator X at slot [X][r][lane] of its LDS copy (one ds_write with
+// an immediate offset), the four copies are added as they lie, and the COLUMN -> flat index map (a table made once per context
+// on the host: perm[], -1 for the padding slots) is applied where each column's 256 partials have been summed
+// (k_reduce_partials4).  Same additions in the same order: the same bits as the flat-order epilogue (MJX_RAW_SLAB=0).
+template <int H1, int H2, int NT1, int MP, int NPC>
+struct RawSlab {
+  static constexpr int MT1 = H1 / 32, MT2 = H2 / 32, RA = MP / 2;
+  static constexpr int QPI3 = 16 / (MP / 4), UPI3 = 4 * QPI3, NT3 = H2 / UPI3;
+  static constexpr int NFQ = NPC ? NPC / 4 : 1;
+  static constexpr int oW2 = 0, nW2 = MT2 * MT1 * 16 * 64;                         // [mt][nt][r][lane]
+  static constexpr int oW1 = oW2 + nW2, nW1 = NPC ? MT1 * NFQ * 4 * 32 : MT1 * NT1 * 16 * 64;   // [mt][fq][r][lane < 32] | [mt][nt][r][lane]
+  static constexpr int oW3 = oW1 + nW1, nW3 = NT3 * 4 * 64;                        // [nt][r][lane]
+  static constexpr int oB2 = oW3 + nW3, nB2 = MT2 * 32;                            // [nt][j]
+  static constexpr int oB3 = oB2 + nB2;                                            // [r][hi]
+  static constexpr int oS = oB3 + 2 * RA;                                          // [r][hi]
+  static constexpr int DR = ((oS + 2 * RA) + 3) & ~3;
+  static int unit(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+  // perm[slot] = flat parameter index (mirrors the flat-order epilogue of k_fused) or -1; -> true when every flat index is hit exactly once
+  static bool fill_perm(int* perm, int n, int m) {
+    const FlatOff fo(n, m, H1, H2);
+    for (int i = 0; i < DR; ++i) perm[i] = -1;
+    auto w1 = [&](int u, int f) { return f < n ? fo.W1 + u * n + f : f == n ? fo.b1 + u : -1; };
+    for (int mt = 0; mt < MT2; ++mt) for (int nt = 0; nt < MT1; ++nt) for (int r = 0; r < 16; ++r) for (int l = 0; l < 64; ++l)
+      perm[oW2 + ((mt * MT1 + nt) * 16 + r) * 64 + l] = fo.W2 + (32 * mt + unit(r, l >> 5)) * H1 + 32 * nt + (l & 31);
+    if (NPC) {
+      for (int mt = 0; mt < MT1; ++mt) for (int fq = 0; fq < NFQ; ++fq) for (int r = 0; r < 4; ++r) for (int l = 0; l < 32; ++l)
+        perm[oW1 + ((mt * NFQ + fq) * 4 + r) * 32 + l] = w1(32 * mt + 4 * ((l >> 2) & 7) + r, 4 * fq + (l & 3));
+    } else {
+      for (int mt = 0; mt < MT1; ++mt) for (int nt = 0; nt < NT1; ++nt) for (int r = 0; r < 16; ++r) for (int l = 0; l < 64; ++l)
+        perm[oW1 + ((mt * NT1 + nt) * 16 + r) * 64 + l] = w1(32 * mt + unit(r, l >> 5), 32 * nt + (l & 31));
+    }
+    for (int nt = 0; nt < NT3; ++nt) for (int r = 0; r < 4; ++r) for (int l = 0; l < 64; ++l) {
+      const int blk = l >> 2, a = 4 * (blk / QPI3) + r, u = 4 * (blk % QPI3) + (l & 3) + UPI3 * nt;
+      perm[oW3 + (nt * 4 + r) * 64 + l] = a < m ? fo.W3 + a * H2 + u : -1;
+    }
+    for (int nt = 0; nt < MT2; ++nt) for (int jj = 0; jj < 32; ++jj) perm[oB2 + nt * 32 + jj] = fo.b2 + 32 * nt + jj;
+    for (int r = 0; r < RA; ++r) for (int hi = 0; hi < 2; ++hi) {
+      const int a = unit(r, hi);
+      perm[oB3 + 2 * r + hi] = a < m ? fo.b3 + a : -1;
+      perm[oS + 2 * r + hi] = a < m ? fo.S + a : -1;
+    }
+    std::vector<int> hits(fo.d, 0);
+    for (int i = 0; i < DR; ++i) if (perm[i] >= 0) { if (perm[i] >= fo.d) return false; ++hits[perm[i]]; }
+    for (int i = 0; i < fo.d; ++i) if (hits[i] != 1) return false;
+    return true;
   }
 };
 
@@ -1705,6 +1759,60 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         if (MODE == MODE_VPG) gls[a] += __shfl_xor(gls[a], off);
         sb3r[a] += __shfl_xor(sb3r[a], off);
       }
+    if (A.raw_dr > 0) {
+      // accumulator-order partial (RawSlab above): one ds_write per register at [X][r][lane], immediates only
+      using RS = RawSlab<H1, H2, NT1, MP, NPC>;
+      float* red = lds;                           // 4 * DR floats <= TOTAL (checked on host)
+      float* mine = red + wave * RS::DR + lane;
+#pragma unroll
+      for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < MT1; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mine[RS::oW2 + ((mt * MT1 + nt) * 16 + r) * 64] = gW2[mt][nt][r];
+      if constexpr (NPC != 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+          for (int fq = 0; fq < NFQ; ++fq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = half_sum(gW1q[mt][fq][r]);
+              if (hi == 0) mine[RS::oW1 + ((mt * NFQ + fq) * 4 + r) * 32] = v;
+            }
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[RS::oW1 + ((mt * NT1 + nt) * 16 + r) * 64] = gW1[mt][nt][r];
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT3; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[RS::oW3 + (nt * 4 + r) * 64] = XCACHED ? gW3[nt][r] + gW3b[XCACHED ? nt : 0][r] : gW3[nt][r];
+#pragma unroll
+      for (int nt = 0; nt < MT2; ++nt) {
+        const float v = half_sum(sb2[nt]);
+        if (hi == 0) mine[RS::oB2 + nt * 32] = v;
+      }
+      if (j == 0) {
+        float* w0 = red + wave * RS::DR;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+          w0[RS::oB3 + 2 * r + hi] = sb3r[r];
+          w0[RS::oS + 2 * r + hi] = (MODE == MODE_VPG) ? gls[r] : 0.f;
+        }
+      }
+      if (lane < RS::DR - (RS::oS + 2 * RA)) red[wave * RS::DR + RS::oS + 2 * RA + lane] = 0.f;      // (the alignment pad)
+      __syncthreads();
+      float* outp = A.partials + (size_t)blockIdx.x * RS::DR;
+      const f32x4* r4 = (const f32x4*)red;
+      constexpr int d4 = RS::DR >> 2;
+      for (int idx = tid; idx < d4; idx += 256)
+        ((f32x4*)outp)[idx] = (r4[idx] + r4[d4 + idx]) + (r4[2 * d4 + idx] + r4[3 * d4 + idx]);
+    } else {
     // each wave drops its partial gradient into its own LDS region [wave][d], then the
     // workgroup sums the four copies.  (weights in LDS are dead by now)
     float* red = lds;                             // 4 * d floats <= TOTAL (checked on host)
@@ -1776,6 +1884,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       for (int idx = tid; idx < fo.d; idx += 256)
         outp[idx] = (red[idx] + red[fo.d + idx]) + (red[2 * fo.d + idx] + red[3 * fo.d + idx]);
     }
+    }
   }
   MJX_GSTAMP(20);
   if (A.clk && blockIdx.x == 0 && threadIdx.x == 0) { A.clk[2] = (long long)__builtin_readcyclecounter(); A.clk[3] = (long long)__builtin_amdgcn_s_memrealtime(); }
@@ -1788,7 +1897,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       s_cnt += __shfl_xor(s_cnt, off);
     }
     __syncthreads();
-    double* sred = (double*)(lds + (EV2 ? 0 : 4 * fo.d + 4));     // (EV2: the weight slots are dead by now)
+    double* sred = (double*)(lds + (EV2 ? 0 : 4 * (A.raw_dr > fo.d ? A.raw_dr : fo.d) + 4));     // (EV2: the weight slots are dead by now)
     sred = (double*)(((uintptr_t)sred + 7) & ~(uintptr_t)7);
     if (lane == 0) { sred[wave * 3 + 0] = s_surr; sred[wave * 3 + 1] = s_kl; sred[wave * 3 + 2] = s_cnt; }
     __syncthreads();

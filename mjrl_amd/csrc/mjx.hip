@@ -96,7 +96,8 @@ struct mjx_ctx {
   bool ocache_valid = false; int64_t ocache_rows = 0;
   int64_t rows_bound = 0;                             // rows handed to the last mjx_bind_batch
   // workspace (device)
-  float* partials = nullptr;       // [grid][d]
+  float* partials = nullptr;       // [grid][max(d, raw_dr)]
+  int raw_dr = 0; int* raw_perm = nullptr;   // fused path: workgroup partials in accumulator order + the column -> flat index table (fused_policy.h RawSlab)
   double* spartials = nullptr;     // [grid][4]
   float* ident_tr = nullptr;       // identity transforms
   float *cg_x = nullptr, *cg_r = nullptr, *cg_p = nullptr, *cg_z = nullptr, *cg_Ap = nullptr;
@@ -162,6 +163,34 @@ int launch_fused(mjx_ctx* c, int mode, const FusedArgs& a, hipStream_t st) {
 }
 
 // variant table: id -> (H1, H2, NT1, MP)
+// the compile-time feature count a shape is served with (dispatch_fused's rule): 64 x 64 x <= 8 actions with 4..7 / 8..11 / 16..19 observations
+int npc_of(int fused, int n) {
+  const int NPr = (n + 1 + 3) & ~3;
+#ifdef MJX_PHASE_CLOCK
+  return (fused == 1 && NPr == 20) ? 20 : 0;       // (the timing build: NPC = 20 or the generic instance, debug buffer or not)
+#else
+  return (fused == 1 && (NPr == 20 || NPr == 12 || NPr == 8)) ? NPr : 0;
+#endif
+}
+// -> RawSlab<...>::DR of the instance (variant id, NPC) and, with perm != nullptr, its column -> flat index table; 0: unknown instance / bad table
+int raw_slab(int fused, int npc, int n, int m, std::vector<int>* perm) {
+  auto one = [&](auto rs) -> int {
+    using RS = decltype(rs);
+    if (perm) { perm->assign(RS::DR, -1); if (!RS::fill_perm(perm->data(), n, m)) return 0; }
+    return RS::DR;
+  };
+  switch (fused) {
+    case 1: return npc == 20 ? one(RawSlab<64, 64, 1, 8, 20>{}) : npc == 12 ? one(RawSlab<64, 64, 1, 8, 12>{}) : npc == 8 ? one(RawSlab<64, 64, 1, 8, 8>{})
+                                                                                                                             : one(RawSlab<64, 64, 1, 8, 0>{});
+    case 2: return one(RawSlab<32, 32, 1, 8, 0>{});
+    case 3: return one(RawSlab<64, 64, 1, 16, 0>{});
+    case 4: return one(RawSlab<32, 32, 1, 16, 0>{});
+    case 5: return one(RawSlab<32, 32, 2, 8, 0>{});
+    case 6: return one(RawSlab<32, 32, 2, 32, 0>{});
+  }
+  return 0;
+}
+
 template <int H1, int H2, int NT1, int MP>
 bool variant_fits(int n, int m, int h1, int h2, int64_t d, size_t* bytes) {
   if (h1 != H1 || h2 != H2 || m > MP || n + 1 > 32 * NT1) return false;
@@ -223,6 +252,11 @@ FusedArgs make_args(mjx_ctx* c, const float* thetaB) {
   a.reverse = 0;
   a.hcache = nullptr; a.ocache = nullptr; a.snap = nullptr; a.snap_out = nullptr;
   a.n = c->n; a.m = c->m;
+#ifdef MJX_PHASE_CLOCK
+  a.raw_dr = c->raw_perm ? c->raw_dr : 0;
+#else
+  a.raw_dr = (c->raw_perm && !c->dbg) ? c->raw_dr : 0;      // (the debug instances may be another NPC: flat-order partials)
+#endif
   return a;
 }
 
@@ -277,7 +311,20 @@ int mjx_create(mjx_ctx** out, int device, int n, int m, const int* hidden, int n
   c->fused = pick_variant(n, m, c->hidden, d, &c->lds_bytes);
   if (const char* e = getenv("MJX_FORCE_LAYERWISE")) if (e[0] == '1') c->fused = 0;
   if (const char* e = getenv("MJX_NO_HCACHE")) if (e[0] == '1') c->use_hcache = 0;
-  HIPCHK(hipMalloc(&c->partials, (size_t)c->grid * d * sizeof(float)));
+  if (c->fused) {
+    // workgroup partials in accumulator order (RawSlab): the table is made here, once; any doubt about it (an instance this
+    // switch does not know, a table that does not hit every flat index exactly once, no room for the four copies in LDS) keeps
+    // the flat-order epilogue.  MJX_RAW_SLAB=0: A/B.
+    const char* e = getenv("MJX_RAW_SLAB");
+    std::vector<int> perm;
+    const int dr = (e && e[0] == '0') ? 0 : raw_slab(c->fused, npc_of(c->fused, n), n, m, &perm);
+    if (dr > 0 && (size_t)(4 * dr + 64) * 4 <= c->lds_bytes) {
+      HIPCHK(hipMalloc((void**)&c->raw_perm, (size_t)dr * sizeof(int)));
+      HIPCHK(hipMemcpy(c->raw_perm, perm.data(), (size_t)dr * sizeof(int), hipMemcpyHostToDevice));
+      c->raw_dr = dr;
+    }
+  }
+  HIPCHK(hipMalloc(&c->partials, (size_t)c->grid * (size_t)(c->raw_dr > d ? c->raw_dr : d) * sizeof(float)));
   HIPCHK(hipMalloc(&c->spartials, (size_t)2 * c->grid * 4 * sizeof(double)));       // (MODE_EVAL launches 2 workgroups per CU)
   HIPCHK(hipMalloc(&c->cg_x, d * 4)); HIPCHK(hipMalloc(&c->cg_r, d * 4)); HIPCHK(hipMalloc(&c->cg_p, d * 4));
   HIPCHK(hipMalloc(&c->cg_z, d * 4)); HIPCHK(hipMalloc(&c->cg_Ap, d * 4));
@@ -306,7 +353,7 @@ void mjx_destroy(mjx_ctx* c) {
   hipFree(c->hcache);
   hipFree(c->ocache);
   hipFree(c->snap);
-  hipFree(c->partials); hipFree(c->spartials); hipFree(c->ident_tr);
+  hipFree(c->partials); hipFree(c->spartials); hipFree(c->ident_tr); hipFree(c->raw_perm);
   hipFree(c->cg_x); hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_z); hipFree(c->cg_Ap); hipFree(c->ticket); hipFree(c->cg_scal);
   delete c;
 }
@@ -764,11 +811,12 @@ static int surr_vpg_impl(mjx_ctx* c, float* grad_out, double* scal_out, void* st
     }
   }
   if (int rc = dispatch_fused(c, MODE_VPG, a, st)) return rc;
-  if ((c->d & 3) == 0) {
+  if ((c->d & 3) == 0 || a.raw_dr > 0) {
     // the 4 sums are reduced by one extra workgroup of the vector reduction (r06: no launch of their own)
-    hipLaunchKernelGGL(k_reduce_partials4, dim3((c->d + 31) / 32 + 1), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
+    const int cols = a.raw_dr > 0 ? a.raw_dr : (int)c->d;
+    hipLaunchKernelGGL(k_reduce_partials4, dim3((cols + 31) / 32 + 1), dim3(256), 0, st, c->partials, c->grid, cols,
                        grad_out, (const float*)nullptr, (const float*)nullptr, c->oS, 0.f, pp ? *pp : PeerPush{},
-                       ScalTail{c->spartials, c->grid, scal_out, pp ? scal_off : -1});
+                       ScalTail{c->spartials, c->grid, scal_out, pp ? scal_off : -1}, a.raw_dr > 0 ? (const int*)c->raw_perm : (const int*)nullptr);
   } else {
     hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
                        grad_out, (const float*)nullptr, (const float*)nullptr, c->oS, 0.f);
@@ -812,10 +860,12 @@ static int fvp_impl(mjx_ctx* c, const float* v, float* out, void* stream, const 
   a.reverse = (a.hcache && sweep_on) ? (int)((c->fvp_seq++ & 1u) ^ 1u) : 0;
   if (int rc = dispatch_fused(c, MODE_FVP, a, st)) return rc;
   if (prof) { HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], st)); c->prof_used += 2; }
-  if ((c->d & 3) == 0)
-    hipLaunchKernelGGL(k_reduce_partials4, dim3((c->d + 31) / 32), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
-                       out, c->theta_new, v, c->oS, frac, pp ? *pp : PeerPush{});
-  else
+  if ((c->d & 3) == 0 || a.raw_dr > 0) {
+    const int cols = a.raw_dr > 0 ? a.raw_dr : (int)c->d;
+    hipLaunchKernelGGL(k_reduce_partials4, dim3((cols + 31) / 32), dim3(256), 0, st, c->partials, c->grid, cols,
+                       out, c->theta_new, v, c->oS, frac, pp ? *pp : PeerPush{}, ScalTail{nullptr, 0, nullptr, -1},
+                       a.raw_dr > 0 ? (const int*)c->raw_perm : (const int*)nullptr);
+  } else
     hipLaunchKernelGGL(k_reduce_partials, dim3((c->d + 15) / 16), dim3(256), 0, st, c->partials, c->grid, (int)c->d,
                        out, c->theta_new, v, c->oS, frac);
   HIPCHK(hipGetLastError());

@@ -177,7 +177,10 @@ struct ScalTail { const double* sp; int G; double* out; int peer_off; };
 __global__ __launch_bounds__(256) void k_reduce_partials4(const float* __restrict__ partials, int G, int d,
                                                            float* __restrict__ out, const float* theta,
                                                            const float* v, int oS, float frac, PeerPush pp = PeerPush{},
-                                                           ScalTail stl = ScalTail{nullptr, 0, nullptr, -1}) {
+                                                           ScalTail stl = ScalTail{nullptr, 0, nullptr, -1},
+                                                           const int* __restrict__ perm = nullptr) {
+  // perm (r06): the partials' columns are in the fused kernels' accumulator order (fused_policy.h RawSlab); column c belongs to
+  // flat index perm[c] (-1: a padding slot) -- `d` is then the slab width, and theta / v / out / the peers' slots are indexed flat
   typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ double sh[32][33];
   if (stl.sp != nullptr && blockIdx.x == gridDim.x - 1) {            // the extra workgroup: k_reduce_scalars' sums (launched with grid + 1)
@@ -206,20 +209,21 @@ __global__ __launch_bounds__(256) void k_reduce_partials4(const float* __restric
   sh[rg][4 * cq] = a0; sh[rg][4 * cq + 1] = a1; sh[rg][4 * cq + 2] = a2; sh[rg][4 * cq + 3] = a3;
   __syncthreads();
   const int cl = threadIdx.x, c = blockIdx.x * 32 + cl;
-  if (cl < 32 && c < d) {
+  const int cf = (cl < 32 && c < d) ? (perm ? perm[c] : c) : -1;
+  if (cf >= 0) {
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < 32; ++k) t += sh[k][cl];
-    if (v != nullptr && c >= oS) {
-      float s = expf(theta[c]);
+    if (v != nullptr && cf >= oS) {
+      float s = expf(theta[cf]);
       float u = s * s, e = 1e-8f;
       float den = 2.0f * u + e;
       float cc = 16.0f * u * u / (den * den) - 4.0f * u / den;
-      t = (double)(frac * cc * v[c]);
+      t = (double)(frac * cc * v[cf]);
     }
-    out[c] = (float)t;
+    out[cf] = (float)t;
     for (int q = 0; q < pp.world; ++q)                 // peer exchange: `out` is this rank's slot in its own buffer
-      if (q != pp.rank) ((float*)pp.dst[q])[c] = (float)t;
+      if (q != pp.rank) ((float*)pp.dst[q])[cf] = (float)t;
   }
   if (pp.world) peer_signal_tail(pp);
 }
