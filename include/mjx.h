@@ -175,14 +175,17 @@ int mjx_comm_allreduce(mjx_ctx* ctx, void* buf, int64_t count, int dtype, void* 
 
 /* Peer exchange: a third transport for the same rank sums, built on HIP IPC and stream memory operations instead of RCCL --
  * for the 5-23 KB vectors of this path a collective library's launch + protocol latency is most of the cost.  Every rank owns one
- * uncached device buffer [2 parities][world slots] + one arrival flag per source rank; mjx_peer_export allocates it and returns its
+ * uncached device buffer [2 parities][world slots of d floats + 4 doubles] + one arrival flag per source rank; mjx_peer_export allocates it and returns its
  * hipIpcMemHandle_t (MJX_PEER_HANDLE_BYTES bytes), the caller gathers the world's handles over any side channel (rank order) and
  * hands them to mjx_peer_connect, which maps the peers' buffers.  From then on every rank sum of mjx_comm_allreduce /
  * mjx_cg_solve / mjx_npg_update / mjx_trpo_update / mjx_dapg_update is: store the local vector into slot `rank` of EVERY rank's
  * buffer, then -- once those stores are acknowledged -- store the exchange number into this rank's flag in every peer's buffer
  * (in the CG loop the Fisher product's reduction kernel does both itself); the consuming kernel (in the loop: the CG vector
  * update) waits on the flags of its own buffer -- local memory, one polling thread per source rank -- and sums the local slots
- * in rank order.  A flag and the data it announces come from the same rank over the same path; nothing is assumed about the
+ * in rank order.  (r06: in the one-call updates on the fused kernels the gradient and K1's four sums travel in ONE exchange -- the
+ * sums at the end of the slot -- raised by the gradient's reduction kernel and consumed by the solve's first kernel; K3's sums are
+ * pushed by their own reduction kernel.  A rank without samples sends zeros through the same exchanges.)
+ * A flag and the data it announces come from the same rank over the same path; nothing is assumed about the
  * relative order of different peers' traffic.  All on the launch stream: no host synchronisation, no extra launch in the loop,
  * bit-identical results on all ranks.  The wait is bounded: a peer that has not delivered within MJX_PEER_TIMEOUT_MS
  * (environment, read by mjx_peer_export; default 5000) turns the result into NaN instead of hanging the GPU and is counted:
@@ -209,6 +212,9 @@ int mjx_peer_status(mjx_ctx* ctx, int* timeouts_out);
  *        value, zero and negative included, is applied as given -- NAN selects the normalised step)
  *        theta_out = theta_old + alpha x, log_std = max(log_std, min_log_std)   (:137-139, gaussian_mlp.py:73-75)
  *   K3   surrogate / KL sums of theta_out against theta_old                [rank sum: 4 doubles]
+ * (r06, d <= 8192: b.x, x_out and theta_out are formed by the kernel of the solve's LAST vector update; K1's and K3's sums are
+ *  reduced by the vector reduction / pushed to the peers by their own reduction -- one launch each around the loop on one rank,
+ *  two on a peer rank; the arithmetic and its order are those of the call-by-call sequence, bit for bit.)
  * Requires mjx_bind_batch and mjx_bind_policy(old_is_new = 1).  theta_out (d floats) may be the bound theta_new
  * buffer (it is rewritten in place) but must not alias theta_old.  On return the context's NEW parameters are
  * theta_out, as after mjx_bind_policy(theta_out, theta_old, tr_new, tr_old, 0).

@@ -58,6 +58,17 @@ if os.environ.get("TL_ALTERNATE") == "1":
             print("%-44s %7.2f -> %7.2f  (%.2f ms)" % (tag, a, c, c - a))
         print("total %.2f ms\n" % total)
     sys.exit(0)
+if os.environ.get("TL_FIRST") == "1":
+    # r06: the FIRST calls of a process, one fresh batch at a time like bench.py's end_to_end loop (calls 2-3 ran 24 ms against 8.5 later)
+    for it in range(6):
+        b = fresh()
+        LOG.clear(); torch.cuda.synchronize(); T0[0] = time.perf_counter()
+        agent.train_from_paths(b)
+        torch.cuda.synchronize(); total = 1e3 * (time.perf_counter() - T0[0])
+        print("---- call %d: total %.2f ms" % (it + 1, total))
+        for tag, a, c in sorted(LOG, key=lambda x: x[1]):
+            print("%-44s %7.2f -> %7.2f  (%.2f ms)" % (tag, a, c, c - a))
+    sys.exit(0)
 batches = [fresh() for _ in range(6)]
 for b in batches:
     LOG.clear(); torch.cuda.synchronize(); T0[0] = time.perf_counter()
