@@ -10,10 +10,15 @@
 //   bool MJX_HI_SET_DEVICE(int index)
 //   int  MJX_HI_H2D_ASYNC(void* dst_dev, const void* src_host, size_t bytes, void* stream, const char** what)   (0 = ok)
 //   int  MJX_HI_CAST_F64_F32(const double* x_dev, int64_t count, float* out_dev, void* stream)                  (MJX_OK = ok)
+//   int  MJX_HI_PULL_F64(const double* x_pinned_host, int64_t count, double* raw_dev, float* f32_dev, void* stream)   (MJX_OK = ok)
+//        -- a kernel that READS the page-locked host block over the bus and writes the fp64 block and its fp32 image
 #pragma once
 #include <unistd.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <functional>
@@ -307,26 +312,53 @@ int mjx_stage_async(void** job_out, const void* const* src, const int64_t* lens,
     job->offs[i + 1] = job->offs[i] + lens[i];
   }
   const int64_t dst_item = hostcast ? 4 : src_itemsize;
+  const bool trace = [] { const char* e = getenv("MJX_STAGE_TRACE"); return e && e[0] == '1'; }();     // (diagnostic: where a staging job's time goes)
   job->th = std::thread([=] {
     const int64_t* offs = job->offs.data();
     const void* const* sp = job->src.data();
+    const auto t_start = std::chrono::steady_clock::now();
+    double ms_gather = 0, ms_h2d = 0, ms_cast = 0, ms_dev = 0;
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     if (!MJX_HI_SET_DEVICE(device_index)) { job->rc = MJX_ERR_STATE; job->err = "hipSetDevice failed in the staging thread"; return; }
+    ms_dev = since(t_start);
+    struct Report { bool on; const double *g, *h, *c, *d; std::chrono::steady_clock::time_point t0; int64_t rows, elems; int item;
+                    ~Report() { if (on) fprintf(stderr, "[mjx stage job] %lld rows x %lld x %d B: set-device %.2f, gather %.2f, h2d enqueue %.2f, cast enqueue %.2f, total %.2f ms\n",
+                                                (long long)rows, (long long)elems, item, *d, *g, *h, *c,
+                                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } }
+        report{trace, &ms_gather, &ms_h2d, &ms_cast, &ms_dev, t_start, offs[count], row_elems, src_itemsize};
     int64_t first = 0;
     while (first < count) {
       int64_t last = first;
       while (last < count && offs[last] - offs[first] < group_rows) ++last;     // whole trajectories, at least group_rows rows
       if (last == first) last = first + 1;
       int rc;
+      auto t0 = std::chrono::steady_clock::now();
       if (hostcast) rc = mjx_host_gather_f64_f32((float*)pinned, (const double* const*)sp, offs, first, last - first, row_elems, n_threads);
       else rc = mjx_host_gather(pinned, sp, offs, first, last - first, row_elems * src_itemsize, n_threads);
+      ms_gather += since(t0);
       if (rc != MJX_OK) { job->rc = rc; job->err = mjx_last_error(); return; }
       const int64_t lo = offs[first] * row_elems, hi = offs[last] * row_elems;   // elements
-      if (hi > lo) {
+      // r06: a SMALL raw fp64 block (the 8 MB of advantages / rewards per 1M timesteps) is pulled by a kernel instead of a copy-engine
+      // transfer: with the observation and action blocks' 90 MB in flight on two other streams, hipMemcpyAsync for a third stream
+      // BLOCKED its caller for 6-7 ms in some calls (MJX_STAGE_TRACE=1: "h2d enqueue 7.21 ms" -- the runtime waiting for a copy engine),
+      // which is what made calls 2-4 of a process take 15 ms instead of 8.  Page-locked host memory is mapped into the device's address
+      // space; 8 MB over the bus by loads take 0.2 ms.  (MJX_STAGE_PULL=0: the copy engine for everything.)
+      static const bool pull_on = [] { const char* e = getenv("MJX_STAGE_PULL"); return !(e && e[0] == '0'); }();
+      if (hi > lo && pull_on && device_f32 && !hostcast && src_itemsize == 8 && (hi - lo) * 8 <= (int64_t)(32 << 20)) {
+        t0 = std::chrono::steady_clock::now();
+        rc = MJX_HI_PULL_F64((const double*)pinned + lo, hi - lo, (double*)device_raw + lo, device_f32 + lo, stream);
+        ms_cast += since(t0);
+        if (rc != MJX_OK) { job->rc = rc; job->err = mjx_last_error(); return; }
+      } else if (hi > lo) {
         const char* what = nullptr;
+        t0 = std::chrono::steady_clock::now();
         const int e = MJX_HI_H2D_ASYNC((char*)device_raw + lo * dst_item, (const char*)pinned + lo * dst_item, (size_t)((hi - lo) * dst_item), stream, &what);
+        ms_h2d += since(t0);
         if (e != 0) { job->rc = e; job->err = std::string("hipMemcpyAsync: ") + (what ? what : "?"); return; }
         if (device_f32 && !hostcast && src_itemsize == 8) {                     // raw fp64 block + its fp32 image (cast on the device)
+          t0 = std::chrono::steady_clock::now();
           rc = MJX_HI_CAST_F64_F32((const double*)device_raw + lo, hi - lo, device_f32 + lo, stream);
+          ms_cast += since(t0);
           if (rc != MJX_OK) { job->rc = rc; job->err = mjx_last_error(); return; }
         }
       }

@@ -1466,6 +1466,23 @@ inline int mjx_hi_h2d_async(void* dst, const void* src, size_t bytes, void* stre
 }
 }  // namespace
 extern "C" int mjx_cast_f64_f32(const double* x, int64_t count, float* out32, void* stream);
+namespace {
+// reads a page-locked HOST block (device-mapped) and writes it to the device twice: as it is, and as fp32 (host_ingest.h: small raw blocks)
+__global__ void k_pull_f64(const double* __restrict__ host, int64_t n, double* __restrict__ raw, float* __restrict__ o32) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = host[i];
+    raw[i] = v; o32[i] = (float)v;
+  }
+}
+inline int mjx_hi_pull_f64(const double* host, int64_t n, double* raw, float* o32, void* stream) {
+  if (n <= 0) return MJX_OK;
+  int grid = (int)((n + 255) / 256); if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_pull_f64, dim3(grid), dim3(256), 0, (hipStream_t)stream, host, n, raw, o32);
+  HIPCHK(hipGetLastError());
+  return MJX_OK;
+}
+}  // namespace
+#define MJX_HI_PULL_F64(x, n, r, o, st) mjx_hi_pull_f64(x, n, r, o, st)
 #define MJX_HI_SET_DEVICE(i) mjx_hi_set_device(i)
 #define MJX_HI_H2D_ASYNC(d, s_, b, st, w) mjx_hi_h2d_async(d, s_, b, st, w)
 #define MJX_HI_CAST_F64_F32(x, n, o, st) mjx_cast_f64_f32(x, n, o, st)

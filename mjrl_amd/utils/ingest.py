@@ -145,19 +145,6 @@ class PathStager:
             s = dict(pin=pin, pin_np=pin.numpy(), width=width, dtype=dtype, cap=cap, hostcast=hostcast)
             self._slots[key] = s
         if self.on_gpu:
-            # r06: the device blocks of a batch stay alive while the next batch is staged (the engine and the registry hold them), so
-            # the first THREE batches of a size each found torch's caching allocator empty: fresh hipMalloc'ed memory, whose first
-            # transfers ran 7-8 ms late (tools/e2e_timeline.py TL_FIRST=1: calls 2 and 3 of a process took 15 / 14 ms against 8).
-            # The first time a block shape is seen, two more generations are allocated, touched and handed back to the allocator's pool.
-            warm = s.setdefault("warmed", set())
-            shape_key = (int(rows), int(width), str(tdt))
-            nbytes = int(rows) * int(width) * (8 if tdt == torch.float64 else 4)
-            if shape_key not in warm and 0 < nbytes <= (1 << 30):
-                warm.add(shape_key)
-                spare = [torch.empty((rows, width), dtype=tdt, device=self.device).zero_() for _ in range(2)]
-                if tdt == torch.float64:
-                    spare += [torch.empty((rows, width), dtype=torch.float32, device=self.device).zero_() for _ in range(2)]
-                del spare
             s["dev_raw"] = torch.empty((rows, width), dtype=tdt, device=self.device)
             s["dev_f32"] = torch.empty((rows, width), dtype=torch.float32, device=self.device) if tdt == torch.float64 else s["dev_raw"]
         else:                                           # CPU stand-in (tests): same ownership rules, plain memory

@@ -34,6 +34,8 @@ static int h2d(void* d, const void* s, size_t b, void*, const char**) { memcpy(d
 #define MJX_HI_H2D_ASYNC(d, s_, b, st, w) h2d(d, s_, b, st, w)
 static int cast(const double* x, int64_t n, float* o, void*) { for (int64_t i = 0; i < n; ++i) o[i] = (float)x[i]; return MJX_OK; }
 #define MJX_HI_CAST_F64_F32(x, n, o, st) cast(x, n, o, st)
+static int pull(const double* x, int64_t n, double* r, float* o, void*) { for (int64_t i = 0; i < n; ++i) { r[i] = x[i]; o[i] = (float)x[i]; } return MJX_OK; }
+#define MJX_HI_PULL_F64(x, n, r, o, st) pull(x, n, r, o, st)
 #include "../../mjrl_amd/csrc/host_ingest.h"
 
 #define CHECK(c) do { if (!(c)) { fprintf(stderr, "FAILED %s:%d: %s (%s)\n", __FILE__, __LINE__, #c, mjx_last_error()); exit(1); } } while (0)

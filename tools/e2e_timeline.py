@@ -58,8 +58,22 @@ if os.environ.get("TL_ALTERNATE") == "1":
             print("%-44s %7.2f -> %7.2f  (%.2f ms)" % (tag, a, c, c - a))
         print("total %.2f ms\n" % total)
     sys.exit(0)
+if os.environ.get("TL_FINE") == "1":        # finer stamps inside the stager (r06: where do calls 2-3 of a process lose 7 ms?)
+    for nm in ("begin", "_stage_async", "join", "_slot"):
+        wrap(ingest.PathStager, nm, "    stager." + nm)
+    _oa = ingest._order_after
+    def oa(backend, ent):
+        t = time.perf_counter(); _oa(backend, ent); LOG.append(("    _order_after", 1e3 * (t - T0[0]), 1e3 * (time.perf_counter() - T0[0])))
+    ingest._order_after = oa
+    _sb = ingest._same_batch
+    def sb(ent, paths_, key):
+        t = time.perf_counter(); r = _sb(ent, paths_, key); LOG.append(("    _same_batch(%s)" % key, 1e3 * (t - T0[0]), 1e3 * (time.perf_counter() - T0[0]))); return r
+    ingest._same_batch = sb
 if os.environ.get("TL_FIRST") == "1":
     # r06: the FIRST calls of a process, one fresh batch at a time like bench.py's end_to_end loop (calls 2-3 ran 24 ms against 8.5 later)
+    if os.environ.get("TL_PREGROW") == "1":      # the host heap already holds three batches' worth of freed chunks when call 1 starts
+        tmp = [fresh() for _ in range(3)]
+        del tmp
     for it in range(6):
         b = fresh()
         LOG.clear(); torch.cuda.synchronize(); T0[0] = time.perf_counter()
