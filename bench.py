@@ -287,15 +287,19 @@ def secondary_measurements(eng, theta0, theta0_dev, ref=None, full_size=True):
         grad = e.surr_vpg()[0].clone()
         e.fvp(grad)
         torch.cuda.synchronize()
-        check(e.lib.mjx_profile_enable(e.ctx, 1))
-        for _ in range(4):
-            e.fvp(grad)
         prof = (ctypes.c_double * 2)()
-        check(e.lib.mjx_profile_read(e.ctx, prof))
-        check(e.lib.mjx_profile_enable(e.ctx, 0))
+
+        def timed_products(k):
+            check(e.lib.mjx_profile_enable(e.ctx, 1))
+            for _ in range(k):
+                e.fvp(grad)
+            check(e.lib.mjx_profile_read(e.ctx, prof))
+            check(e.lib.mjx_profile_enable(e.ctx, 0))
+            return prof[0] / prof[1]
+        ms_first = timed_products(4)          # products 2-5 after K1 (r01-r05's figure: clocks / caches still settling)
+        ms = timed_products(8)                # products 6-13: what the 10-25 products of a solve run at
         P = sum(sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1))
         flop = 2 * (4 * P - 2 * n * hid[0]) * N
-        ms = prof[0] / prof[1]
         ab = lw_switch_ab(e, grad, flop)
         # one whole NPG update of this shard (K1, the config's CG iterations, step, K3) through the one-call entry point
         cg_iters = cfg["cg_iters"]
@@ -311,7 +315,8 @@ def secondary_measurements(eng, theta0, theta0_dev, ref=None, full_size=True):
         upd_ms = 1e3 * (time.perf_counter() - t0)
         lw[name] = {"rows": N, "fvp_ms": ms, "TFLOPs": flop / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
                     "flop_per_fvp": flop, "kernels": "k_gemm_p (persistent tangent / delta products, csrc/lw_gemm_p.h) + k_gemm<128,256> / <128,128> weight gradients + k_lw_head (one-pass output layer, csrc/lw_head.h)",
-                    "timed": "4 products, HIP events around the whole chain of one product",
+                    "timed": "8 products (the 6th to 13th after K1: a solve runs 10-25), HIP events around the whole chain of one product",
+                    "fvp_ms_first_four_after_K1": ms_first, "frac_first_four_after_K1": flop / (ms_first * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
                     "npg_update_ms": upd_ms, "cg_iters": cg_iters, "inputs": "seeded host rows (bench.lw_shard_inputs, PCG64 seed %d)" % cfg["seed"],
                     "switch_ab_same_process": ab}
         if cfg["algo"] == "dapg":

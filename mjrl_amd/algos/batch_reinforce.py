@@ -308,17 +308,20 @@ class BatchREINFORCE:
                 return eng.stage_paths(paths, keys)
         return run
 
-    def _process_and_bind(self, paths):
+    def _process_and_bind(self, paths, defer_stats=False):
         """process_paths + upload + binding for train_from_paths: the (whitened, fp64) advantages are assembled on the
         host like the reference does, observations / actions go path by path through the engine's page-locked
         stager (utils/ingest.py) -- no concatenated host copy, transfers overlapped with staging.
-        -> base_stats; sets self.running_score."""
+        -> base_stats; sets self.running_score.  defer_stats (r06): -> a callable that returns base_stats (and sets the running
+        score) when asked -- the per-path return statistics are host work the update does not depend on; NPG runs them under the
+        update's device time."""
         # the gather / upload of observations and actions runs on a helper thread (native memcpy threads + asynchronous
         # copies, no GIL) while this thread assembles the advantage vector and the path statistics
         eng = self.engine
         from ..utils import ingest
         if not paths:
-            return self._bind_empty_shard()
+            bs = self._bind_empty_shard()
+            return (lambda: bs) if defer_stats else bs
         # (asked before the staging jobs start: a helper holds its key's registry lock while it stages)
         adv64 = ingest.lookup(eng.backend, paths, "advantages") if eng.device.type == "cuda" else None
         host_adv = False
@@ -351,11 +354,17 @@ class BatchREINFORCE:
                 # and are whitened on the device like the resident ones -- np.concatenate + mean + std + the division cost 2-3 ms of
                 # this thread per 1M timesteps
                 adv64 = ingest.stage_shared(eng.backend, paths, ("advantages",))["advantages"]["raw"].view(-1)
+            stats_later = None
             if adv64 is not None:
                 # the advantages never left the device (utils/process_samples.compute_advantages): whitening statistics
                 # and the fp32 cast happen there; only the per-path return statistics are host work
                 advantages = eng.whitened_advantages(adv64)
-                base_stats, self.running_score = self._path_statistics(paths)
+                if defer_stats:
+                    def stats_later():
+                        bs, self.running_score = self._path_statistics(paths)
+                        return bs
+                else:
+                    base_stats, self.running_score = self._path_statistics(paths)
             else:
                 advantages, base_stats, self.running_score = self._advantages_and_statistics(paths)
         finally:
@@ -367,6 +376,8 @@ class BatchREINFORCE:
         if not native:
             self._push_policy()
         eng.set_batch(staged["observations"], staged["actions"], advantages)
+        if defer_stats:
+            return stats_later if stats_later is not None else (lambda: base_stats)
         return base_stats
 
     def _bind_empty_shard(self):

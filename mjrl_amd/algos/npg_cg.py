@@ -124,10 +124,9 @@ class NPG(BatchREINFORCE):
             observations, actions, advantages, base_stats, self.running_score = self.process_paths(paths)
             self._normalize_inputs(observations)
             self._bind(observations, actions, advantages)
+            stats_later = None
         else:
-            base_stats = self._process_and_bind(paths)
-        if self.save_logs:
-            self.log_rollout_statistics(paths)
+            stats_later = self._process_and_bind(paths, defer_stats=True)      # (the path statistics: under the update, below)
         eng = self.engine
 
         const_alpha = self.alpha is not None
@@ -138,10 +137,20 @@ class NPG(BatchREINFORCE):
             # step, K3 -- rank sums included -- and one read-back.  (t_gLL / t_FIM cannot be told apart any more: the
             # gradient time is logged as 0, the solve time is the whole call.)
             t0 = timer.time()
-            surr_after, kl_dist = eng.npg_update(iters, damping, self.n_step_size, self.policy.min_log_std,
-                                                 const_alpha=self.alpha if const_alpha else None)   # npg_cg.py:108-141
+            eng.npg_update(iters, damping, self.n_step_size, self.policy.min_log_std,
+                           const_alpha=self.alpha if const_alpha else None, enqueue_only=True)      # npg_cg.py:108-141
+            # host work the update does not depend on runs under its device time: per-path return statistics, rollout log entries
+            if stats_later is not None:
+                base_stats, stats_later = stats_later(), None
+            if self.save_logs:
+                self.log_rollout_statistics(paths)
+            surr_after, kl_dist = eng.npg_update_result()
             t_gLL, t_FIM = 0.0, timer.time() - t0
         else:
+            if stats_later is not None:
+                base_stats, stats_later = stats_later(), None
+            if self.save_logs:
+                self.log_rollout_statistics(paths)
             # row-subsampled Fisher products (a fresh host-drawn sample per product, npg_cg.py:65-69) and the general
             # position theta_new != theta_old (input_normalization, :101-107): call by call
             t0 = timer.time()

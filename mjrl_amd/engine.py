@@ -552,26 +552,38 @@ class UpdateEngine:
         self.old_is_new = False
         self._bind_policy()
 
-    def npg_update(self, iters, damping, step_size, min_log_std, const_alpha=None, tol=1e-10):
+    def npg_update(self, iters, damping, step_size, min_log_std, const_alpha=None, tol=1e-10, enqueue_only=False):
         """The whole NPG update (npg_cg.py:108-142: K1, CG, step length, step, K3) enqueued by ONE call into libmjx
         (mjx_npg_update), rank sums included -> (surr_after, kl); deferred() has surr_before / g.x / alpha.
         Needs theta_new == theta_old at entry; the torch.distributed fallback path (no RCCL inside libmjx) issues the same
-        sequence call by call."""
+        sequence call by call.  enqueue_only (r06): return as soon as the update is ENQUEUED -- the caller does host work that
+        does not depend on it (path statistics, log entries) under the 3.8 ms of device time and then asks npg_update_result()."""
         assert self.old_is_new, "npg_update starts from theta_new == theta_old"
         d = _dist()
         if (d is None or self._native_comm()) and hasattr(self.backend, "npg_update"):
             self._host_results = None
             self.backend.npg_update(iters, damping, tol, step_size, const_alpha, min_log_std, self.grad, self.x, self.theta_new, self.results)
             self.old_is_new = False
-            s = self._host_results = self._checked(self.results.cpu().numpy())
-            return float(s[0] / self.N_global), float(s[1] / self.N_global)
+            self._npg_pending = True
+            return None if enqueue_only else self.npg_update_result()
         g, _ = self.surr_vpg(sync=False)
         self.cg_solve(g, iters, damping, tol, sync=const_alpha is not None)
         if const_alpha is not None:
             self.apply_step(const_alpha, min_log_std)
         else:
             self.apply_npg_step(step_size, min_log_std)
-        return self.eval_surr_kl()
+        self._npg_pending = self.eval_surr_kl()
+        return None if enqueue_only else self.npg_update_result()
+
+    def npg_update_result(self):
+        """-> (surr_after, kl) of the update npg_update(..., enqueue_only=True) started: the one read-back"""
+        pend, self._npg_pending = getattr(self, "_npg_pending", None), None
+        if pend is None:
+            raise _lib.MjxError("npg_update_result() without an update in flight")
+        if pend is not True:                              # (the call-by-call fallback has read its results already)
+            return pend
+        s = self._host_results = self._checked(self.results.cpu().numpy())
+        return float(s[0] / self.N_global), float(s[1] / self.N_global)
 
     def dapg_update(self, iters, damping, step_size, min_log_std, rows_on, adv_on, N_on_global=None, tol=1e-10):
         """The whole DAPG update (dapg.py:92-121) through ONE call into libmjx (mjx_dapg_update), rank sums included: K1
