@@ -136,10 +136,13 @@ def _main_would_rerun():
     return re.search(r"^[ \t]*if[ \t]+__name__[ \t]*==[ \t]*['\"]__main__['\"]", src, re.M) is None
 
 
-def _serve_here(reason):
-    """remember (and say once) that this process runs its rollouts itself"""
-    if "why" not in _SERIAL_ONLY:
-        _SERIAL_ONLY["why"] = reason
+def _serve_here(reason, sticky=True):
+    """say (once per process) that a num_cpu > 1 request is served in this process; sticky: ... and every later one too (a property
+    of the PROCESS -- its main module; a payload that cannot travel concerns that request only)"""
+    if sticky:
+        _SERIAL_ONLY.setdefault("why", reason)
+    if "warned" not in _SERIAL_ONLY:
+        _SERIAL_ONLY["warned"] = True
         import warnings
         warnings.warn("mjrl_amd.samplers: num_cpu > 1 is served in the training process itself -- %s.  Guard the script with "
                       "`if __name__ == \"__main__\":` and define env factories / policy classes in an importable module, or set "
@@ -241,7 +244,7 @@ def native_sample_paths(num_traj, env, policy, eval_mode=False, horizon=1e6, bas
         try:
             blobs = (pickle.dumps((env, env_kwargs)), pickle.dumps(policy))
         except Exception as e:                            # a lambda, a local class, an env holding an open handle ...
-            _serve_here("the env / policy cannot be pickled for the workers (%s: %s)" % (type(e).__name__, e))
+            _serve_here("the env / policy cannot be pickled for the workers (%s: %s)" % (type(e).__name__, e), sticky=False)
     if blobs is None:
         # this process: the reference's one-process call (episodes base_seed + ep); with a sink in pieces, each handed on when done
         total = num_traj if num_cpu == 1 else num_cpu * int(np.ceil(num_traj / num_cpu))       # (core.py:124 rounds every worker's share up)
@@ -273,11 +276,11 @@ def native_sample_paths(num_traj, env, policy, eval_mode=False, horizon=1e6, bas
     try:
         results = _try_multiprocess(jobs, num_cpu, max_process_time, max_timeouts, sink)
     except _PayloadError as e:
-        _serve_here("the workers cannot rebuild the env / policy they were sent (%s)" % e)
+        _serve_here("the workers cannot rebuild the env / policy they were sent (%s)" % e, sticky=False)
         if sink is not None:
             sink.abort("the worker pool was given up")
-        return native_sample_paths(num_traj, env, policy, eval_mode, horizon, base_seed, num_cpu, max_process_time, max_timeouts,
-                                   True, env_kwargs, None)
+        total = num_cpu * paths_per_cpu                                     # (the episodes the pool would have returned, seeded alike)
+        return native_do_rollout(num_traj=total, base_seed=base_seed, **common)
     if results is None:
         raise RuntimeError("sample_paths: %d worker timeouts of %s s each -- no rollouts (mjrl/samplers/core.py:192-193 returns None here, "
                            "which its caller then fails on)" % (max_timeouts, max_process_time))
