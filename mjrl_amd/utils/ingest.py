@@ -784,7 +784,12 @@ class StreamedBatch:
             keys.append(k)
         if not keys or self.total is None:
             return self.abort("nothing to stream")
-        self.cap = int(self.total) * int(max(1, min(int(T), 10 ** 7)))
+        # capacity: total_episodes x horizon is the bound, but an env whose episodes end long before their horizon would make the
+        # page-locked and device blocks many times the size of the data -- so 1.5 x (mean length of the first chunk) x episodes when
+        # that is smaller; a later chunk that does not fit aborts the stream (the batch is then staged after sampling, as before)
+        rows0 = sum(len(p["rewards"]) for p in chunk)
+        est = int(1.5 * rows0 / max(len(chunk), 1) * int(self.total)) + 1
+        self.cap = min(int(self.total) * int(max(1, min(int(T), 10 ** 7))), max(est, rows0))
         if self.cap > (1 << 31):
             return self.abort("capacity bound beyond 2^31 rows")
         dev = self.dev
@@ -818,7 +823,7 @@ class StreamedBatch:
                     return
             rows = sum(len(p["rewards"]) for p in chunk)
             if self.rows + rows > self.cap:
-                return self.abort("a chunk beyond the capacity bound (trajectories longer than the horizon the sampler named)")
+                return self.abort("a chunk beyond the capacity bound (trajectories longer than the horizon the sampler named, or much longer than the first chunk's)")
             for k, st in self.st.items():
                 st.add_paths(chunk)                                 # native gather into the page-locked block + queued copies
             self.rows += rows

@@ -282,3 +282,48 @@ def test_a_straggling_workgroup_cannot_launder_a_timed_out_fit(monkeypatch):
     monkeypatch.delenv("MJX_FIT_FAULT")
     e0, e1 = bl.fit(paths, return_errors=True)             # the baseline is still usable
     assert np.isfinite(e0) and np.isfinite(e1) and bl.adam_steps == 2 * before[3] and not np.array_equal(bl.params, before[0])
+
+
+@pytest.mark.parametrize("kind", ["quadratic", "linear"])
+def test_ridge_fit_async_equals_fit_and_settles_on_access(kind, monkeypatch):
+    """r06: the ridge baselines' fit_async -- Gram kernel enqueued on the caller's stream, the F x F solve (and, for the logged errors,
+    the evaluation of the new coefficients) on a helper thread -- gives the coefficients and errors of fit() bit for bit; reading
+    `_coeffs`, predict, pickle and deepcopy wait for it; a second fit settles the first; MJX_ASYNC_FIT=0 runs in place."""
+    from mjrl_amd.baselines.quadratic_baseline import LinearBaseline, QuadraticBaseline, PendingRidgeFit
+    from mjrl_amd.utils import ingest, process_samples
+    cls = QuadraticBaseline if kind == "quadratic" else LinearBaseline
+    spec = type("Spec", (), dict(observation_dim=11, action_dim=3, horizon=120))
+    rng = np.random.RandomState(3)
+
+    def batch(seed):
+        r = np.random.RandomState(seed)
+        ps = [dict(observations=r.randn(T, 11), rewards=r.randn(T), terminated=False) for T in r.randint(20, 121, size=50)]
+        process_samples.compute_returns(ps, 0.99)
+        return ps
+    a, b = batch(1), batch(2)
+    ref = cls(spec)
+    e_ref = [ref.fit(a, return_errors=True)]
+    c1 = ref._coeffs.copy()
+    e_ref.append(ref.fit(b, return_errors=True))
+    ingest.drop_shared_batch()
+    bl = cls(spec)
+    p1 = bl.fit_async(a, return_errors=True)
+    assert isinstance(p1, PendingRidgeFit)
+    delivered = []
+    p1.hooks.append(lambda errs, ms: delivered.append((errs, ms)))
+    snap = copy.deepcopy(bl)                                  # waits; the copy carries the finished fit and no pending state
+    assert p1.done and "_pending" not in snap.__dict__ and np.array_equal(snap._coeffs, c1)
+    assert delivered and delivered[0][0] == p1.value == e_ref[0] and delivered[0][1] > 0.0
+    assert np.array_equal(pickle.loads(pickle.dumps(bl))._coeffs, c1)
+    p2 = bl.fit_async(b, return_errors=True)                  # error_before uses the coefficients of the first fit
+    pred = bl.predict(b[0])                                   # settles p2
+    assert p2.done and p2.result() == e_ref[1] and np.array_equal(bl._coeffs, ref._coeffs)
+    np.testing.assert_array_equal(pred, ref.predict(b[0]))
+    p3 = bl.fit_async(a)                                      # no errors asked for: value None, coefficients those of a fit from here
+    assert p3.result() is None and p3.done
+    ref.fit(a)
+    assert np.array_equal(bl._coeffs, ref._coeffs)
+    monkeypatch.setenv("MJX_ASYNC_FIT", "0")
+    p4 = bl.fit_async(b, return_errors=True)
+    assert p4.done and p4.future is None and p4.value == ref.fit(b, return_errors=True) and np.array_equal(bl._coeffs, ref._coeffs)
+    ingest.drop_shared()
