@@ -346,6 +346,9 @@ int mjx_host_segment_sums(const double* const* src, const int64_t* lens, int64_t
  * once per epoch (mjrl/utils/optimize_model.py:22).  key624 / pos_io: the generator state as np.random.get_state() returns it
  * (624 words + position), advanced in place -- hand it back with np.random.set_state.  n < 2^31.  Host only, any thread. */
 int mjx_host_mt19937_permutation(uint32_t* key624_host, int32_t* pos_io_host, int64_t n, int32_t* out_host);
+/* `epochs` consecutive permutations of that stream, out[e * n .. (e + 1) * n): the bits of `epochs` calls of the function above (one
+ * fit of MLPBaseline draws one per epoch), with the generator and the swaps running on two threads (r06) */
+int mjx_host_mt19937_permutations(uint32_t* key624_host, int32_t* pos_io_host, int64_t n, int epochs, int32_t* out_host);
 /* `count` draws of np.random.choice(n, size=...) (with replacement; == np.random.randint(0, n, size=...)) of the same stream: the
  * minibatch row indices BC and PPO draw once per Adam step (mjrl/algos/behavior_cloning.py:113, ppo_clip.py:77); draws of any
  * sizes concatenate, so steps x minibatch indices are ONE call.  1 <= n < 2^31. */

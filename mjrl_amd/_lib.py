@@ -71,6 +71,7 @@ PROTOTYPES = {
     "mjx_host_gather_f64_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "mjx_host_segment_sums": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int]),
     "mjx_host_mt19937_permutation": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int32), c_int64, c_void_p]),
+    "mjx_host_mt19937_permutations": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int32), c_int64, c_int, c_void_p]),
     "mjx_host_mt19937_randint": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int32), c_int64, c_int64, c_void_p]),
     "mjx_stage_async": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                 c_int64, c_int, c_int, c_void_p]),

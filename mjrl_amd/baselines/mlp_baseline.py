@@ -30,6 +30,21 @@ def _permutation_into(lib, out):
     np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
 
 
+def _permutations_into(lib, out, n, epochs):
+    """out[e * n : (e + 1) * n] = np.random.permutation(n) for e in range(epochs), consecutively from NumPy's global stream -- one native
+    call (mjx_host_mt19937_permutations: the generator on this thread, the swaps on a second one)"""
+    n, epochs = int(n), int(epochs)
+    st = np.random.get_state()
+    if n < 2 or epochs < 1 or st[0] != 'MT19937' or out.dtype != np.int32 or not out.flags.c_contiguous or out.shape[0] < n * epochs:
+        for ep in range(epochs):
+            _permutation_into(lib, out[ep * n:(ep + 1) * n])
+        return
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = ctypes.c_int32(int(st[2]))
+    check(lib.mjx_host_mt19937_permutations(ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), n, epochs, ctypes.c_void_p(out.ctypes.data)))
+    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+
+
 _FIT_STREAMS = {}            # device -> the side stream the asynchronous fits run on
 
 
@@ -191,10 +206,9 @@ class MLPBaseline:
 
         def work():
             try:
-                out = pin.numpy()
-                for ep in range(h["epochs"]):
-                    check(blk.lib.mjx_host_mt19937_permutation(ctypes.c_void_p(key.ctypes.data), ctypes.byref(h["pos"]), num_samples,
-                                                               ctypes.c_void_p(out[ep * num_samples:].ctypes.data)))
+                out = pin.numpy()                                # (all epochs in one native call: generator and swaps on two threads)
+                check(blk.lib.mjx_host_mt19937_permutations(ctypes.c_void_p(key.ctypes.data), ctypes.byref(h["pos"]), num_samples, h["epochs"],
+                                                            ctypes.c_void_p(out.ctypes.data)))
             except Exception as e:                               # pragma: no cover
                 h["error"] = e
         h["thread"] = threading.Thread(target=work, name="mjx-predraw", daemon=True)
@@ -277,8 +291,8 @@ class MLPBaseline:
         perm = perm_pin.numpy()[:max(self.epochs * num_samples, 1)]
         if self.epochs * num_samples == 0:
             perm[:] = 0
-        for ep in ([] if have else range(self.epochs)):
-            _permutation_into(blk.lib, perm[ep * num_samples:(ep + 1) * num_samples])
+        if not have:
+            _permutations_into(blk.lib, perm, num_samples, self.epochs)
         if ranks.group() is not None:
             perm[:] = ranks.broadcast_host(perm, src=-1)        # the LAST rank's draw (see above)
         perm_t = perm_pin[:perm.shape[0]].to(blk.dev, non_blocking=True)

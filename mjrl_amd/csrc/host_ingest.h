@@ -15,6 +15,7 @@
 #pragma once
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -22,6 +23,7 @@
 #include <cstdint>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -243,14 +245,21 @@ extern "C" int mjx_host_mt19937_permutation(uint32_t* key624, int32_t* pos_io, i
   int64_t i = n - 1;
   while (i >= 1) {
     const int cnt = (int)(i >= B ? B : i);
-    for (int b = 0; b < cnt; ++b) {
-      const uint32_t ii = (uint32_t)(i - b);
+    {
+      // (masked rejection without a data-dependent branch -- see mjx_host_mt19937_permutations below: the rejected third of the
+      //  candidates cost ~5 ns per index in mispredictions)
+      uint32_t ii = (uint32_t)i;
       uint32_t mask = ii;
       mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-      uint32_t j;
-      while ((j = (g.next() & mask)) > ii) {}
-      js[b] = j;
-      __builtin_prefetch(out + j, 1, 1);
+      int b = 0;
+      while (b < cnt) {
+        const uint32_t v = g.next() & mask;
+        const uint32_t acc = (uint32_t)(v <= ii);
+        js[b] = v;
+        b += (int)acc; ii -= acc;
+        mask = (ii <= (mask >> 1)) ? (mask >> 1) : mask;
+      }
+      for (b = 0; b < cnt; ++b) __builtin_prefetch(out + js[b], 1, 1);
     }
     for (int b = 0; b < cnt; ++b) {
       const int64_t ii = i - b;
@@ -259,6 +268,75 @@ extern "C" int mjx_host_mt19937_permutation(uint32_t* key624, int32_t* pos_io, i
     }
     i -= cnt;
   }
+  *pos_io = g.pos;
+  return MJX_OK;
+}
+
+// `epochs` consecutive np.random.permutation(n) of the same stream, out[e * n ..]: what MLPBaseline.fit draws per fit (one per epoch,
+// optimize_model.py:22).  The draws are sequential in the GENERATOR only -- the swap partners j_i do not depend on the array -- so the
+// work is cut where it can be: the calling thread runs the generator through all epochs (masked rejection, ~1.5 words per index) and
+// publishes the partners in blocks, a second thread applies the swaps behind it (random accesses into the 4 MB index array, with the
+// partners known far ahead to prefetch).  Same draws, same swaps, same order: the bits of `epochs` calls of the function above, in
+// ~the time of the slower of the two halves instead of their sum (r06: 2 x 1M rows 11 -> ~6 ms on the GPU boxes' hosts -- the tail of
+// these draws was what MLPBaseline.fit still cost on train_step's critical path).
+extern "C" int mjx_host_mt19937_permutations(uint32_t* key624, int32_t* pos_io, int64_t n, int epochs, int32_t* out) {
+  if (!key624 || !pos_io || !out || n < 0 || epochs < 0 || n >= ((int64_t)1 << 31) || *pos_io < 0 || *pos_io > 624) return fail(MJX_ERR_ARG, "bad arguments");
+  if (n < 65536 || epochs == 0) {                     // small: the pipeline's hand-over costs more than it saves
+    for (int e = 0; e < epochs; ++e)
+      if (int rc = mjx_host_mt19937_permutation(key624, pos_io, n, out + (int64_t)e * n)) return rc;
+    return MJX_OK;
+  }
+  const int64_t per = n - 1, total = per * epochs;    // swaps per epoch (i = n - 1 .. 1), over all epochs
+  std::unique_ptr<uint32_t[]> js_own(new uint32_t[(size_t)total]);      // (not value-initialised: 8 MB per 2 x 1M rows, every word written before it is read)
+  struct { uint32_t* p; uint32_t* data() const { return p; } } js{js_own.get()};
+  std::atomic<int64_t> ready{0};                      // partners published so far
+  std::thread applier([&] {
+    constexpr int64_t AHEAD = 24;
+    int64_t seen = 0;
+    for (int e = 0; e < epochs; ++e) {
+      int32_t* o = out + (int64_t)e * n;
+      for (int64_t i = 0; i < n; ++i) o[i] = (int32_t)i;
+      const uint32_t* je = js.data() + (int64_t)e * per;
+      const int64_t base = (int64_t)e * per;
+      for (int64_t k = 0; k < per; ++k) {
+        if (base + k >= seen) {
+          while ((seen = ready.load(std::memory_order_acquire)) <= base + k) std::this_thread::yield();
+        }
+        if (k + AHEAD < per && base + k + AHEAD < seen) __builtin_prefetch(o + je[k + AHEAD], 1, 1);
+        const int64_t ii = n - 1 - k;
+        const uint32_t j = je[k];
+        const int32_t t = o[ii]; o[ii] = o[j]; o[j] = t;
+      }
+    }
+  });
+  Mt19937 g{key624, *pos_io};
+  constexpr int64_t BLK = 8192;
+  int64_t w = 0, published = 0;
+  for (int e = 0; e < epochs; ++e) {
+    // masked rejection (RandomState's random_interval: draw & mask until <= i) WITHOUT a data-dependent branch: a third of the
+    // candidates is rejected, unpredictably -- as a branch that is ~5 ns per index in mispredictions, most of this function's time.
+    // Every candidate is stored at the write position, the position (and the bound i) advance only when it was accepted; the mask
+    // shrinks exactly when i reaches the next power of two minus one, as recomputing it from i would give.
+    uint32_t ii = (uint32_t)(n - 1);
+    uint32_t mask = ii;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    const int64_t w_end = w + per;
+    uint32_t* jp = js.data();
+    while (w < w_end) {
+      const int64_t stop = (w_end - w < BLK) ? w_end : w + BLK;     // (publish a block at a time)
+      while (w < stop) {
+        const uint32_t v = g.next() & mask;
+        const uint32_t acc = (uint32_t)(v <= ii);
+        jp[w] = v;
+        w += acc; ii -= acc;
+        mask = (ii <= (mask >> 1)) ? (mask >> 1) : mask;
+      }
+      published = w;
+      ready.store(published, std::memory_order_release);
+    }
+  }
+  ready.store(w, std::memory_order_release);
+  applier.join();
   *pos_io = g.pos;
   return MJX_OK;
 }

@@ -119,6 +119,19 @@ int main(int argc, char** argv) {
   std::vector<std::thread> callers;
   for (unsigned t = 0; t < 4; ++t) callers.emplace_back(one_caller, 100 + 17 * t, rounds, &bad);
   for (auto& t : callers) t.join();
+  // r06: the two-thread permutation pipeline (generator on the caller, swaps on a second thread) against the one-thread function:
+  // the same permutations and the same generator state -- and clean under ThreadSanitizer
+  {
+    const int64_t n = 70001; const int epochs = 3;
+    std::vector<uint32_t> k1(624), k2(624);
+    for (int i = 0; i < 624; ++i) k1[i] = k2[i] = 0x9e3779b9u * (uint32_t)(i + 1) + 12345u;
+    int32_t p1 = 624, p2 = 624;
+    std::vector<int32_t> a((size_t)(n * epochs)), c((size_t)(n * epochs));
+    for (int e = 0; e < epochs; ++e) CHECK(mjx_host_mt19937_permutation(k1.data(), &p1, n, a.data() + (int64_t)e * n) == MJX_OK);
+    CHECK(mjx_host_mt19937_permutations(k2.data(), &p2, n, epochs, c.data()) == MJX_OK);
+    CHECK(a == c && k1 == k2 && p1 == p2);
+    CHECK(mjx_host_mt19937_permutations(nullptr, &p2, n, epochs, c.data()) == MJX_ERR_ARG);
+  }
   if (bad.load()) { fprintf(stderr, "FAILED: %d mismatches\n", bad.load()); return 1; }
   printf("host_san ok: 4 concurrent callers x %d rounds\n", rounds);
   return 0;

@@ -438,6 +438,17 @@ def test_native_permutation_is_numpys_stream_bit_for_bit():
             tail_b = (np.random.randn(2), np.random.randint(0, 1000, 5))
             assert all(np.array_equal(x, y) for x, y in zip(a, b)), (seed, n)
             assert all(np.array_equal(x, y) for x, y in zip(tail_a, tail_b)), (seed, n)
+    # r06: all epochs of a fit in ONE call (mjx_host_mt19937_permutations: generator and swaps on two threads above 65 536 rows) --
+    # the same permutations, the same generator state afterwards
+    from mjrl_amd.baselines.mlp_baseline import _permutations_into
+    for seed, n, epochs in ((3, 1000, 3), (4, 65536, 2), (5, 65537, 3), (6, 300007, 2), (7, 1000003, 2), (8, 70001, 1)):
+        np.random.seed(seed); np.random.randn(1)
+        a = np.concatenate([np.random.permutation(n) for _ in range(epochs)])
+        tail_a = np.random.randint(0, 10 ** 6, 4)
+        np.random.seed(seed); np.random.randn(1)
+        b = np.empty(n * epochs, np.int32)
+        _permutations_into(lib, b, n, epochs)
+        assert np.array_equal(a, b) and np.array_equal(tail_a, np.random.randint(0, 10 ** 6, 4)), (seed, n, epochs)
 
 
 def test_native_minibatch_indices_are_numpys_choice_stream():
