@@ -424,4 +424,87 @@ struct MlpRegressor {
   }
 };
 
+// ---- the value network of mjrl's MLPBaseline, (n + 4) -> 128 -> 128 -> 1 ReLU (mjrl/baselines/mlp_baseline.py:21-28), evaluated in
+// ONE launch (r06).  The layer-by-layer route (MlpRegressor::forward: 3 GEMM launches per 131 072-row chunk) spent 1.3 ms per 1M
+// timesteps, most of it in the K = 21 first layer (rows of 84 bytes: neither 16-byte granules nor a whole 32-wide k-tile, i.e. the
+// general kernel's element-wise loads) -- and baseline.predict sits on train_step's critical path (compute_advantages).  Same scheme as
+// the fused policy kernels: units on the MFMA M / K dims, the tile's 32 samples on N, so layer 1's accumulators ARE layer 2's B
+// operands; weights in LDS, read as one ds_read_b128 per four k-steps in the k-permuted order (k-slot `hi` of step (q, t) carries
+// k = 8 q + 4 hi + t).  One wave = one 32-sample tile at a time; 8 waves per workgroup (two per SIMD), one workgroup per CU.
+// Per tile: 4 x K1 / 2 + 256 MFMAs of 32x32x2; 1M timesteps: 8.9 GF on the matrix pipe.  d_in <= 64.
+struct MlpPredictArgs { const float* feat; const float* params; float* out; int64_t N; int d_in; };
+constexpr int MP_H = 128, MP_S2 = MP_H + 4;
+__host__ __device__ inline int mp_k1(int d_in) { return (d_in + 7) & ~7; }
+__host__ __device__ inline size_t mlp_predict_lds_bytes(int d_in) { return sizeof(float) * (size_t)(MP_H * (mp_k1(d_in) + 4) + MP_H * MP_S2 + 3 * MP_H + 4); }
+
+__global__ __launch_bounds__(512, 1) void k_mlp_predict128(MlpPredictArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float mps[];
+  const int d_in = a.d_in, K1 = mp_k1(d_in), S1 = K1 + 4, NQ = K1 / 8;
+  float* W1s = mps;                       // [128][S1]   (columns d_in .. K1 - 1 zero)
+  float* W2s = W1s + MP_H * S1;           // [128][132]
+  float* b1s = W2s + MP_H * MP_S2;        // [128]
+  float* b2s = b1s + MP_H;
+  float* w3s = b2s + MP_H;
+  float* b3s = w3s + MP_H;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t oB1 = (int64_t)MP_H * d_in, oW2 = oB1 + MP_H, oB2 = oW2 + (int64_t)MP_H * MP_H, oW3 = oB2 + MP_H, oB3 = oW3 + MP_H;
+  for (int i = tid; i < MP_H * S1; i += 512) { const int u = i / S1, f = i - u * S1; W1s[i] = f < d_in ? a.params[(int64_t)u * d_in + f] : 0.f; }
+  for (int i = tid; i < MP_H * MP_H / 4; i += 512) {
+    const int u = (4 * i) / MP_H, c = (4 * i) % MP_H;
+    *(f32x4*)&W2s[u * MP_S2 + c] = *(const f32x4*)&a.params[oW2 + 4 * (int64_t)i];       // (W2 starts 16-byte aligned when d_in * 128 + 128 is a multiple of 4: always)
+  }
+  if (tid < MP_H) { b1s[tid] = a.params[oB1 + tid]; b2s[tid] = a.params[oB2 + tid]; w3s[tid] = a.params[oW3 + tid]; }
+  if (tid == 0) b3s[0] = a.params[oB3];
+  __syncthreads();
+  const float b3 = b3s[0];
+  const int64_t ntiles = (a.N + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
+    const int64_t s0 = tile * 32 + j;
+    const bool valid = s0 < a.N;
+    const float* __restrict__ xr = a.feat + (valid ? s0 : 0) * (int64_t)d_in;
+    // layer 1: this lane's features in the k-permuted order of its half
+    f32x16 h1[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h1[mb] = (f32x16)(0.f);
+    for (int q = 0; q < NQ; ++q) {
+      float xb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const int f = 8 * q + 4 * hi + t; const float v = xr[f < d_in ? f : 0]; xb[t] = (valid && f < d_in) ? v : 0.f; }
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const f32x4 a4 = *(const f32x4*)&W1s[(32 * mb + j) * S1 + 8 * q + 4 * hi];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h1[mb] = MJX_MFMA(a4[t], xb[t], h1[mb]);
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h1[mb][r] = fmaxf(h1[mb][r] + b1s[32 * mb + unit_of(r, hi)], 0.f);
+    // layer 2 + output: register r of h1[mb] holds unit 32 mb + unit_of(r, hi) -- the B operand of k-step (mb, r) as it lies
+    float ysum = 0.f;
+#pragma unroll 1
+    for (int ob = 0; ob < 4; ++ob) {
+      f32x16 acc = (f32x16)(0.f);
+      const float* wrow = &W2s[(32 * ob + j) * MP_S2 + 4 * hi];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const f32x4 a4 = *(const f32x4*)(wrow + 32 * mb + 8 * rq);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc = MJX_MFMA(a4[t], h1[mb][4 * rq + t], acc);
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int u = 32 * ob + unit_of(r, hi);
+        ysum = fmaf(fmaxf(acc[r] + b2s[u], 0.f), w3s[u], ysum);
+      }
+    }
+    const float y = half_sum(ysum) + b3;
+    if (hi == 0 && valid) a.out[s0] = y;
+  }
+}
+
 }  // namespace mjx

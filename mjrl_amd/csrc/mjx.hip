@@ -523,6 +523,28 @@ int mjx_bl_predict(int kind, const double* obs, const int32_t* tpos, int64_t N, 
 int mjx_mlp_predict(const float* feat, int64_t N, int d_in, const int* hidden, int n_hidden, const float* params, float* out, void* stream) {
   if (!feat || !params || !out || N < 0 || d_in <= 0 || n_hidden < 0 || (n_hidden && !hidden)) return fail(MJX_ERR_ARG, "bad arguments");
   if (N == 0) return MJX_OK;
+  {
+    // the reference's default value network (128 x 128 ReLU) in one launch: csrc/baseline.h k_mlp_predict128 (MJX_MLP_PREDICT_FUSED=0: A/B)
+    const char* e = getenv("MJX_MLP_PREDICT_FUSED");
+    if (!(e && e[0] == '0') && n_hidden == 2 && hidden[0] == 128 && hidden[1] == 128 && d_in <= 64 && (((uintptr_t)params) & 15) == 0 &&
+        mlp_predict_lds_bytes(d_in) <= (size_t)160 * 1024) {
+      int dev = 0, ncu = 256;
+      HIPCHK(hipGetDevice(&dev));
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+      static thread_local std::vector<std::pair<int, size_t>> configured;      // (device, bytes): the dynamic-LDS limit is per device
+      const size_t bytes = mlp_predict_lds_bytes(d_in);
+      size_t* have = nullptr;
+      for (auto& c : configured) if (c.first == dev) have = &c.second;
+      if (!have) { configured.push_back({dev, 0}); have = &configured.back().second; }
+      if (*have < bytes) { HIPCHK(hipFuncSetAttribute((const void*)k_mlp_predict128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); *have = bytes; }
+      const int64_t ntiles = (N + 31) / 32;
+      const int64_t want = (ntiles + 7) / 8;
+      MlpPredictArgs pa{feat, params, out, N, d_in};
+      hipLaunchKernelGGL(k_mlp_predict128, dim3((unsigned)(want < ncu ? want : ncu)), dim3(512), bytes, (hipStream_t)stream, pa);
+      HIPCHK(hipGetLastError());
+      return MJX_OK;
+    }
+  }
   MlpRegressor net; net.init(d_in, hidden, n_hidden);
   const int64_t CH = 1 << 17;
   size_t per_row = 0; for (int i = 0; i < n_hidden; ++i) per_row += hidden[i];

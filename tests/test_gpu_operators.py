@@ -725,6 +725,42 @@ def test_train_step_streams_its_rollouts_and_changes_nothing(monkeypatch):
     ingest.drop_shared()
 
 
+@pytest.mark.parametrize("d_in", [5, 8, 9, 21, 24, 25, 43, 63, 64])
+def test_fused_mlp_predict_equals_the_layerwise_forward_and_numpy(monkeypatch, d_in):
+    """r06: mjx_mlp_predict for the reference's default value network ((n + 4) -> 128 -> 128 -> 1, ReLU: mlp_baseline.py:21-28) is ONE
+    launch of k_mlp_predict128 (chained MFMA accumulators, weights in LDS) instead of three GEMM launches per 131 072-row chunk.  Against
+    the layer-by-layer route (MJX_MLP_PREDICT_FUSED=0) and an fp64 NumPy forward, row counts around the 32-sample tile and the grid edges."""
+    import ctypes
+    import torch
+    from mjrl_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(100 + d_in)
+    P = 128 * d_in + 128 + 128 * 128 + 128 + 128 + 1
+    params = (rng.randn(P) / np.sqrt(np.concatenate([np.full(128 * d_in + 128, d_in), np.full(128 * 128 + 128, 128.0), np.full(129, 128.0)]))).astype(np.float32)
+    W1 = params[:128 * d_in].reshape(128, d_in).astype(np.float64); b1 = params[128 * d_in:128 * d_in + 128].astype(np.float64)
+    o = 128 * d_in + 128
+    W2 = params[o:o + 128 * 128].reshape(128, 128).astype(np.float64); b2 = params[o + 128 * 128:o + 128 * 128 + 128].astype(np.float64)
+    o += 128 * 128 + 128
+    W3 = params[o:o + 128].astype(np.float64); b3 = float(params[o + 128])
+    pt = torch.from_numpy(params).cuda()
+    hid = (ctypes.c_int * 2)(128, 128)
+    for N in (1, 31, 32, 33, 257, 8191, 100003, 400000):
+        X = rng.randn(N, d_in).astype(np.float32)
+        xt = torch.from_numpy(X).cuda()
+        outs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MJX_MLP_PREDICT_FUSED", mode)
+            out = torch.full((N,), float("nan"), dtype=torch.float32, device="cuda")
+            _lib.check(lib.mjx_mlp_predict(_lib.ptr(xt), N, d_in, hid, 2, _lib.ptr(pt), _lib.ptr(out), None))
+            torch.cuda.synchronize()
+            outs[mode] = out.cpu().numpy().astype(np.float64)
+        ref = np.maximum(np.maximum(X.astype(np.float64) @ W1.T + b1, 0) @ W2.T + b2, 0) @ W3 + b3
+        scale = np.abs(ref).max() + 1e-12
+        assert np.all(np.isfinite(outs["1"]))
+        assert np.abs(outs["1"] - ref).max() < 3e-6 * scale, (N, np.abs(outs["1"] - ref).max() / scale)
+        assert np.abs(outs["1"] - outs["0"]).max() < 3e-6 * scale, (N, np.abs(outs["1"] - outs["0"]).max() / scale)
+
+
 @pytest.mark.parametrize("d_in", [9, 21, 23, 27, 35, 43, 50, 55, 56, 64, 96, 97, 115, 380, 768, 769])
 def test_persistent_mlp_trainer_equals_per_step_launches(monkeypatch, d_in):
     """The persistent single-workgroup trainer of the MLP baseline (csrc/mlp_fit.h; two 32-feature blocks of the input
