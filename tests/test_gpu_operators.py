@@ -755,7 +755,7 @@ def test_fused_mlp_predict_equals_the_layerwise_forward_and_numpy(monkeypatch, d
             torch.cuda.synchronize()
             outs[mode] = out.cpu().numpy().astype(np.float64)
         ref = np.maximum(np.maximum(X.astype(np.float64) @ W1.T + b1, 0) @ W2.T + b2, 0) @ W3 + b3
-        scale = np.abs(ref).max() + 1e-12
+        scale = max(np.abs(ref).max(), 0.25)           # (a lone sample's output can be a small difference of O(0.3) terms)
         assert np.all(np.isfinite(outs["1"]))
         assert np.abs(outs["1"] - ref).max() < 3e-6 * scale, (N, np.abs(outs["1"] - ref).max() / scale)
         assert np.abs(outs["1"] - outs["0"]).max() < 3e-6 * scale, (N, np.abs(outs["1"] - outs["0"]).max() / scale)
