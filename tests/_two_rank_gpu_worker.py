@@ -21,6 +21,9 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n, m, hid, N = 17, 6, (64, 64), 60000
+    if os.environ.get("MJX_TEST_SHAPE"):                 # "n,m,h1,h2": another fused instance (e.g. one whose d is not a multiple of 4)
+        n, m, h1, h2 = (int(v) for v in os.environ["MJX_TEST_SHAPE"].split(","))
+        hid = (h1, h2)
     rng = np.random.RandomState(5)                       # identical on all ranks
     obs, act, adv = rng.randn(N, n).astype(np.float32), rng.randn(N, m).astype(np.float32), rng.randn(N).astype(np.float32)
     cut = int(os.environ.get("MJX_TEST_CUT", "23456"))   # ragged shards (0: rank 0 holds NO trajectories)

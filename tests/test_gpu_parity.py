@@ -321,7 +321,7 @@ def test_shard_sum_parity():
     eng.close()
 
 
-@pytest.mark.parametrize("transport,cut", [("peer", 23456), ("hook", 23456), ("peer", 0), ("peer3", 20000), ("peer8", 7000)])
+@pytest.mark.parametrize("transport,cut", [("peer", 23456), ("hook", 23456), ("peer", 0), ("peer3", 20000), ("peer8", 7000), ("peer-odd-d", 31000)])
 def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport, cut):
     """The multi-rank control flow on real kernels: two processes (torch.distributed.run) share the GPU, each binds a ragged
     trajectory shard and runs the engine's update sequence (K1 + rank sum, the per-iteration FVP / rank sum / CG-step loop,
@@ -334,6 +334,8 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport, cut):
     line search, DAPG as one call); all ranks hold bit-identical vectors.
     "peer3" (r04): THREE processes on the GPU -- the peer exchange with one arrival flag per source rank beyond two ranks (a 4-slot
     sum with one slot of zeros; ADVICE r03 asked for >= 3 ranks: this covers the protocol, not the ordering of real xGMI links).
+    "peer-odd-d" (r06): a 32 x 32 policy with 5 observations and 3 actions -- d = 1 350 is not a multiple of 4, so the vector exchanges are
+    NOT folded into the loop's kernels (generic push / sum launches) while the kernels still write accumulator-order partials.
     "peer8" (r06): EIGHT processes on the GPU, the world size of the north-star's node -- 8 per-source flags, the 8-slot sums of
     k_cg_init_w / k_cg_step_reg<8, 8>, both slot parities, one rank (3) without any trajectory (the generic exchange next to the
     folded ones); the gradient and K1's sums travel in ONE exchange, the step is formed by the solve's last kernel."""
@@ -343,11 +345,14 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport, cut):
     from mjrl_amd.engine import UpdateEngine
     out = str(tmp_path / "two_rank.npz")
     port = 29600 + (os.getpid() % 300)
+    odd = transport == "peer-odd-d"
+    if odd:
+        transport = "peer"
     world = 3 if transport == "peer3" else 8 if transport == "peer8" else 2
     cuts3 = [20000, 41000] if world != 8 else [7000, 15000, 22000, 22000, 38000, 45000, 52500]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MJX_PEER_COMM="1" if transport.startswith("peer") else "0",
-               MJX_TEST_CUT=str(cut), MJX_TEST_CUTS=",".join(str(c) for c in cuts3))
-    port += (7 if transport == "peer" else 0) + (13 if cut == 0 else 0) + (29 if world == 3 else 0) + (41 if world == 8 else 0)
+               MJX_TEST_CUT=str(cut), MJX_TEST_CUTS=",".join(str(c) for c in cuts3), **({"MJX_TEST_SHAPE": "5,3,32,32"} if odd else {}))
+    port += (7 if transport == "peer" else 0) + (13 if cut == 0 else 0) + (29 if world == 3 else 0) + (41 if world == 8 else 0) + (53 if odd else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "_two_rank_gpu_worker.py"), out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280 if world < 8 else 900)
@@ -357,10 +362,11 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport, cut):
     assert two["native_comm"].all(), "the rank sums must run inside libmjx's C loops (mjx_cg_solve / mjx_npg_update)"
     assert str(two["comm_kind"][0]) == ("peer" if world > 2 else transport)
     assert bool(two["one_call_equal"][0]), "mjx_npg_update != the call-by-call sequence on two ranks"
-    n, m, hid, N = 17, 6, (64, 64), 60000
+    n, m, hid, N = (5, 3, (32, 32), 60000) if odd else (17, 6, (64, 64), 60000)
     rng = np.random.RandomState(5)
     obs, act, adv = rng.randn(N, n).astype(np.float32), rng.randn(N, m).astype(np.float32), rng.randn(N).astype(np.float32)
     th = synth.perturbed_params(synth.init_params(n, m, hid))
+    assert (th.size % 4 != 0) == odd
     ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
     eng = UpdateEngine(n, m, hid)
     eng.set_policy(th, th, ident, ident)
@@ -378,7 +384,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, transport, cut):
     # TRPO with the device-side line search: same number of trials, same step length / KL / parameters as on one rank
     eng.set_policy(th, th, ident, ident)
     tr = eng.trpo_update(10, 1e-4, 0.02, 0.002, -3.0)
-    assert two["trpo"][4] == 1.0 and tr["accepted"] and int(two["trpo"][1]) == tr["trials"] and tr["trials"] > 3
+    assert two["trpo"][4] == 1.0 and tr["accepted"] and int(two["trpo"][1]) == tr["trials"] and (tr["trials"] > 3 or odd)
     np.testing.assert_allclose(two["trpo"][[0, 2, 3]], [tr["alpha"], tr["kl"], tr["surr_after"]], rtol=2e-5, atol=1e-7)
     assert rel(two["trpo_theta"], eng.theta_new.cpu().numpy()) < 1e-6
     # DAPG: the ranks' blocks are [on-policy ; demonstrations] each; one rank sees the same rows as [all on-policy ; all demonstrations]
