@@ -519,11 +519,23 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
     for (int r = 0; r < RA; ++r) { kc3r[r] = cst[9 * MP + 2 * unit_of(r, hi)]; kcsr[r] = cst[9 * MP + 2 * unit_of(r, hi) + 1]; }
   }
+  // One wave-uniform base (scalar registers, formed on the scalar unit) + the lane's 32-bit byte offset + an immediate: no
+  // vector-ALU address arithmetic per access.  (readfirstlane of a uniform value is a scalar move; it keeps the compiler from
+  // folding the steps back into 64-bit vector adds.)
+  typedef const char __attribute__((address_space(1)))* gcptr;
+  typedef char __attribute__((address_space(1)))* gwptr;
+  typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));          // a register pair at a 4-byte-aligned address
+  auto ubase = [&](const float* p) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (gcptr)(((uint64_t)hi32 << 32) | lo);
+  };
   constexpr int OC_TILE = (MP + 1) * 32;
   float ocn[MP + 1];                              // next tile's old-policy outputs (MODE_EVAL)
   auto load_oc = [&](int64_t t) {
+    gcptr b = ubase(A.ocache + t * OC_TILE);
 #pragma unroll
-    for (int a = 0; a <= MP; ++a) ocn[a] = A.ocache[t * OC_TILE + a * 32 + j];
+    for (int a = 0; a <= MP; ++a) ocn[a] = *(const float __attribute__((address_space(1)))*)(b + (uint32_t)(j * 4) + a * 128);
   };
 
   MJX_GSTAMP(17);
@@ -539,7 +551,8 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   constexpr int NFQ = NPC ? NPC / 4 : 1;
   f32x4 gW1q[MT1][NFQ];
   f32x4 gW3[NT3];
-  f32x4 gW3b[XCACHED ? NT3 : 1];      // cached FVP: a second set (odd sample quads), so that 4 chains of 4x4x1 MFMAs are in flight
+  constexpr bool G3B = XCACHED || (MODE == MODE_VPG && !DBG && NT3 < 4);
+  f32x4 gW3b[G3B ? NT3 : 1];          // cached FVP, K1 (r06): a second set (odd sample quads), so that 4 chains of 4x4x1 MFMAs are in flight
   float sb2[MT2], sb3r[RA], gls[RA];      // grad b2[32*nt + j] (every lane); grad b3 / grad log_std of action unit_of(r, hi), this lane's samples
 #pragma unroll
   for (int a = 0; a < MT1; ++a)
@@ -556,7 +569,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
   for (int a = 0; a < NT3; ++a) gW3[a] = (f32x4)(0.f);
 #pragma unroll
-  for (int a = 0; a < (XCACHED ? NT3 : 1); ++a) gW3b[a] = (f32x4)(0.f);
+  for (int a = 0; a < (G3B ? NT3 : 1); ++a) gW3b[a] = (f32x4)(0.f);
 #pragma unroll
   for (int a = 0; a < RA; ++a) { gls[a] = 0.f; sb3r[a] = 0.f; }
 #pragma unroll
@@ -593,15 +606,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   // same registers as soon as the current ones are dead (behind the weight-gradient products), so nothing is copied.
   f32x16 hn1[MT1], hn2[MT2];
   f32x2 xc[NQC];
-  // One wave-uniform base per 4 KB of the tile's cache lines (scalar registers, formed on the scalar unit) + the lane's
-  // 32-bit byte offset + an immediate: no vector-ALU address arithmetic per load.  (readfirstlane of a uniform value is a
-  // scalar move; it keeps the compiler from folding the 4 KB steps back into 64-bit vector adds.)
-  typedef const char __attribute__((address_space(1)))* gcptr;
-  auto ubase = [&](const float* p) {
-    const uint64_t a = (uint64_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    return (gcptr)(((uint64_t)hi32 << 32) | lo);
-  };
+  // (one wave-uniform base per 4 KB of the tile's cache lines: ubase above)
   auto load_h = [&](int64_t t) {
     const float* tb = A.hcache + t * HC_TILE;
     if (NPC) {
@@ -630,8 +635,52 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   };
 
   auto load_xi = [&](int64_t t) {                 // MODE_EVAL with K1's observation image: the layer-1 operand pairs of tile t
+    gcptr xb = ubase(A.hcache + t * HC_TILE + HC_H);
 #pragma unroll
-    for (int q = 0; q < NQC; ++q) xc[q] = *(const f32x2*)(A.hcache + t * HC_TILE + HC_H + (q * 64 + lane) * 2);
+    for (int q = 0; q < NQC; ++q) xc[q] = *(const f32x2 __attribute__((address_space(1)))*)(xb + (uint32_t)(lane * 8) + q * 512);
+  };
+
+  // K1 of the instances with a compile-time observation width (r06): the lane's layer-1 operand pairs come STRAIGHT from the
+  // observation block -- lane (sample j, half hi) needs features 4 q + 2 hi, + 1 of its row, a 4-byte-aligned pair per q at a byte
+  // offset that is the same in every tile (scalar tile base + pinned lane offset: no address arithmetic in the loop) -- one tile
+  // ahead into registers, normalised in ONE packed burst at the end of the previous tile.  The route through LDS it replaces
+  // (raw image, wave hand-over, per-value ds_read + subtract + multiply + two selects under divergent branches) cost K1 ~4 000 of
+  // its 26 900 cycles per tile (`tools/phase_clock_k1.py`: staging 2 500, layer 1 3 120 for 1 280 of MFMA).
+  // Only the last pair can hold the ones column (f == n) or padding (f > n): its two elements are fetched one by one, from the
+  // row's first element where f >= n (in bounds; shift and reciprocal scale are 0 there, the value drops out), and the 1 comes in
+  // as the addend of a packed FMA.  Rows past the batch end (last tile only, a uniform branch): fetched from the tile's first row, zeroed.
+  constexpr bool DIRX = (MODE == MODE_VPG) && NPC != 0 && !DBG;
+  constexpr int NQX = DIRX ? NPC / 4 : 1;
+  f32x2 xn[NQX], xw[NQX];                         // this tile's normalised pairs ; the next tile's raw pairs
+  uint32_t xo[NQX + 1];
+  f32x2 onep = {0.f, 0.f};
+  auto set_xoff = [&](uint32_t (&o)[NQX + 1], uint32_t row) {
+#pragma unroll
+    for (int q = 0; q + 1 < NQX; ++q) o[q] = (row * (uint32_t)n + 4 * q + 2 * hi) * 4;
+    const int f0 = NPC - 4 + 2 * hi;
+    o[NQX - 1] = (row * (uint32_t)n + (f0 < n ? f0 : 0)) * 4;
+    o[NQX] = (row * (uint32_t)n + (f0 + 1 < n ? f0 + 1 : 0)) * 4;
+  };
+  auto load_xw = [&](f32x2 (&w)[NQX], const uint32_t (&o)[NQX + 1], int64_t t) {
+    gcptr b = ubase(A.obs + t * 32 * (int64_t)n);
+#pragma unroll
+    for (int q = 0; q + 1 < NQX; ++q) { const f32x2u v = *(const f32x2u __attribute__((address_space(1)))*)(b + o[q]); w[q] = f32x2{v.x, v.y}; }
+    w[NQX - 1].x = *(const float __attribute__((address_space(1)))*)(b + o[NQX - 1]);
+    w[NQX - 1].y = *(const float __attribute__((address_space(1)))*)(b + o[NQX]);
+  };
+  // x~ = (x - shift) * (1 / (scale + 1e-8)) pair by pair (the same two roundings as the scalar form); `t` = the tile the raw pairs belong to
+  auto norm_xw = [&](f32x2 (&dst)[NQX], const f32x2 (&w)[NQX], const float* tsh, const float* tsc, int64_t t) {
+#pragma unroll
+    for (int q = 0; q < NQX; ++q) {
+      const f32x2 sh = *(const f32x2*)&tsh[4 * q + 2 * hi], sc = *(const f32x2*)&tsc[4 * q + 2 * hi];
+      const f32x2 d = w[q] - sh;
+      dst[q] = (q == NQX - 1) ? __builtin_elementwise_fma(d, sc, onep) : d * sc;
+    }
+    if ((t + 1) * 32 > A.N) {                     // the batch's last, partial tile
+      const bool vl = t * 32 + j < A.N;
+#pragma unroll
+      for (int q = 0; q < NQX; ++q) { dst[q].x = vl ? dst[q].x : (q == NQX - 1 ? onep.x : 0.f); dst[q].y = vl ? dst[q].y : (q == NQX - 1 ? onep.y : 0.f); }
+    }
   };
 
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -659,9 +708,26 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
     for (int g = 0; g < 4 * MT2; ++g) pinW[g] = lds_pin(&slotA[L.oW2 + (8 * g + 4 * hi) * S2 + j]);
   }
+  float sum_lsA = 0.f, sum_lsB = 0.f;             // sum of log_std over the actions (new, old): constants of the likelihood head
+  if (MODE != MODE_FVP) {
+#pragma unroll
+    for (int a = 0; a < MP; ++a) { sum_lsA += cst[C_LS * MP + a]; sum_lsB += cst[C_LSB * MP + a]; }
+  }
+  uint32_t aoff = (uint32_t)(j * m * 4);          // the lane's row in a tile of the action block
+  asm volatile("" : "+v"(aoff));
   const bool rev = XCACHED && A.reverse;
   auto ptile = [&](int64_t t) { return rev ? ntiles - 1 - t : t; };          // logical -> physical tile of this launch
-  if (!XCACHED && !use_xi && tile < ntiles) load_x(tile);
+  if constexpr (DIRX) {
+    const int f0 = NPC - 4 + 2 * hi;
+    onep = f32x2{f0 == n ? 1.0f : 0.f, f0 + 1 == n ? 1.0f : 0.f};
+    set_xoff(xo, (uint32_t)j);
+    if (tile < ntiles) {
+      if ((tile + 1) * 32 > A.N) set_xoff(xo, (tile * 32 + j < A.N) ? (uint32_t)j : 0u);
+      load_xw(xw, xo, tile);
+      norm_xw(xn, xw, trs, trs + NP, tile);
+    }
+  }
+  if (!DIRX && !XCACHED && !use_xi && tile < ntiles) load_x(tile);
   if (XCACHED && tile < ntiles) load_h(ptile(tile));
   if (MODE == MODE_EVAL && use_oc && tile < ntiles) load_oc(tile);
   if (MODE == MODE_EVAL && use_xi && tile < ntiles) load_xi(tile);
@@ -1096,11 +1162,34 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
     // this tile's actions / advantage: requested now, consumed by the likelihood head two layers later
     float actr[MP], advr = 0.f;
     if (MODE != MODE_FVP) {
+      if (s0 + 32 + MP <= A.N) {
+        // every tile but the batch's last one or two: the lane's MP values from its row on (a >= m: the next row's, dropped below) at
+        // scalar tile base + pinned lane offset + immediate -- no address arithmetic, no selects
+        gcptr ab = ubase(A.act + s0 * m);
+        gcptr db = ubase(A.adv + s0);
 #pragma unroll
-      for (int a = 0; a < MP; ++a) actr[a] = A.act[(valid && a < m) ? (s0 + j) * m + a : 0];
-      advr = A.adv[valid ? s0 + j : 0];
+        for (int a = 0; a < MP; ++a) actr[a] = *(const float __attribute__((address_space(1)))*)(ab + aoff + 4 * a);
+        advr = *(const float __attribute__((address_space(1)))*)(db + (uint32_t)(j * 4));
+      } else {
+#pragma unroll
+        for (int a = 0; a < MP; ++a) actr[a] = A.act[(valid && a < m) ? (s0 + j) * m + a : 0];
+        advr = A.adv[valid ? s0 + j : 0];
+      }
     }
-    if (!XCACHED && !XI) {
+    if constexpr (DIRX) {
+      // the next tile's raw pairs: in flight under this whole tile, normalised behind its last MFMA phase
+      const int64_t tn = tile + tstride;
+      if (tn < ntiles) {
+        if ((tn + 1) * 32 > A.N) set_xoff(xo, (tn * 32 + j < A.N) ? (uint32_t)j : 0u);
+        load_xw(xw, xo, tn);
+      }
+      if (A.hcache) {                               // the operand image for the Fisher-vector products / K3: one batch of stores
+        gwptr xb = (gwptr)ubase(A.hcache + tile * HC_TILE + HC_H);
+#pragma unroll
+        for (int q = 0; q < NQX; ++q) *(f32x2 __attribute__((address_space(1)))*)(xb + (uint32_t)(lane * 8) + q * 512) = xn[q];
+      }
+    }
+    if (!DIRX && !XCACHED && !XI) {
 #pragma unroll
       for (int c = 0; c < XL4; ++c) {
         const int e4 = c * 64 + lane;
@@ -1116,7 +1205,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
     //   TAN == false: h1 = tanh(W1a x~), h2 = tanh(W2 h1 + b2)                      (slot)
     //   TAN == true : additionally t1 = (V1a x~)(1-h1^2), t2 = (V2 h1 + W2 t1 + c2)(1-h2^2) (slotB)
     auto layers12 = [&](auto tan_tag, const float* slot, const float* tsh, const float* tsc, bool writeT,
-                        f32x16 (&h1)[MT1], f32x16 (&h2)[MT2], f32x16 (&t1)[MT1], f32x16 (&t2)[MT2]) {
+                        f32x16 (&h1)[MT1], f32x16 (&h2)[MT2], f32x16 (&t1)[MT1], f32x16 (&t2)[MT2], const f32x2 (&xdir)[NQX]) {
       constexpr bool TAN = decltype(tan_tag)::value;
       constexpr bool FWD = !(TAN && CACHED);          // cached FVP: h1 / h2 arrive from HBM, only the tangent products run
       f32x16 z1[MT1];
@@ -1140,6 +1229,8 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
             if constexpr (NPC != 0) return xc[q]; else return *(const f32x2*)(ximg + q * 128);
           } else if constexpr (XI) {
             return xc[q];
+          } else if constexpr (DIRX) {
+            return xdir[q];
           } else {
             const int f = 4 * q + 2 * hi;
             return f32x2{xnorm(f), xnorm(f + 1)};
@@ -1159,7 +1250,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
           f32x2 wn[MT1], vn[MT1];
           const f32x2 xnx = xpair((q + 1 < NP / 4) ? q + 1 : q);
           const float xn0 = xnx.x, xn1 = xnx.y;
-          if (MODE == MODE_VPG && writeT && A.hcache) *(f32x2*)(A.hcache + tile * HC_TILE + HC_H + (q * 64 + lane) * 2) = f32x2{xb0, xb1};
+          if (!DIRX && MODE == MODE_VPG && writeT && A.hcache) *(f32x2*)(A.hcache + tile * HC_TILE + HC_H + (q * 64 + lane) * 2) = f32x2{xb0, xb1};
 #pragma unroll
           for (int mt = 0; mt < MT1; ++mt) {
             if (FWD) wn[mt] = *(const f32x2*)&slot[L.oW1 + (32 * mt + j) * S1 + f1];
@@ -1184,20 +1275,28 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       }
       MJX_STAMP(2);
       if (XI && tile + tstride < ntiles) load_xi(tile + tstride);      // xc is dead: the next tile's image flies under the rest of this one
+      // (forward-only passes: tanh as ONE burst between the layers' matrix instructions -- hipcc otherwise feeds layer 2 "just in
+      //  time", a few exp / rcp between every four MFMAs, and on this chip a vector-ALU instruction in an MFMA gap costs 8 cycles
+      //  on top of its own; with two waves per SIMD (K3) the burst runs at raised priority so that the other wave's MFMAs do not
+      //  cut it into such gaps either)
+      constexpr bool BURST = !TAN && !DBG;
+      if constexpr (BURST) { __builtin_amdgcn_sched_barrier(0); if (EV2) __builtin_amdgcn_s_setprio(3); }
 #pragma unroll
       for (int mt = 0; mt < MT1; ++mt) {
         if (FWD) fast_tanh16(h1[mt], z1[mt]);
         if (TAN) pk_mul_1mh2(t1[mt], h1[mt]);
       }
+      if constexpr (BURST) { if (EV2) __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
       if (MODE == MODE_VPG && writeT && A.hcache) {
         // keep h1 for the Fisher-vector products of this update (theta is fixed during CG); issued here so that the
         // stores drain under the layer-2 MFMAs
-        float* base = A.hcache + tile * HC_TILE + lane * 4;
 #pragma unroll
-        for (int mt = 0; mt < MT1; ++mt)
+        for (int mt = 0; mt < MT1; ++mt) {
+          gwptr base = (gwptr)ubase(A.hcache + tile * HC_TILE + mt * 1024);
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            *(f32x4*)(base + (mt * 4 + q) * 256) = f32x4{h1[mt][4 * q], h1[mt][4 * q + 1], h1[mt][4 * q + 2], h1[mt][4 * q + 3]};
+            *(f32x4 __attribute__((address_space(1)))*)(base + (uint32_t)(lane * 16) + q * 1024) = f32x4{h1[mt][4 * q], h1[mt][4 * q + 1], h1[mt][4 * q + 2], h1[mt][4 * q + 3]};
+        }
       }
       MJX_STAMP(3);
       // layer 2: accumulators start at the bias (b2 / c2), K = h1 units chained from registers
@@ -1296,8 +1395,10 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
           for (int r = 0; r < 16; ++r) t2[mt][r] *= fmaf(-h2[mt][r], h2[mt][r], 1.0f);
       } else {
+        if constexpr (BURST) { __builtin_amdgcn_sched_barrier(0); if (EV2) __builtin_amdgcn_s_setprio(3); }
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) fast_tanh16(h2[mt], z2[mt]);
+        if constexpr (BURST) { if (EV2) __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
       }
     };
 
@@ -1317,17 +1418,28 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
       for (int gp = 0; gp < NGRP; ++gp) w[gp] = *(const f32x4*)(wbase + 4 * gp * S3);
     };
+    // (r06: two accumulator chains per action group where there are fewer than four groups -- with NGRP = 2 an accumulator
+    //  recurred every second instruction and every dependent 4x4x1 waited for its producer: the cached product's R4 rule)
     auto out_small = [&](f32x4 (&og)[NGRP], const float* slot, const f32x16 (&v)[MT2]) {
-      f32x4 w[NGRP];
+      constexpr int CH = (NGRP >= 4) ? 1 : 2;
+      f32x4 w[NGRP], o2[NGRP];
       out_frag(w, slot);
+#pragma unroll
+      for (int gp = 0; gp < NGRP; ++gp) o2[gp] = (f32x4)(0.f);
       static_for<MT2 * 4>([&](auto st) {
         constexpr int mt = decltype(st)::value >> 2, q = decltype(st)::value & 3;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int gp = 0; gp < NGRP; ++gp)
-            og[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[gp][t], v[mt][4 * q + t], og[gp], 3, mt * 4 + q, 0);
+          for (int gp = 0; gp < NGRP; ++gp) {
+            if (CH == 2 && (t & 1)) o2[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[gp][t], v[mt][4 * q + t], o2[gp], 3, mt * 4 + q, 0);
+            else og[gp] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[gp][t], v[mt][4 * q + t], og[gp], 3, mt * 4 + q, 0);
+          }
       });
+      if (CH == 2) {
+#pragma unroll
+        for (int gp = 0; gp < NGRP; ++gp) og[gp] += o2[gp];
+      }
     };
     // the same with two independent accumulator sets (out = Wa va + Wb vb): twice the distance between
     // dependent 4x4x1 MFMAs, which otherwise stall on their own 8-cycle predecessors
@@ -1360,16 +1472,17 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
     f32x16 (&h1)[MT1] = XCACHED ? hn1 : h1l;
     f32x16 (&h2)[MT2] = XCACHED ? hn2 : h2l;
     f32x16 t1[MT1], t2[MT2];                        // tangent activations (FVP only)
-    if (MODE == MODE_FVP) layers12(std::true_type{}, slotA, trs, trs + NP, true, h1, h2, t1, t2);
-    else layers12(std::false_type{}, slotA, trs, trs + NP, MODE != MODE_EVAL, h1, h2, t1, t2);
+    if (MODE == MODE_FVP) layers12(std::true_type{}, slotA, trs, trs + NP, true, h1, h2, t1, t2, xn);
+    else layers12(std::false_type{}, slotA, trs, trs + NP, MODE != MODE_EVAL, h1, h2, t1, t2, xn);
     if (MODE == MODE_VPG && A.hcache) {
       // ... and h2 (h1 was stored right after its tanh)
-      float* base = A.hcache + tile * HC_TILE + lane * 4;
 #pragma unroll
-      for (int mt = 0; mt < MT2; ++mt)
+      for (int mt = 0; mt < MT2; ++mt) {
+        gwptr base = (gwptr)ubase(A.hcache + tile * HC_TILE + (MT1 + mt) * 1024);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *(f32x4*)(base + ((MT1 + mt) * 4 + q) * 256) = f32x4{h2[mt][4 * q], h2[mt][4 * q + 1], h2[mt][4 * q + 2], h2[mt][4 * q + 3]};
+          *(f32x4 __attribute__((address_space(1)))*)(base + (uint32_t)(lane * 16) + q * 1024) = f32x4{h2[mt][4 * q], h2[mt][4 * q + 1], h2[mt][4 * q + 2], h2[mt][4 * q + 3]};
+      }
     }
 
     MJX_STAMP(6);
@@ -1424,14 +1537,27 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       }
     } else {
       // ---- likelihoods (mean_LL, gaussian_mlp.py:99-115); each lane owns the actions a = unit_of(r, hi)
-      float sum_lsA = 0.f, sum_lsB = 0.f;
-#pragma unroll
-      for (int a = 0; a < MP; ++a) { sum_lsA += cst[C_LS * MP + a]; sum_lsB += cst[C_LSB * MP + a]; }
       const float llc = 0.5f * (float)m * 1.8378770664093453f;
+      // K1 (one wave per SIMD): the head's per-action constants are requested BEFORE the output layer's matrix instructions and
+      // tanh(z2) is finished before them -- a vector-ALU instruction between two MFMAs costs 8 cycles on top of its own, and a
+      // ds_read consumed right behind its issue is a full LDS round trip (r06: this phase took 2 556 cycles for 512 of MFMA
+      // and ~110 vector-ALU instructions).  K3 keeps the reads at their use: two waves per SIMD, 231 of 256 registers.
+      constexpr bool HK = (MODE == MODE_VPG) && !DBG;
+      f32x4 kb3[HK ? NGRP : 1], kosc[HK ? NGRP : 1], kosh[HK ? NGRP : 1], kisg[HK ? NGRP : 1];
+      if constexpr (HK) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gp = 0; gp < NGRP; ++gp) {
+          kb3[gp] = *(const f32x4*)&slotA[L.oB3 + 4 * gp]; kosc[gp] = *(const f32x4*)&cst[C_OSC * MP + 4 * gp];
+          kosh[gp] = *(const f32x4*)&cst[C_OSH * MP + 4 * gp]; kisg[gp] = *(const f32x4*)&cst[C_ISG * MP + 4 * gp];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       f32x4 og[NGRP];
 #pragma unroll
       for (int gp = 0; gp < NGRP; ++gp) og[gp] = (f32x4)(0.f);
       out_small(og, slotA, h2);
+      if constexpr (HK) __builtin_amdgcn_sched_barrier(0);
       float oa[MP];
       out_finish(og, oa);
       float z[MP], muv[MP], av[MP];
@@ -1440,8 +1566,13 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       for (int a = 0; a < MP; ++a) {
         const bool ok = valid && (a < m);
         av[a] = ok ? actr[a] : 0.f;
-        muv[a] = (oa[a] + slotA[L.oB3 + a]) * cst[C_OSC * MP + a] + cst[C_OSH * MP + a];
-        z[a] = (av[a] - muv[a]) * cst[C_ISG * MP + a];
+        if constexpr (HK) {
+          muv[a] = (oa[a] + kb3[a >> 2][a & 3]) * kosc[a >> 2][a & 3] + kosh[a >> 2][a & 3];
+          z[a] = (av[a] - muv[a]) * kisg[a >> 2][a & 3];
+        } else {
+          muv[a] = (oa[a] + slotA[L.oB3 + a]) * cst[C_OSC * MP + a] + cst[C_OSH * MP + a];
+          z[a] = (av[a] - muv[a]) * cst[C_ISG * MP + a];
+        }
         llA = fmaf(-0.5f * z[a], z[a], llA);
       }
       llA = llA - sum_lsA - llc;
@@ -1461,7 +1592,15 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         if (tile + tstride < ntiles) load_oc(tile + tstride);
       } else if (MODE == MODE_EVAL || !A.old_is_new) {
         f32x16 g1[MT1], g2[MT2];
-        layers12(std::false_type{}, slotB, trs + 2 * NP, trs + 3 * NP, false, g1, g2, t1, t2);
+        f32x2 xnB[NQX];
+        if constexpr (DIRX) {                       // the old network's input transform on the same rows (fetched again: L2)
+          uint32_t xoB[NQX + 1];
+          f32x2 xwB[NQX];
+          set_xoff(xoB, valid ? (uint32_t)j : 0u);
+          load_xw(xwB, xoB, tile);
+          norm_xw(xnB, xwB, trs + 2 * NP, trs + 3 * NP, tile);
+        }
+        layers12(std::false_type{}, slotB, trs + 2 * NP, trs + 3 * NP, false, g1, g2, t1, t2, xnB);
 #pragma unroll
         for (int gp = 0; gp < NGRP; ++gp) og[gp] = (f32x4)(0.f);
         out_small(og, slotB, g2);
@@ -1477,7 +1616,8 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         llB = llB - sum_lsB - llc;
       }
       const float advv = valid ? advr : 0.f;
-      float LR = expf(llA - llB);
+      // (old == new in K1: llB IS llA, the ratio is exp(0) = 1 exactly -- a uniform branch instead of the exponential's ~12 instructions)
+      float LR = (MODE == MODE_VPG && A.old_is_new) ? 1.0f : expf(llA - llB);
       if (valid && hi == 0) { s_surr += (double)(LR * advv); s_cnt += 1.0; }
       if (MODE == MODE_EVAL) {
         // mean_kl(new, old), gaussian_mlp.py:135-145
@@ -1495,7 +1635,8 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         float d3a[MP];
 #pragma unroll
         for (int a = 0; a < MP; ++a) {
-          d3a[a] = cst[C_OSC * MP + a] * ((w * z[a]) * cst[C_ISG * MP + a]);
+          if constexpr (HK) d3a[a] = kosc[a >> 2][a & 3] * ((w * z[a]) * kisg[a >> 2][a & 3]);
+          else d3a[a] = cst[C_OSC * MP + a] * ((w * z[a]) * cst[C_ISG * MP + a]);
         }
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
@@ -1575,6 +1716,22 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         for (int nt = 0; nt < MT2; ++nt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) fc[nt][q] = *(const f32x4*)&bufA[(32 * nt + j) * ST + 8 * q + 4 * hi];
+        if constexpr (G3B) {
+#pragma unroll
+          for (int sp = 0; sp < 4; ++sp) {                 // sample quads 2 sp (-> gW3) and 2 sp + 1 (-> gW3b), instruction by instruction
+            const f32x4 ave = *(const f32x4*)(arow + 8 * sp), avo = *(const f32x4*)(arow + 8 * sp + 4);
+            f32x4 bve[NT3], bvo[NT3];
+#pragma unroll
+            for (int nt = 0; nt < NT3; ++nt) { bve[nt] = *(const f32x4*)(brow + UPI3 * nt * ST + 8 * sp); bvo[nt] = *(const f32x4*)(brow + UPI3 * nt * ST + 8 * sp + 4); }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int nt = 0; nt < NT3; ++nt) {
+                gW3[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(ave[t], bve[nt][t], gW3[nt], 0, 0, 0);
+                gW3b[G3B ? nt : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(avo[t], bvo[nt][t], gW3b[G3B ? nt : 0], 0, 0, 0);
+              }
+          }
+        } else {
 #pragma unroll
         for (int s4 = 0; s4 < 8; ++s4) {
           const f32x4 av = *(const f32x4*)(arow + 4 * s4);
@@ -1585,6 +1742,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT3; ++nt) gW3[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[t], bv[nt][t], gW3[nt], 0, 0, 0);
+        }
         }
 #pragma unroll
         for (int nt = 0; nt < MT2; ++nt)
@@ -1736,6 +1894,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       }
     }
     MJX_STAMP(13);
+    if constexpr (DIRX) { if (tile + tstride < ntiles) norm_xw(xn, xw, trs, trs + NP, tile + tstride); }
     wave_sync();                                  // everything read before the next tile's staging
     }   // !XCACHED
   }
@@ -1791,7 +1950,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
       for (int nt = 0; nt < NT3; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mine[RS::oW3 + (nt * 4 + r) * 64] = XCACHED ? gW3[nt][r] + gW3b[XCACHED ? nt : 0][r] : gW3[nt][r];
+        for (int r = 0; r < 4; ++r) mine[RS::oW3 + (nt * 4 + r) * 64] = G3B ? gW3[nt][r] + gW3b[G3B ? nt : 0][r] : gW3[nt][r];
 #pragma unroll
       for (int nt = 0; nt < MT2; ++nt) {
         const float v = half_sum(sb2[nt]);
@@ -1856,7 +2015,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int blk = lane >> 2, a = 4 * (blk / QPI3) + r, u = 4 * (blk % QPI3) + (lane & 3) + UPI3 * nt;
-        if (a < m) mine[fo.W3 + a * H2 + u] = XCACHED ? gW3[nt][r] + gW3b[XCACHED ? nt : 0][r] : gW3[nt][r];
+        if (a < m) mine[fo.W3 + a * H2 + u] = G3B ? gW3[nt][r] + gW3b[G3B ? nt : 0][r] : gW3[nt][r];
       }
     float sb2f[MT2];
 #pragma unroll
