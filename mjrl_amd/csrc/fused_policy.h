@@ -1682,6 +1682,10 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       }
       MJX_STAMP(8);
       // delta2 in both layouts: K = actions, the W3 column fragment serves as A (-> lane = sample) and as B (-> lane = unit)
+      // (K1, r06: ONE layout like the cached product -- the lane = unit copy the gW2 product needs takes a trip through LDS in
+      //  the shadow of the delta1 phase, into bufA where h2^T is dead by then, and arrives with its (1 - h2^2) factor applied:
+      //  8 matrix instructions, 32 packed factor instructions and 8 fragment reads less per tile)
+      constexpr bool T2L = (MODE == MODE_VPG) && PINNED;
       f32x16 dl2s[MT2], dl2u[MT2];
 #pragma unroll
       for (int mt = 0; mt < MT2; ++mt) { dl2s[mt] = (f32x16)(0.f); dl2u[mt] = (f32x16)(0.f); }
@@ -1691,7 +1695,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         for (int mt = 0; mt < MT2; ++mt) {
           float w = slotA[L.oW3 + unit_of(sidx, hi) * S3 + 32 * mt + j];
           dl2s[mt] = MJX_MFMA(w, d3r[sidx], dl2s[mt]);
-          dl2u[mt] = MJX_MFMA(d3r[sidx], w, dl2u[mt]);
+          if (!T2L) dl2u[mt] = MJX_MFMA(d3r[sidx], w, dl2u[mt]);
         }
       }
 #pragma unroll
@@ -1712,10 +1716,12 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         const float* brow = &bufA[(4 * uq3 + (lane & 3)) * ST];
         // delta2u *= (1 - h2^2): h2[sample unit_of(4q+t, hi)][unit 32nt + j] from the [unit][sample] copy
         f32x4 fc[MT2][4];
+        if constexpr (!T2L) {
 #pragma unroll
         for (int nt = 0; nt < MT2; ++nt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) fc[nt][q] = *(const f32x4*)&bufA[(32 * nt + j) * ST + 8 * q + 4 * hi];
+        }
         if constexpr (G3B) {
 #pragma unroll
           for (int sp = 0; sp < 4; ++sp) {                 // sample quads 2 sp (-> gW3) and 2 sp + 1 (-> gW3b), instruction by instruction
@@ -1744,6 +1750,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
             for (int nt = 0; nt < NT3; ++nt) gW3[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[t], bv[nt][t], gW3[nt], 0, 0, 0);
         }
         }
+        if constexpr (!T2L) {
 #pragma unroll
         for (int nt = 0; nt < MT2; ++nt)
 #pragma unroll
@@ -1753,16 +1760,19 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
               const f32x2 v = mul_1mh2_pair(dl2u[nt][4 * q + t], dl2u[nt][4 * q + t + 1], fc[nt][q][t], fc[nt][q][t + 1]);
               dl2u[nt][4 * q + t] = v.x; dl2u[nt][4 * q + t + 1] = v.y;
             }
+        }
       }
 #pragma unroll
       for (int r = 0; r < RA; ++r) sb3r[r] += d3r[r];   // grad b3[a] = sum_s d3[s][a]: per-lane partial sums, reduced over the lanes after the tile loop
       // grad b2[32nt + j] = sum over this tile's samples (16 registers x 2 lane halves)
+      if constexpr (!T2L) {
 #pragma unroll
       for (int nt = 0; nt < MT2; ++nt) {
         float sacc = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc += dl2u[nt][r];
         sb2[nt] += sacc;                            // the two lane halves are summed once, after the tile loop
+      }
       }
       MJX_STAMP(10);
       // gW2[u2][u1] += sum_s delta2[s][u2] * h1[s][u1]; delta1u = (delta2 W2)(1 - h1^2), lane = h1 unit.
@@ -1798,19 +1808,68 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int nt = 0; nt < MT1; ++nt) dl1u[nt] = MJX_MFMA(dl2s[kb][4 * q + t], wc[t][nt], dl1u[nt]);
+          if constexpr (T2L) {
+            constexpr int NGH = NG / 2;
+            if (g < NGH) {
+              // this group's share of the transposed copy: 16 MT2 / NGH registers of delta2 (LDS executes one wave's operations in order)
+              constexpr int RS = 16 * MT2 / NGH;
+#pragma unroll
+              for (int e = 0; e < RS; ++e) {
+                const int idx = g * RS + e, mt = idx >> 4, r = idx & 15;
+                LDS_AT(pinA[4 * mt + (r >> 2)])[(r & 3) * ST] = dl2s[mt][r];
+              }
+            } else {
+              // ... and of the read-back: delta2[sample unit_of(4 qq + t, hi)][unit 32 nt + j], one ds_read_b128 per (nt, qq)
+              constexpr int RQ = (4 * MT2 + NGH - 1) / NGH;
+#pragma unroll
+              for (int e = 0; e < RQ; ++e) {
+                const int idx = (g - NGH) * RQ + e;
+                if (idx < 4 * MT2) {
+                  const int nt = idx >> 2, qq = idx & 3;
+                  const f32x4 v = *(const f32x4*)&bufA[(32 * nt + j) * ST + 8 * qq + 4 * hi];
+                  dl2u[nt][4 * qq] = v.x; dl2u[nt][4 * qq + 1] = v.y; dl2u[nt][4 * qq + 2] = v.z; dl2u[nt][4 * qq + 3] = v.w;
+                }
+              }
+            }
+          }
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int nt = 0; nt < MT1; ++nt) wc[t][nt] = wn[t][nt];
         }
         // pipeline: prologue reads, then per group [reads of g+1][MFMAs of g]
+        if constexpr (T2L) {
+          constexpr int NGH = NG / 2;
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT1, 0);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT1, 0);      // (the ds_read_b32 pair up as ds_read2_b32)
+#pragma unroll
+            for (int i = 0; i < 4 * MT1; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (g < NGH) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+              else if (i < (4 * MT2 + NGH - 1) / NGH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+          }
+        } else {
         __builtin_amdgcn_sched_group_barrier(0x100, 4 * MT1, 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 4 * MT1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT1, 0);
         }
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (T2L) {
+          // grad b2[32 nt + j] += sum over the tile's samples (16 registers x 2 lane halves; the halves are added after the tile loop)
+#pragma unroll
+          for (int nt = 0; nt < MT2; ++nt) {
+            f32x2 s2 = {dl2u[nt][0], dl2u[nt][1]};
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) s2 += f32x2{dl2u[nt][r], dl2u[nt][r + 1]};
+            sb2[nt] += s2.x + s2.y;
+          }
+        }
       }
       MJX_STAMP(11);
       {
