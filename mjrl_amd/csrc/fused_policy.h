@@ -486,8 +486,10 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
     cst[C_SGB * MP + a] = ok ? expf(lsb) : 1.0f;
     cst[C_LSB * MP + a] = lsb;
     cst[C_DK * MP + a] = dk;
-    cst[C_ISG * MP + a] = 1.0f / sga;
-    cst[C_ISGB * MP + a] = 1.0f / cst[C_SGB * MP + a];
+    // (0 for the padding actions a >= m: their z is then 0 whatever the action registers hold -- the likelihood head takes
+    //  the loaded values as they are, no select per action and sample)
+    cst[C_ISG * MP + a] = ok ? 1.0f / sga : 0.f;
+    cst[C_ISGB * MP + a] = ok ? 1.0f / cst[C_SGB * MP + a] : 0.f;
     if (MODE == MODE_FVP) {                       // FVP epilogue: d3 = (md + c3) * osc^2 * Dk / N
       const float osc = ok ? csr[2] : 0.f;
       cst[9 * MP + 2 * a] = ok ? csr[6] : 0.f;
@@ -1564,8 +1566,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
       float llA = 0.f;
 #pragma unroll
       for (int a = 0; a < MP; ++a) {
-        const bool ok = valid && (a < m);
-        av[a] = ok ? actr[a] : 0.f;
+        av[a] = actr[a];                              // (a >= m: 1 / sigma reads 0; rows past the batch end: every sum below is masked)
         if constexpr (HK) {
           muv[a] = (oa[a] + kb3[a >> 2][a & 3]) * kosc[a >> 2][a & 3] + kosh[a >> 2][a & 3];
           z[a] = (av[a] - muv[a]) * kisg[a >> 2][a & 3];
