@@ -566,6 +566,23 @@ __global__ void k_pad_rows(const float* __restrict__ src, int rows, int cols, in
     dst[i] = c < cols ? src[r * cols + c] : 0.f;
   }
 }
+// dst[c][r] = src[r][c] (32 x 32 tiles through LDS): the hidden layers' weight blocks in the K-contiguous ("NT") layout the
+// persistent GEMM's delta products run fastest with (r06)
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < cols && r < rows) dst[(int64_t)c * rows + r] = tile[tx][ty + 8 * i];
+  }
+}
 __global__ void k_unpad_rows(const float* __restrict__ src, int rows, int cols, int ld, float* __restrict__ dst) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += gridDim.x * blockDim.x) {
     const int r = i / cols, c = i - r * cols;
@@ -902,6 +919,14 @@ struct LayerwiseWS {
   int64_t cap = 0;                   // rows allocated
   float* Xn = nullptr;               // normalised obs (N x ldx(): rows padded with zeros to a multiple of 4 floats)
   float* V1p = nullptr; float* G1p = nullptr; float* W1p = nullptr;   // first-layer direction / gradient / weight blocks with rows padded the same way (only when ldx() != n)
+  // r06: W_l^T of the hidden layers l >= 1 (made by the forward pass that fills the activation cache, from the same theta): the
+  // delta product delta_l W_l then has its B operand K-contiguous like the tangent products, i.e. runs as k_gemm_p<0, EPI_BACK>
+  // (0.75-0.76 of the fp32-MFMA peak) instead of <1, EPI_BACK> (0.67: one ds_read_b32 per k-step and column instead of a
+  // ds_read_b128 per four).  MJX_LW_WT=0: the weights as they lie.
+  std::vector<float*> Wt;
+  const float* wt_theta = nullptr;
+  static bool wt_on() { static const bool on = [] { const char* e = getenv("MJX_LW_WT"); return !(e && e[0] == '0'); }(); return on; }
+  bool wt_eligible(int l) const { return l >= 1 && l < nL() && sizes[l + 1] >= 64 && (sizes[l + 1] % 32) == 0 && (sizes[l] % 4) == 0 && sizes[l] > 32; }
   // (up to 32 features: whole 16-byte granules; beyond: whole 128-byte k-tiles, so that every k-tile segment of a row is one
   //  cache line and the first layer needs no K tail -- 376 -> 384, 39 -> 64)
   int ldx() const { return n <= 32 ? ((n + 3) & ~3) : ((n + 31) & ~31); }
@@ -929,6 +954,7 @@ struct LayerwiseWS {
     oS = k; d = k + m;
     H.assign(hid.size(), nullptr); T.assign(hid.size(), nullptr);
     P.assign(hid.size(), nullptr); RD.assign(hid.size(), nullptr);
+    Wt.assign(sizes.size(), nullptr);
   }
   void invalidate() { fwd_valid = false; }
   void release() {
@@ -936,6 +962,8 @@ struct LayerwiseWS {
     hipFree(V1p); V1p = nullptr; hipFree(G1p); G1p = nullptr; hipFree(W1p); W1p = nullptr;
     for (auto& p : H) { hipFree(p); p = nullptr; }
     for (auto& p : T) { hipFree(p); p = nullptr; }
+    for (auto& p : Wt) { hipFree(p); p = nullptr; }
+    wt_theta = nullptr;
     hipFree(mu); hipFree(mu2); hipFree(d3); hipFree(part); hipFree(hpart); hipFree(rd3); rd3 = nullptr; gen_cap = 0;
     hipFree(cpart2); cpart2 = nullptr; cpart2_cap = 0;
     if (side) { (void)hipStreamDestroy(side); side = nullptr; }
@@ -964,6 +992,8 @@ struct LayerwiseWS {
       if (hipMalloc(&H[l], (size_t)newcap * hid[l] * 4) != hipSuccess) return 2;
       if (hipMalloc(&T[l], (size_t)newcap * hid[l] * 4) != hipSuccess) return 2;
     }
+    for (int l = 1; l < nL(); ++l)
+      if (wt_eligible(l) && hipMalloc(&Wt[l], (size_t)sizes[l] * sizes[l + 1] * 4) != hipSuccess) return 2;
     if (hipMalloc(&mu, (size_t)newcap * m * 4) != hipSuccess) return 2;
     if (hipMalloc(&mu2, (size_t)newcap * m * 4) != hipSuccess) return 2;
     if (hipMalloc(&d3, (size_t)newcap * m * 4) != hipSuccess) return 2;
@@ -1174,6 +1204,14 @@ struct LayerwiseWS {
   void forward(const float* theta, const float* tr, const float* obs, int64_t N, std::vector<float*>& acts, float* out,
                hipStream_t st) {
     hipLaunchKernelGGL(k_normalize, dim3(ew_grid(N * ldx())), dim3(256), 0, st, obs, N, n, ldx(), tr, Xn);
+    if (&acts == &H) {                               // the pass that fills the activation cache also transposes this theta's hidden weight blocks
+      wt_theta = nullptr;
+      if (wt_on()) {
+        for (int l = 1; l < nL(); ++l)
+          if (Wt[l]) hipLaunchKernelGGL(k_transpose, dim3((sizes[l] + 31) / 32, (sizes[l + 1] + 31) / 32), dim3(256), 0, st, theta + oW[l], sizes[l + 1], sizes[l], Wt[l]);
+        wt_theta = theta;
+      }
+    }
     const float* in = Xn;
     for (int l = 0; l < nL(); ++l) {
       const bool last = (l == nL() - 1);
@@ -1286,6 +1324,7 @@ struct LayerwiseWS {
         b.M = (int)N; b.N = hi_; b.npairs = 1; b.K[0] = ho;
         b.A[0] = delta; b.a_rs[0] = ho; b.a_ks[0] = 1;
         b.B[0] = theta + oW[l]; b.b_cs[0] = 1; b.b_ks[0] = hi_;
+        if (Wt[l] && wt_theta == theta && N >= 2 * GP_BM) { b.B[0] = Wt[l]; b.b_cs[0] = ho; b.b_ks[0] = 1; }      // W_l^T: B(k, j) = Wt[j][k]
         b.C = T[l - 1]; b.ldc = hi_; b.c_zs = 0;
         b.aux = H[l - 1]; b.ld_aux = hi_;
         b.epi = EPI_BACK;
