@@ -254,6 +254,8 @@ struct FusedLayout {
   int oXS, oXT, oD3, oBA, oBB, WAVE;            // per-wave scratch
   int oTR, oCST, oWAVES, TOTAL;
   static constexpr int NCST = 13;               // osc, osh, sigma, log_std (new) ; the same for old ; Dk = 2/(2 sigma^2 + 1e-8) ; {c3, osc^2 Dk / N} pairs ; 1/sigma new, old
+                                                // (MODE_EVAL keeps mean_kl's per-action constants in the rows only the other modes read: 2, 8, 9, 10 --
+                                                //  the 16-action 64 x 64 instance with 17 observations sits exactly AT the 160 KB limit, no row to spare)
   // eval_only: the layout of MODE_EVAL launches -- no backward pass, so a wave's scratch is just the raw image of its
   // observation tile (3.2 KB instead of 25 KB at HalfCheetah shapes); the workgroup then needs ~64 KB and TWO of them
   // share a CU, i.e. two waves per SIMD: one wave's tanh / likelihood VALU work runs under the other's MFMAs
@@ -469,7 +471,8 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
 
   // ---------------- per-action constants (LDS, broadcast reads) ----------------
   float* cst = lds + L.oCST;
-  enum { C_OSC = 0, C_OSH = 1, C_SG = 2, C_LS = 3, C_OSCB = 4, C_OSHB = 5, C_SGB = 6, C_LSB = 7, C_DK = 8, C_ISG = 11, C_ISGB = 12 };   // (9, 10: the FVP's {c3, scale} pairs)
+  enum { C_OSC = 0, C_OSH = 1, C_SG = 2, C_LS = 3, C_OSCB = 4, C_OSHB = 5, C_SGB = 6, C_LSB = 7, C_DK = 8, C_ISG = 11, C_ISGB = 12,   // (9, 10: the FVP's {c3, scale} pairs)
+         C_RD = 8, C_SO2 = 9, C_SN2 = 10, C_KD = 2 };       // MODE_EVAL only: 1 / Dr, sigma_old^2, sigma_new^2, log_std_new - log_std_old (over C_DK, the FVP pairs, C_SG)
   if (tid < MP) {
     const int a = tid;
     const bool ok = a < m;
@@ -490,6 +493,19 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
     //  the loaded values as they are, no select per action and sample)
     cst[C_ISG * MP + a] = ok ? 1.0f / sga : 0.f;
     cst[C_ISGB * MP + a] = ok ? 1.0f / cst[C_SGB * MP + a] : 0.f;
+    if (MODE == MODE_EVAL) {
+      // mean_kl (gaussian_mlp.py:135-145): what does not depend on the sample is formed once -- 1 / Dr with fast_div's own
+      // reciprocal + Newton step (the per-sample quotient keeps its bits), sigma^2 of both nets, the log_std difference.
+      // (r06: the head recomputed them per action and sample, 8 quarter-rate reciprocals and ~40 instructions per tile and wave.)
+      const float sgb = cst[C_SGB * MP + a];
+      const float Dr = 2.0f * sga * sga + 1e-8f;
+      float r = __builtin_amdgcn_rcpf(Dr);
+      r = r * fmaf(-Dr, r, 2.0f);
+      cst[C_RD * MP + a] = r;
+      cst[C_SO2 * MP + a] = sgb * sgb;
+      cst[C_SN2 * MP + a] = sga * sga;
+      cst[C_KD * MP + a] = lsa - lsb;
+    }
     if (MODE == MODE_FVP) {                       // FVP epilogue: d3 = (md + c3) * osc^2 * Dk / N
       const float osc = ok ? csr[2] : 0.f;
       cst[9 * MP + 2 * a] = ok ? csr[6] : 0.f;
@@ -1625,10 +1641,9 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
         float kl = 0.f;
 #pragma unroll
         for (int a = 0; a < MP; ++a) {
-          float so = cst[C_SGB * MP + a], sn = cst[C_SG * MP + a];
-          float Nr = (muB[a] - muv[a]) * (muB[a] - muv[a]) + so * so - sn * sn;
-          float Dr = 2.0f * sn * sn + 1e-8f;
-          kl += fast_div(Nr, Dr) + cst[C_LS * MP + a] - cst[C_LSB * MP + a];
+          const float dm = muB[a] - muv[a];
+          const float Nr = (dm * dm + cst[C_SO2 * MP + a]) - cst[C_SN2 * MP + a];
+          kl += Nr * cst[C_RD * MP + a] + cst[C_KD * MP + a];
         }
         if (valid && hi == 0) s_kl += (double)kl;
       } else {
