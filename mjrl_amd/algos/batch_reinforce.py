@@ -345,6 +345,11 @@ class BatchREINFORCE:
         native = getattr(eng, "_stager", None) is None and eng.device.type == "cuda"
         futs, staged = [], {}
         if native:
+            # the policy's four small (synchronous, pageable) uploads go FIRST, while no copy engine is busy: issued under the
+            # staging jobs -- as r04-r06 did -- they wait for a DMA engine whenever the runtime hands them the one that is moving
+            # the 90 MB observation / action blocks: 6.7 ms of `set_policy` in every other call of a process's first ten
+            # (`tools/e2e_timeline.py TL_FIRST=1`, profiles/r06b_bench/e2e_first_calls.log), 0.1 ms here
+            self._push_policy()
             staged = eng.stage_paths(paths, ("observations", "actions"), defer=True)
         else:                                    # (CPU stand-ins, caller-supplied stagers: a helper thread)
             futs = [self._staging_pool().submit(self._stage_on_callers_stream(), paths, ("observations", "actions"))]
@@ -371,7 +376,6 @@ class BatchREINFORCE:
             for f in futs:
                 staged.update(f.result())
             if native:
-                self._push_policy()              # (four small uploads: under the staging jobs, not behind them)
                 ingest.settle(eng.backend)       # the staging jobs have queued their copies; this stream waits for them
         if not native:
             self._push_policy()
