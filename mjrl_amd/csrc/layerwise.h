@@ -595,57 +595,72 @@ __global__ void k_unpad_rows(const float* __restrict__ src, int rows, int cols, 
 // mode 2 (EVAL): partial sums [surr, kl]
 // part: [gridDim.x][2 + MPH] doubles
 constexpr int MPH = 64;   // max action dim of the layer-wise head
-__global__ __launch_bounds__(256) void k_head(int mode, const float* __restrict__ mu, const float* __restrict__ mu_old,
+// r06: ONE pass with the actions on the lanes.  The r01-r05 kernel gave every thread a sample and walked its m actions in a loop
+// (rows of m floats per thread: uncoalesced) -- and, to keep the log_std gradients out of a dynamically indexed register array,
+// it repeated the WHOLE pass over the batch once per four actions: 7 passes at configs[4]'s 28 actions, 2.27 ms per launch for
+// 0.45 GB (K1 and K3 of every update: 4.5 of 226 ms).  Now a wave takes one sample (m > 32) or two (a lane half each) per step: lane a
+// holds action a's element of the row (coalesced loads / stores), the sums over the actions are wave reductions (DPP row sums +
+// v_permlane16_swap / v_permlane32_swap: no LDS), and lane a keeps d log_std[a] in ONE fp64 register for the whole launch.
+// Per element the arithmetic is the old kernel's (the same divisions); the sums over the actions are trees instead of chains, and the
+// likelihood ratio is formed from the per-action DIFFERENCE of the two log-likelihoods (below).
+__device__ __forceinline__ float head_sum32(float v) {       // every lane: the sum over its 32-lane half
+  v = row16_sum(v);
+  auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+constexpr int HEAD_NT = 1024;                            // 16 waves per workgroup: the pass is latency-bound (a row or two per wave step)
+__global__ __launch_bounds__(HEAD_NT) void k_head(int mode, const float* __restrict__ mu, const float* __restrict__ mu_old,
                                               const float* __restrict__ act, const float* __restrict__ adv, int64_t N, int m,
                                               const float* __restrict__ ls_new, const float* __restrict__ ls_old,
                                               const float* __restrict__ osc, float inv_N, float* __restrict__ d3,
                                               double* __restrict__ part) {
   __shared__ double sh[17];
-  __shared__ float sgn[MPH], sgo[MPH], lsn[MPH], lso[MPH];
-  if (threadIdx.x < m) {
-    lsn[threadIdx.x] = ls_new[threadIdx.x]; lso[threadIdx.x] = ls_old[threadIdx.x];
-    sgn[threadIdx.x] = expf(ls_new[threadIdx.x]); sgo[threadIdx.x] = expf(ls_old[threadIdx.x]);
-  }
-  __syncthreads();
+  __shared__ double shg[HEAD_NT / 64][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  const bool wide = m > 32;                      // one sample per wave step; else two (lane half = sample)
+  const int a = wide ? lane : (lane & 31), sub = wide ? 0 : (lane >> 5), SP = wide ? 1 : 2;
+  const bool on = a < m;
+  const float lsn_a = on ? ls_new[a] : 0.f, lso_a = on ? ls_old[a] : 0.f;
+  const float sgn_a = on ? expf(lsn_a) : 1.f, sgo_a = on ? expf(lso_a) : 1.f;
+  const float osc_a = (on && mode == 0) ? osc[a] : 0.f;
+  const float dkl = 2.0f * sgn_a * sgn_a + 1e-8f;
   float sumn = 0.f, sumo = 0.f;
-  for (int a = 0; a < m; ++a) { sumn += lsn[a]; sumo += lso[a]; }
-  double s_surr = 0.0, s_b = 0.0;
-  double gl[4] = {0, 0, 0, 0};                 // log_std grads handled 4 at a time below
-  const float c = 0.5f * (float)m * 1.8378770664093453f;
-  for (int a0 = 0; a0 < ((mode == 0) ? m : 1); a0 += 4) {
-    gl[0] = gl[1] = gl[2] = gl[3] = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
-      float lln = 0.f, llo = 0.f, kl = 0.f;
-      for (int a = 0; a < m; ++a) {
-        float x = act[i * m + a], mn = mu[i * m + a];
-        float zn = (x - mn) / sgn[a];
-        lln = fmaf(-0.5f * zn, zn, lln);
-        if (mu_old) {
-          float mo = mu_old[i * m + a];
-          float zo = (x - mo) / sgo[a];
-          llo = fmaf(-0.5f * zo, zo, llo);
-          float Nr = (mo - mn) * (mo - mn) + sgo[a] * sgo[a] - sgn[a] * sgn[a];
-          kl += Nr / (2.0f * sgn[a] * sgn[a] + 1e-8f) + lsn[a] - lso[a];
-        }
-      }
-      lln = lln - sumn - c;
-      llo = mu_old ? (llo - sumo - c) : lln;
-      float LR = expf(lln - llo), ad = adv[i];
-      if (a0 == 0) { s_surr += (double)(LR * ad); s_b += (mode == 0) ? 1.0 : (double)kl; }
-      if (mode == 0) {
-        float w = ad * LR * inv_N;
-        for (int a = 0; a < m; ++a) {
-          float zn = (act[i * m + a] - mu[i * m + a]) / sgn[a];
-          if (a0 == 0) d3[i * m + a] = osc[a] * (w * zn / sgn[a]);
-          if (a >= a0 && a < a0 + 4) gl[a - a0] += (double)(w * (zn * zn - 1.0f));
-        }
-      }
+  for (int k = 0; k < m; ++k) { sumn += ls_new[k]; sumo += ls_old[k]; }
+  auto asum = [&](float v) { v = head_sum32(v); return wide ? half_sum(v) : v; };
+  double s_surr = 0.0, s_b = 0.0, gl = 0.0;
+  const int64_t nw = (int64_t)gridDim.x * nwv;
+  for (int64_t i0 = ((int64_t)blockIdx.x * nwv + wave) * SP; i0 < N; i0 += nw * SP) {
+    const int64_t i = i0 + sub;
+    const bool row = i < N, ok = on && row;
+    const int64_t e = ok ? i * m + a : 0;
+    const float x = act[e], mn = mu[e];
+    const float zn = ok ? (x - mn) / sgn_a : 0.f;
+    // LL_new - LL_old = sum_a -0.5 (zn - zo)(zn + zo) - (sum log_std_new - sum log_std_old): the DIFFERENCE per action, summed --
+    // not two sums of magnitude ~m/2 + |sum log_std| subtracted afterwards (their fp32 rounding, ~|LL| x 6e-8, went straight into
+    // the likelihood ratio: the old != new gradients sat 5e-6..1.3e-5 from the fp64 oracle because of it)
+    float dll = 0.f, kl = 0.f;
+    if (mu_old) {
+      const float mo = mu_old[e];
+      const float zo = ok ? (x - mo) / sgo_a : 0.f;
+      dll = asum(-0.5f * (zn - zo) * (zn + zo)) - (sumn - sumo);
+      const float Nr = (mo - mn) * (mo - mn) + sgo_a * sgo_a - sgn_a * sgn_a;
+      kl = asum(ok ? Nr / dkl + lsn_a - lso_a : 0.f);
     }
-    if (mode == 0)
-      for (int k = 0; k < 4 && a0 + k < m; ++k) {
-        double t = block_sum(gl[k], sh);
-        if (threadIdx.x == 0) part[(size_t)blockIdx.x * (2 + MPH) + 2 + a0 + k] = t;
-      }
+    const float LR = expf(dll), ad = adv[row ? i : 0];
+    if (a == 0 && row) { s_surr += (double)(LR * ad); s_b += (mode == 0) ? 1.0 : (double)kl; }
+    if (mode == 0 && ok) {
+      const float w = ad * LR * inv_N;
+      d3[e] = osc_a * (w * zn / sgn_a);
+      gl += (double)(w * (zn * zn - 1.0f));
+    }
+  }
+  shg[wave][lane] = gl;
+  __syncthreads();
+  if (mode == 0 && (int)threadIdx.x < m) {       // fixed order: waves, then the two lane halves
+    double t = 0.0;
+    for (int w = 0; w < nwv; ++w)
+      for (int h = 0; h < SP; ++h) t += shg[w][h * 32 + threadIdx.x];
+    part[(size_t)blockIdx.x * (2 + MPH) + 2 + threadIdx.x] = t;
   }
   s_surr = block_sum(s_surr, sh);
   s_b = block_sum(s_b, sh);
@@ -1361,7 +1376,7 @@ struct LayerwiseWS {
     }
     forward(th_new, tr_new, obs, N, H, mu, st);
     fwd_valid = true;
-    hipLaunchKernelGGL(k_head, dim3(HEAD_G), dim3(256), 0, st, 0, mu, mo, act, adv, N, m, th_new + oS, th_old + oS,
+    hipLaunchKernelGGL(k_head, dim3(HEAD_G), dim3(HEAD_NT), 0, st, 0, mu, mo, act, adv, N, m, th_new + oS, th_old + oS,
                        tr_new + 2 * n + m, (float)(1.0 / (double)Ng), d3, hpart);
     hipLaunchKernelGGL(k_reduce_head, dim3(1), dim3(256), 0, st, hpart, HEAD_G, m, 0, scal, grad + oS);
     return backward(th_new, N, grad, st);
@@ -1551,7 +1566,7 @@ struct LayerwiseWS {
     forward(th_old, tr_old, obs, N, T, mu2, st);
     forward(th_new, tr_new, obs, N, T, mu, st);       // hidden activations are scratch here
     fwd_valid = false;
-    hipLaunchKernelGGL(k_head, dim3(HEAD_G), dim3(256), 0, st, 2, mu, mu2, act, adv, N, m, th_new + oS, th_old + oS,
+    hipLaunchKernelGGL(k_head, dim3(HEAD_G), dim3(HEAD_NT), 0, st, 2, mu, mu2, act, adv, N, m, th_new + oS, th_old + oS,
                        tr_new + 2 * n + m, 0.f, (float*)nullptr, hpart);
     hipLaunchKernelGGL(k_reduce_head, dim3(1), dim3(256), 0, st, hpart, HEAD_G, m, 2, scal, (float*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : 1;
