@@ -987,9 +987,19 @@ int mjx_cg_step(mjx_ctx* c, const float* Ap, float damping, double tol, void* st
   if (c->d <= 8 * 1024)
     hipLaunchKernelGGL(k_cg_step_reg<8>, dim3(1), dim3(1024), 0, (hipStream_t)stream, Ap, damping, tol, c->cg_x, c->cg_r, c->cg_p,
                        c->cg_scal, (int)c->d);
-  else
-    hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(1024), 0, (hipStream_t)stream, Ap, damping, tol, c->cg_x, c->cg_r, c->cg_p,
-                       c->cg_z, c->cg_scal, (int)c->d);
+  else {
+    static const bool multi = [] { const char* e = getenv("MJX_CG_MULTI"); return !(e && e[0] == '0'); }();
+    hipStream_t st = (hipStream_t)stream;
+    if (multi && c->d >= 4 * CGM_G) {                   // (the partials fit c->cg_z: d floats >= 2 x CGM_G doubles)
+      // large d: three launches of CGM_G workgroups (vecops.h); c->cg_z serves as their 2 x CGM_G fp64 partials
+      double* part = (double*)c->cg_z;
+      hipLaunchKernelGGL(k_cgm_pz, dim3(CGM_G), dim3(CGM_T), 0, st, Ap, (const float*)c->cg_p, damping, (const double*)c->cg_scal, part, (int)c->d);
+      hipLaunchKernelGGL(k_cgm_xr, dim3(CGM_G), dim3(CGM_T), 0, st, Ap, (const float*)c->cg_p, damping, c->cg_x, c->cg_r, c->cg_scal, part, (int)c->d);
+      hipLaunchKernelGGL(k_cgm_p, dim3(CGM_G), dim3(CGM_T), 0, st, (const float*)c->cg_r, c->cg_p, tol, c->cg_scal, (const double*)part, (int)c->d);
+    } else
+      hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(1024), 0, st, Ap, damping, tol, c->cg_x, c->cg_r, c->cg_p,
+                         c->cg_z, c->cg_scal, (int)c->d);
+  }
   HIPCHK(hipGetLastError());
   return MJX_OK;
 }

@@ -338,6 +338,65 @@ __global__ __launch_bounds__(1024) void k_cg_step(const float* __restrict__ Ap, 
   }
 }
 
+// The same step for LARGE d (the layer-wise policies: 166 690 parameters at BASELINE configs[3], 297 528 at configs[4]) on many
+// workgroups (r06).  The single-workgroup kernel above walks five d-float vectors through one CU: 286 us per CG iteration at
+// configs[3], 524 us at configs[4] -- 5.9 % / 2.4 % of an NPG update (rocprofv3 over tools/lw_update_trace.py).  Three launches of
+// CGM_G workgroups instead, each phase ending in per-workgroup fp64 partials that EVERY workgroup of the next launch sums in the
+// same fixed order (so all of them hold the same alpha / mu bit for bit); z = Ap + damping p is recomputed where it is used (the same
+// two fp32 operations) instead of being stored.  Scalars that a later phase needs although workgroup 0 rewrites them at its end
+// (rr, the convergence flag) are copied to scal[4..6] by the phase before.
+constexpr int CGM_G = 64, CGM_T = 256;
+__device__ __forceinline__ double cgm_total(const double* part, double* sh) {      // sum of the CGM_G partials, fixed order
+  return block_sum(threadIdx.x < CGM_G ? part[threadIdx.x] : 0.0, sh);
+}
+__global__ __launch_bounds__(CGM_T) void k_cgm_pz(const float* __restrict__ Ap, const float* __restrict__ p, float damping,
+                                                   const double* __restrict__ scal, double* __restrict__ part, int d) {
+  __shared__ double sh[17];
+  double pz = 0.0;
+  if (scal[1] == 0.0)
+    for (int i = blockIdx.x * CGM_T + threadIdx.x; i < d; i += CGM_G * CGM_T) {
+      const float zi = Ap[i] + damping * p[i];        // npg_cg.py:81  hvp_flat + regu_coef*vector
+      pz += (double)p[i] * (double)zi;
+    }
+  pz = block_sum(pz, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = pz;
+}
+__global__ __launch_bounds__(CGM_T) void k_cgm_xr(const float* __restrict__ Ap, const float* __restrict__ p, float damping,
+                                                   float* __restrict__ x, float* __restrict__ r, double* scal, double* part, int d) {
+  __shared__ double sh[17];
+  const double done = scal[1], rr = scal[0];
+  const double pz = cgm_total(part, sh);
+  double nrr = 0.0;
+  if (done == 0.0) {                                  // (converged earlier: cg_solve.py:19-20 `break` -- nothing moves any more)
+    const float alpha = (float)(rr / pz);
+    for (int i = blockIdx.x * CGM_T + threadIdx.x; i < d; i += CGM_G * CGM_T) {
+      const float pi = p[i], zi = Ap[i] + damping * pi;
+      x[i] = fmaf(alpha, pi, x[i]);
+      const float ri = fmaf(-alpha, zi, r[i]);
+      r[i] = ri;
+      nrr += (double)ri * (double)ri;
+    }
+  }
+  nrr = block_sum(nrr, sh);
+  if (threadIdx.x == 0) {
+    part[CGM_G + blockIdx.x] = nrr;
+    if (blockIdx.x == 0) { scal[4] = rr; scal[5] = pz; scal[6] = done; }
+  }
+}
+__global__ __launch_bounds__(CGM_T) void k_cgm_p(const float* __restrict__ r, float* __restrict__ p, double tol, double* scal,
+                                                  const double* __restrict__ part, int d) {
+  __shared__ double sh[17];
+  const double rr = scal[4], pz = scal[5], done = scal[6];
+  const double nrr = cgm_total(part + CGM_G, sh);
+  if (done != 0.0) return;
+  const float mu = (float)(nrr / rr);
+  for (int i = blockIdx.x * CGM_T + threadIdx.x; i < d; i += CGM_G * CGM_T) p[i] = fmaf(mu, p[i], r[i]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[0] = nrr; scal[2] = pz; scal[3] += 1.0;
+    if (nrr < tol) scal[1] = 1.0;
+  }
+}
+
 // the same step for d <= 1024 * EPT with every vector element held in registers: one round of loads, two block
 // reductions, one round of stores (the looped version above pays a global round trip per phase).  Same arithmetic.
 // W > 0: the Fisher-vector product arrives as one slot per rank (peer exchange, W = slots read: world rounded up to a power
