@@ -958,6 +958,11 @@ struct LayerwiseWS {
   hipStream_t side = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;
   double* hpart = nullptr;           // head partials
   bool fwd_valid = false;
+  int64_t fwd_rows = 0;              // rows the cached activations cover (a binding narrowed to a prefix keeps them: mjx_bind_rows)
+  // r06: `mu` as left by surr_vpg with old == new IS the old policy's output for rows [0, mu_rows) of `mu_obs` until something
+  // overwrites it: the evaluations that close an update (K3, TRPO's trials, DAPG's surr_before) reuse it instead of running the
+  // old network again -- the fused path's "ocache", for the layer-wise path.  Only the one-call updates ask for it (eval(old_cached)).
+  bool mu_valid = false; int64_t mu_rows = 0; const float* mu_obs = nullptr;
   int nL() const { return (int)sizes.size() - 1; }   // number of affine layers
 
   void init(int n_, int m_, const std::vector<int>& hid) {
@@ -972,6 +977,7 @@ struct LayerwiseWS {
     Wt.assign(sizes.size(), nullptr);
   }
   void invalidate() { fwd_valid = false; }
+  void narrow(int64_t N) { if (N > fwd_rows) fwd_valid = false; }      // fewer rows of the same batch: the prefix of the cache stays valid
   void release() {
     hipFree(Xn); Xn = nullptr;
     hipFree(V1p); V1p = nullptr; hipFree(G1p); G1p = nullptr; hipFree(W1p); W1p = nullptr;
@@ -990,7 +996,7 @@ struct LayerwiseWS {
   }
   static constexpr int HEAD_G = 512;
   int reserve(int64_t N) {
-    fwd_valid = false;
+    fwd_valid = false; mu_valid = false;
     if (m > MPH) return -3;
     if (N <= cap) return 0;
     int64_t newcap = (N + 127) / 128 * 128;       // whole 128-row tiles: the persistent GEMM (lw_gemm_p.h) reads / writes the padding rows
@@ -1375,7 +1381,8 @@ struct LayerwiseWS {
       mo = mu2;
     }
     forward(th_new, tr_new, obs, N, H, mu, st);
-    fwd_valid = true;
+    fwd_valid = true; fwd_rows = N;
+    mu_valid = old_is_new != 0; mu_rows = N; mu_obs = obs;
     hipLaunchKernelGGL(k_head, dim3(HEAD_G), dim3(HEAD_NT), 0, st, 0, mu, mo, act, adv, N, m, th_new + oS, th_old + oS,
                        tr_new + 2 * n + m, (float)(1.0 / (double)Ng), d3, hpart);
     hipLaunchKernelGGL(k_reduce_head, dim3(1), dim3(256), 0, st, hpart, HEAD_G, m, 0, scal, grad + oS);
@@ -1384,7 +1391,7 @@ struct LayerwiseWS {
 
   int fvp(const float* obs, int64_t N, int64_t Ng, const float* theta, const float* tr, const float* v, float* out, hipStream_t st) {
     if (N > cap) return 1;
-    if (!fwd_valid) { forward(theta, tr, obs, N, H, mu, st); fwd_valid = true; }
+    if (!fwd_valid || N > fwd_rows) { forward(theta, tr, obs, N, H, mu, st); fwd_valid = true; fwd_rows = N; mu_valid = false; }
     // tangent pass
     const float* tin = nullptr;
     for (int l = 0; l < nL(); ++l) {
@@ -1492,7 +1499,7 @@ struct LayerwiseWS {
     const float inv_N = (float)(1.0 / (double)Ng);
     forward(th_old, tr_old, obs, N, T, mu2, st);          // old means (hidden activations are scratch)
     forward(th_new, tr_new, obs, N, H, mu, st);
-    fwd_valid = true;
+    fwd_valid = true; fwd_rows = N; mu_valid = false;
     // R-forward: T_l = (in V_l^T + T_{l-1} W_l^T + c_l)(1 - H_l^2), rd3 = out_scale (.. + c_L)
     const float* tin = nullptr;
     for (int l = 0; l < nL(); ++l) {
@@ -1560,13 +1567,26 @@ struct LayerwiseWS {
     return hipGetLastError() == hipSuccess ? 0 : 1;
   }
 
+  // old_cached: the caller vouches that theta_old / tr_old / obs are what surr_vpg saw (the one-call updates: nothing outside the
+  // library runs between their K1 and their evaluations); old_is_new: theta_new == theta_old as well (DAPG's surr_before)
   int eval(const float* obs, const float* act, const float* adv, int64_t N, const float* th_new, const float* th_old,
-           const float* tr_new, const float* tr_old, double* scal, hipStream_t st) {
+           const float* tr_new, const float* tr_old, double* scal, hipStream_t st, bool old_cached = false, bool old_is_new = false) {
     if (N > cap) return 1;
-    forward(th_old, tr_old, obs, N, T, mu2, st);
-    forward(th_new, tr_new, obs, N, T, mu, st);       // hidden activations are scratch here
-    fwd_valid = false;
-    hipLaunchKernelGGL(k_head, dim3(HEAD_G), dim3(HEAD_NT), 0, st, 2, mu, mu2, act, adv, N, m, th_new + oS, th_old + oS,
+    static const bool reuse_on = [] { const char* e = getenv("MJX_LW_OLD_OUTPUTS"); return !(e && e[0] == '0'); }();
+    const float *mnew = mu, *mold = mu2;
+    if (reuse_on && old_cached && mu_valid && obs == mu_obs && N <= mu_rows) {
+      if (old_is_new) { mnew = mu; mold = nullptr; }                    // LR = 1, KL = 0: no network runs at all; the caches stay
+      else {
+        forward(th_new, tr_new, obs, N, T, mu2, st);                    // (hidden activations are scratch; `mu` keeps the old outputs)
+        fwd_valid = false;
+        mnew = mu2; mold = mu;
+      }
+    } else {
+      forward(th_old, tr_old, obs, N, T, mu2, st);
+      forward(th_new, tr_new, obs, N, T, mu, st);       // hidden activations are scratch here
+      fwd_valid = false; mu_valid = false;
+    }
+    hipLaunchKernelGGL(k_head, dim3(HEAD_G), dim3(HEAD_NT), 0, st, 2, mnew, mold, act, adv, N, m, th_new + oS, th_old + oS,
                        tr_new + 2 * n + m, 0.f, (float*)nullptr, hpart);
     hipLaunchKernelGGL(k_reduce_head, dim3(1), dim3(256), 0, st, hpart, HEAD_G, m, 2, scal, (float*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -105,6 +105,8 @@ struct mjx_ctx {
   float* dbg = nullptr;
   long long* clk = nullptr;        // launch clock stamps (mjx_set_clock_buffer)
   unsigned fvp_seq = 0;            // products since the cache was filled / the last solve began: alternate sweep direction
+  bool lw_old_ok = false;          // layer-wise path: K1's outputs are the OLD policy's (old == new at K1, theta_old / batch untouched since by this library);
+                                   // set by mjx_surr_vpg, cleared by the public binding calls, consumed by the one-call updates' evaluations
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;   // pairs
   size_t prof_used = 0;
@@ -384,6 +386,7 @@ int mjx_bind_batch(mjx_ctx* c, const float* obs, const float* act, const float* 
   c->ocache_valid = false;
   c->ximg_ok = false;
   c->lw.invalidate();
+  c->lw_old_ok = false;
   if (!c->fused) {
     // the layer-wise launches put one 128-row tile per grid row: gridDim.y <= 65 535 -> 8 388 480 rows per context (BASELINE
     // configs[4] at its full 8M + demonstrations fits; beyond that, shard the batch -- element and byte offsets are 64-bit throughout)
@@ -398,13 +401,22 @@ int mjx_bind_rows(mjx_ctx* c, int64_t N_local, int64_t N_global, const float* ad
   if (N_local < 0 || N_local > c->rows_bound || N_global < N_local || N_global <= 0) return fail(MJX_ERR_ARG, "bad row count");
   c->N_local = N_local; c->N_global = N_global;
   if (adv) c->adv = adv;
-  c->lw.invalidate();
+  c->lw.narrow(N_local);                        // (r06: a prefix of the bound rows keeps the activations cached for it -- DAPG's on-policy prefix)
   return MJX_OK;
 }
 
+static int bind_policy_impl(mjx_ctx* c, const float* theta_new, const float* theta_old, const float* tr_new,
+                            const float* tr_old, int old_is_new, bool keep_old_outputs);
 int mjx_bind_policy(mjx_ctx* c, const float* theta_new, const float* theta_old, const float* tr_new,
                     const float* tr_old, int old_is_new) {
+  return bind_policy_impl(c, theta_new, theta_old, tr_new, tr_old, old_is_new, false);
+}
+// keep_old_outputs: the one-call updates re-bind (stepped parameters, the SAME old parameters) between their K1 and their
+// evaluations -- the old policy's cached outputs stay usable; a caller's own binding may come with new contents under the same pointers
+static int bind_policy_impl(mjx_ctx* c, const float* theta_new, const float* theta_old, const float* tr_new,
+                            const float* tr_old, int old_is_new, bool keep_old_outputs) {
   if (!c || !theta_new || !theta_old) return fail(MJX_ERR_ARG, "bad policy");
+  if (c && !(keep_old_outputs && theta_old == c->theta_old && tr_old == c->tr_old)) c->lw_old_ok = false;
   if ((((uintptr_t)theta_new) | ((uintptr_t)theta_old)) & 15) return fail(MJX_ERR_ARG, "parameter vectors must be 16-byte aligned");
   c->theta_new = theta_new; c->theta_old = theta_old; c->tr_new = tr_new; c->tr_old = tr_old;
   c->old_is_new = old_is_new ? 1 : 0;
@@ -797,10 +809,13 @@ static int surr_vpg_impl(mjx_ctx* c, float* grad_out, double* scal_out, void* st
     HIPCHK(hipMemsetAsync(scal_out, 0, 4 * sizeof(double), st));
     return MJX_OK;
   }
-  if (!c->fused)
-    return c->lw.surr_vpg(c->obs, c->act, c->adv, c->N_local, c->N_global, c->theta_new, c->theta_old,
-                          c->tr_new ? c->tr_new : c->ident_tr, c->tr_old ? c->tr_old : c->ident_tr, c->old_is_new,
-                          grad_out, scal_out, st) ? fail(MJX_ERR_STATE, "layer-wise surr_vpg failed") : MJX_OK;
+  if (!c->fused) {
+    if (c->lw.surr_vpg(c->obs, c->act, c->adv, c->N_local, c->N_global, c->theta_new, c->theta_old,
+                       c->tr_new ? c->tr_new : c->ident_tr, c->tr_old ? c->tr_old : c->ident_tr, c->old_is_new,
+                       grad_out, scal_out, st)) return fail(MJX_ERR_STATE, "layer-wise surr_vpg failed");
+    c->lw_old_ok = c->old_is_new != 0;          // its output block now holds the old policy's means for the bound rows
+    return MJX_OK;
+  }
   FusedArgs a = make_args(c, c->theta_old);
   c->hcache_valid = false;
   c->ximg_ok = false;
@@ -898,7 +913,7 @@ int mjx_fvp(mjx_ctx* c, const float* v, float* out, void* stream) { return fvp_i
 
 // pp (peer exchange): the reduction of K3's sums writes them into slot `rank` of every buffer (scal_out IS the own slot) and raises
 // the flags; the caller launches the consumer (k_peer_sum<double>)
-static int eval_impl(mjx_ctx* c, double* scal_out, void* stream, const PeerPush* pp) {
+static int eval_impl(mjx_ctx* c, double* scal_out, void* stream, const PeerPush* pp, bool old_ok = false) {
   if (int rc = check_bound(c, true)) return rc;
   if (!scal_out) return fail(MJX_ERR_ARG, "null output");
   hipStream_t st = (hipStream_t)stream;
@@ -906,7 +921,8 @@ static int eval_impl(mjx_ctx* c, double* scal_out, void* stream, const PeerPush*
   if (c->N_local == 0) { HIPCHK(hipMemsetAsync(scal_out, 0, 4 * sizeof(double), st)); return MJX_OK; }
   if (!c->fused)
     return c->lw.eval(c->obs, c->act, c->adv, c->N_local, c->theta_new, c->theta_old,
-                      c->tr_new ? c->tr_new : c->ident_tr, c->tr_old ? c->tr_old : c->ident_tr, scal_out, st)
+                      c->tr_new ? c->tr_new : c->ident_tr, c->tr_old ? c->tr_old : c->ident_tr, scal_out, st,
+                      old_ok && c->lw_old_ok, c->old_is_new != 0)
                ? fail(MJX_ERR_STATE, "layer-wise eval failed") : MJX_OK;
   FusedArgs a = make_args(c, c->theta_old);
   if (c->ocache_valid && c->N_local <= c->ocache_rows) { a.ocache = c->ocache; a.snap = c->snap; }
@@ -1127,6 +1143,7 @@ int vpg_and_rank_sums(mjx_ctx* c, float* grad_out, double* s4, bool need_s4_sum,
 }
 
 // K3 and the rank sum of its 4 doubles (peer exchange: the push rides on the reduction kernel)
+// (one-call updates only: their evaluations may use the old policy's outputs K1 left -- nothing outside the library ran in between)
 int eval_and_rank_sum(mjx_ctx* c, double* res4, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (c->peer.on && c->fused && c->N_local > 0) {
@@ -1138,7 +1155,7 @@ int eval_and_rank_sum(mjx_ctx* c, double* res4, void* stream) {
     HIPCHK(hipGetLastError());
     return MJX_OK;
   }
-  if (int rc = mjx_eval_surr_kl(c, res4, stream)) return rc;
+  if (int rc = eval_impl(c, res4, stream, nullptr, true)) return rc;
   if (has_ranks(c)) if (int rc = mjx_comm_allreduce(c, res4, 4, 1, stream)) return rc;
   return MJX_OK;
 }
@@ -1291,7 +1308,7 @@ int mjx_npg_update(mjx_ctx* c, int iters, float damping, double tol, double step
   // (theta_out == theta_new: the stepped parameters are written by the solve's LAST kernel, after every product has read theta)
   if (int rc = cg_solve_impl(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream, folded ? &gs : nullptr, results + 4,
                              fin_step(base, theta_out, results + 9, step_size, const_alpha, min_log_std))) return rc;
-  if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc;
+  if (int rc = bind_policy_impl(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0, true)) return rc;
   return eval_and_rank_sum(c, results, stream);
 }
 
@@ -1313,7 +1330,7 @@ int mjx_trpo_update(mjx_ctx* c, int iters, float damping, double tol, double ste
     hipLaunchKernelGGL(k_trpo_try, dim3((c->d + 255) / 256), dim3(256), 0, st, c->theta_old, x_out, results, step_size,
                        (first && t == 0) ? 1 : 0, min_log_std, theta_out, (int)c->d, c->oS);
     HIPCHK(hipGetLastError());
-    if (first && t == 0) { if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc; }
+    if (first && t == 0) { if (int rc = bind_policy_impl(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0, true)) return rc; }
     if (int rc = eval_and_rank_sum(c, results, stream)) return rc;
     hipLaunchKernelGGL(k_trpo_check, dim3(1), dim3(64), 0, st, results, kl_dist, (double)c->N_global);
     HIPCHK(hipGetLastError());
@@ -1342,7 +1359,7 @@ int mjx_dapg_update(mjx_ctx* c, int iters, float damping, double tol, double ste
   if (int rc = eval_and_rank_sum(c, results + 4, stream)) return rc;                   // surr_before (theta_new == theta_old)
   if (int rc = cg_solve_impl(c, grad_out, iters, damping, tol, x_out, results + 8, nullptr, nullptr, stream, nullptr, nullptr,
                              fin_step(c->theta_old, theta_out, results + 9, step_size, std::nan(""), min_log_std))) return rc;
-  if (int rc = mjx_bind_policy(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0)) return rc;
+  if (int rc = bind_policy_impl(c, theta_out, c->theta_old, c->tr_new, c->tr_old, 0, true)) return rc;
   return eval_and_rank_sum(c, results, stream);
 }
 

@@ -25,3 +25,15 @@ for _ in range(a.updates):
     e.npg_update(cg, 1e-4, 0.05, -3.0)
     torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
 print(json.dumps({"cfg": a.cfg, "rows": N, "cg_iters": cg, "update_ms": ts}))
+if os.environ.get("DAPG") == "1":           # ... and one DAPG update: [N on-policy ; 5 000 demonstration] rows (dapg.py:92-121)
+    nd = 5000
+    obs2 = torch.cat([obs, obs[:nd]]); act2 = torch.cat([act, act[:nd]]); adv2 = torch.cat([adv, torch.full((nd,), 0.01, device="cuda")])
+    e.set_policy(th, th, ident, ident); e.set_batch(obs2, act2, adv2)
+    e.dapg_update(cg, 1e-4, 0.05, -3.0, N, adv); torch.cuda.synchronize()
+    td = []
+    for _ in range(a.updates):
+        e.set_policy(th, th, ident, ident)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        e.dapg_update(cg, 1e-4, 0.05, -3.0, N, adv)
+        torch.cuda.synchronize(); td.append(1e3 * (time.perf_counter() - t0))
+    print(json.dumps({"cfg": a.cfg, "dapg_update_ms": td}))
