@@ -1504,6 +1504,42 @@ def test_one_upload_per_batch_shared_by_update_and_baselines():
     eng.close()
 
 
+def test_large_d_cg_update_on_many_workgroups_breaks_like_the_reference():
+    """r06: beyond 8 192 parameters the CG vector update runs as three launches of 64 workgroups (csrc/vecops.h k_cgm_*); the
+    residual test of cg_solve.py:19-20 (`break`) is decided on the device: with a tolerance the solve reaches after a few
+    iterations every later product must leave x untouched -- same x as the oracle's loop, which really breaks."""
+    import torch
+    from mjrl_amd.engine import UpdateEngine
+    n, m, hid, N = 23, 5, (128, 128), 6000 + 7
+    rng = np.random.RandomState(77)
+    obs, act, adv = rng.randn(N, n), rng.randn(N, m), rng.randn(N)
+    th = synth.perturbed_params(synth.init_params(n, m, hid), scale=0.05)
+    assert th.size > 8192
+    ident = np.concatenate([np.zeros(n), np.ones(n), np.zeros(m), np.ones(m)]).astype(np.float32)
+    eng = UpdateEngine(n, m, hid)
+    assert not eng.fused
+    eng.set_policy(th, th, ident, ident)
+    eng.set_batch(obs, act, adv)
+    g, _ = eng.surr_vpg()
+    g64 = g.cpu().numpy().astype(np.float64)
+    hv = lambda p: O.fvp(th.astype(np.float64), obs, p, n, m, hid, O.Transforms(n, m), damping=0.1)
+    # the residual after each of 12 iterations (fp64): pick a tolerance that the k-th iteration is the first to reach
+    res, x, r = [], np.zeros_like(g64), g64.copy()
+    p_, rr = r.copy(), r.dot(r)
+    for _ in range(12):
+        z = hv(p_); a = rr / p_.dot(z); x += a * p_; r -= a * z
+        new = r.dot(r); p_ = r + (new / rr) * p_; rr = new; res.append(rr)
+    k = next(i for i in range(3, 10) if res[i] < 0.5 * min(res[:i]))    # (the residual is not monotone: a drop below everything before it)
+    tol = float(np.sqrt(res[k] * min(res[:k])))
+    assert res[k] < tol < min(res[:k])
+    x_ref = O.cg_solve(hv, g64, 12, residual_tol=tol)
+    x_dev, _ = eng.cg_solve(g, 12, 0.1, tol=tol)
+    assert rel(x_dev.cpu().numpy(), x_ref) < TOL_STEP
+    x_all = O.cg_solve(hv, g64, 12)                               # (the unbroken solve really differs)
+    assert rel(x_all, x_ref) > 10 * TOL_STEP
+    eng.close()
+
+
 def test_device_step_length_matches_host_formula():
     """mjx_apply_npg_step: alpha = sqrt(|delta / (g.x + 1e-20)|) formed on the device (fp64) and applied == the host
     formula of npg_cg.py:133 followed by mjx_apply_step, bit for bit, incl. the log_std clamp."""
