@@ -54,6 +54,8 @@ struct FusedArgs {
   float* ocache;         // old-policy outputs [tile][MP + 1][32]: mean per action + log-likelihood; written by MODE_VPG
                          // (old == new), read by MODE_EVAL when thetaB / trB still equal `snap`
   const float* snap;     // [d + 2n + 2m] parameters and transforms the ocache was computed with
+  int snap_trusted;      // MODE_EVAL: the caller vouches that thetaB / trB / trA still equal `snap` (the one-call updates: nothing
+                         // outside the library ran since K1) -- the bit-exact compare in the prologue is skipped (~4 us per launch)
   float* snap_out;       // MODE_VPG: the kernel writes that snapshot (thetaB | trB) while it fills the ocache
   int n, m;
   int raw_dr;            // > 0: the gradient partial of a workgroup is written in ACCUMULATOR order (RawSlab<..>::DR floats per
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_EVAL && !DBG && MP <= 8) ? 2 : 1
   // MODE_EVAL: the old policy's per-sample outputs of this batch may still be around from MODE_VPG (same update);
   // they are used only if the old parameters and transforms are bit-identical to the ones they were computed with.
   int mism = 0, mismx = 0;
-  if (MODE == MODE_EVAL && A.ocache) {
+  if (MODE == MODE_EVAL && A.ocache && !A.snap_trusted) {
     for (int idx = tid; idx < fo.d; idx += 256) mism |= (A.thetaB[idx] != A.snap[idx]);
     for (int idx = tid; idx < 2 * (n + m); idx += 256) mism |= (A.trB[idx] != A.snap[fo.d + idx]);
     // K1's normalised-observation image (in the forward-activation cache) may stand in for staging + normalising the raw

@@ -105,8 +105,9 @@ struct mjx_ctx {
   float* dbg = nullptr;
   long long* clk = nullptr;        // launch clock stamps (mjx_set_clock_buffer)
   unsigned fvp_seq = 0;            // products since the cache was filled / the last solve began: alternate sweep direction
-  bool lw_old_ok = false;          // layer-wise path: K1's outputs are the OLD policy's (old == new at K1, theta_old / batch untouched since by this library);
-                                   // set by mjx_surr_vpg, cleared by the public binding calls, consumed by the one-call updates' evaluations
+  bool lw_old_ok = false;          // K1's outputs are the OLD policy's (old == new at K1; theta_old, its transform and the batch untouched since by this
+                                   // library): set by mjx_surr_vpg, cleared by the public binding calls, consumed by the one-call updates' evaluations
+                                   // (layer-wise path: reuse of the output block; fused path: the snapshot compare of K3's prologue is skipped)
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;   // pairs
   size_t prof_used = 0;
@@ -252,7 +253,7 @@ FusedArgs make_args(mjx_ctx* c, const float* thetaB) {
   a.dbg = c->dbg;
   a.clk = c->clk;
   a.reverse = 0;
-  a.hcache = nullptr; a.ocache = nullptr; a.snap = nullptr; a.snap_out = nullptr;
+  a.hcache = nullptr; a.ocache = nullptr; a.snap = nullptr; a.snap_out = nullptr; a.snap_trusted = 0;
   a.n = c->n; a.m = c->m;
 #ifdef MJX_PHASE_CLOCK
   a.raw_dr = c->raw_perm ? c->raw_dr : 0;
@@ -416,7 +417,7 @@ int mjx_bind_policy(mjx_ctx* c, const float* theta_new, const float* theta_old, 
 static int bind_policy_impl(mjx_ctx* c, const float* theta_new, const float* theta_old, const float* tr_new,
                             const float* tr_old, int old_is_new, bool keep_old_outputs) {
   if (!c || !theta_new || !theta_old) return fail(MJX_ERR_ARG, "bad policy");
-  if (c && !(keep_old_outputs && theta_old == c->theta_old && tr_old == c->tr_old)) c->lw_old_ok = false;
+  if (c && !(keep_old_outputs && theta_old == c->theta_old && tr_old == c->tr_old && tr_new == c->tr_new)) c->lw_old_ok = false;
   if ((((uintptr_t)theta_new) | ((uintptr_t)theta_old)) & 15) return fail(MJX_ERR_ARG, "parameter vectors must be 16-byte aligned");
   c->theta_new = theta_new; c->theta_old = theta_old; c->tr_new = tr_new; c->tr_old = tr_old;
   c->old_is_new = old_is_new ? 1 : 0;
@@ -847,6 +848,8 @@ static int surr_vpg_impl(mjx_ctx* c, float* grad_out, double* scal_out, void* st
       a.ocache = c->ocache; c->ocache_valid = true; c->ocache_rows = c->N_local;
     }
   }
+  // (the one-call updates' evaluations may trust the snapshot without comparing: they run before anything outside the library can)
+  c->lw_old_ok = c->old_is_new != 0 && a.ocache != nullptr;
   if (int rc = dispatch_fused(c, MODE_VPG, a, st)) return rc;
   if ((c->d & 3) == 0 || a.raw_dr > 0) {
     // the 4 sums are reduced by one extra workgroup of the vector reduction (r06: no launch of their own)
@@ -925,7 +928,7 @@ static int eval_impl(mjx_ctx* c, double* scal_out, void* stream, const PeerPush*
                       old_ok && c->lw_old_ok, c->old_is_new != 0)
                ? fail(MJX_ERR_STATE, "layer-wise eval failed") : MJX_OK;
   FusedArgs a = make_args(c, c->theta_old);
-  if (c->ocache_valid && c->N_local <= c->ocache_rows) { a.ocache = c->ocache; a.snap = c->snap; }
+  if (c->ocache_valid && c->N_local <= c->ocache_rows) { a.ocache = c->ocache; a.snap = c->snap; a.snap_trusted = (old_ok && c->lw_old_ok) ? 1 : 0; }
   // K1's normalised-observation image of this batch (same rows, same observations; the kernel checks the input transform
   // against the snapshot before it trusts it) spares K3 the staging and normalisation of the raw observations
   const bool ximg_on = [] { const char* e = getenv("MJX_K3_XIMG"); return !(e && e[0] == '0'); }();
@@ -1150,7 +1153,7 @@ int eval_and_rank_sum(mjx_ctx* c, double* res4, void* stream) {
     const uint32_t seq = ++c->peer.seq;
     const int par = (int)(seq & 1u);
     const PeerPush pp = peer_push(c, par, seq);
-    if (int rc = eval_impl(c, (double*)peer_slot(c, c->peer.rank, par, c->peer.rank), stream, &pp)) return rc;
+    if (int rc = eval_impl(c, (double*)peer_slot(c, c->peer.rank, par, c->peer.rank), stream, &pp, true)) return rc;
     hipLaunchKernelGGL(k_peer_sum<double>, dim3(1), dim3(256), 0, st, peer_slots(c, par, seq), res4, (int64_t)4);
     HIPCHK(hipGetLastError());
     return MJX_OK;
