@@ -65,4 +65,30 @@ for it in range(60):
     rss.append(proc.memory_info().rss); mem.append(torch.cuda.memory_allocated())
 out["npg_mlp_baseline"] = dict(seconds=round(time.perf_counter() - t0, 2), host_rss_MB_at_10=round(rss[10] / 2**20, 1), host_rss_MB_last=round(rss[-1] / 2**20, 1),
                                host_rss_MB_max=round(max(rss) / 2**20, 1), dev_mem_MB_at_10=round(mem[10] / 2**20, 1), dev_mem_MB_last=round(mem[-1] / 2**20, 1))
+# r06: the layer-wise path under the same loop (a 128 x 128 policy, d > 8 192: the multi-workgroup CG update, the one-pass likelihood head,
+# the old-output reuse of the one-call updates) -- NPG and TRPO with batches of changing size
+for name, cls, kw in (("npg_layerwise_128x128", NPG, dict(normalized_step_size=0.05)), ("trpo_layerwise_128x128", TRPO, dict(kl_dist=0.01))):
+    pol = MLP(spec, hidden_sizes=(128, 128), seed=1, init_log_std=-0.5)
+    bl = QuadraticBaseline(spec)
+    agent = cls(None, pol, bl, **kw)
+    assert not agent.engine.fused
+    mem = []
+    t0 = time.perf_counter()
+    for it in range(40):
+        n_traj = int(rng.randint(20, 120))
+        paths = []
+        for _ in range(n_traj):
+            T = int(rng.randint(1, 1000))
+            obs = rng.randn(T, 17)
+            act = pol.model.forward(np.float32(obs)) + np.exp(pol.log_std_val) * rng.randn(T, 6)
+            paths.append(dict(observations=obs, actions=act, rewards=-np.sum(act ** 2, axis=1) + rng.randn(T) * 0.1, terminated=bool(T < 999)))
+        process_samples.compute_returns(paths, 0.995)
+        process_samples.compute_advantages(paths, bl, 0.995, 0.97)
+        stats = agent.train_from_paths(paths)
+        bl.fit(paths)
+        assert np.all(np.isfinite(pol.get_param_values())) and np.all(np.isfinite(stats)), (name, it)
+        assert 0.0 <= agent.last_update["kl_dist"] < 0.2, (name, it, agent.last_update)
+        mem.append(torch.cuda.memory_allocated())
+    out[name] = dict(seconds=round(time.perf_counter() - t0, 2), mem_at_10_MB=round(mem[10] / 2**20, 1), mem_last_MB=round(mem[-1] / 2**20, 1),
+                     mem_max_MB=round(max(mem) / 2**20, 1), final_log_std=float(np.mean(pol.log_std_val)))
 print(json.dumps(out))
